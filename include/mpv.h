@@ -1,0 +1,197 @@
+/* mpv.h -- C ABI of libmpv_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * mPLUG-Video pre-train hot path.
+ *
+ * The reference (X-PLUG/Youku-mPLUG) has no FFI/plugin layer: its hot path reaches native code
+ * only through PyTorch/cuBLAS/cuDNN, megatron_util's fused CUDA kernels and DeepSpeed's
+ * FusedAdam.  Each entry point below names the reference call site(s) whose native work it
+ * replaces (paths relative to the reference repo root).  The Python host side
+ * (youku-mplug_amd/) binds these with ctypes; see INTEGRATION.md for the binding a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *  - All tensor pointers are device pointers owned by the caller (PyTorch); bf16 unless noted.
+ *    The library never allocates user-visible memory: scratch is passed in (workspace + size,
+ *    with a *_workspace_size query).
+ *  - Every call takes the hipStream_t to launch on and is asynchronous.
+ *  - Return 0 on success, negative MPV_E_* otherwise; mpv_last_error() returns a thread-local
+ *    message.  Nothing aborts.
+ *  - Re-entrant; no global mutable state besides the thread-local error string.
+ *  - Row maps: logical row r lives at physical row (r / group) * stride + (r % group) + offset;
+ *    group == 0 means identity.  They address the token rows of the [B,T,1+N,D] ViT stream
+ *    (one cls slot per frame) and the abstractor's K/V buffer with its extra bias-kv token.
+ */
+#ifndef MPV_H_
+#define MPV_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* mpv_stream_t; /* == hipStream_t */
+
+#define MPV_OK 0
+#define MPV_E_SHAPE (-1)
+#define MPV_E_ALIGN (-2)
+#define MPV_E_ARCH (-3)
+#define MPV_E_HIP (-4)
+#define MPV_E_ARG (-5)
+
+#define MPV_ACT_NONE 0
+#define MPV_ACT_GELU_ERF 1  /* nn.GELU, models/vision_transformer.py:94,99 */
+#define MPV_ACT_GELU_TANH 2 /* megatron bias_gelu_impl, models/modeling_distributed_gpt3.py:586-588 */
+
+int mpv_version(void);
+const char* mpv_last_error(void);
+/* 0 if the current device is gfx950, MPV_E_ARCH otherwise */
+int mpv_check_device(void);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM: C[M,N] = epilogue(sum_k A(m,k) B(n,k)), bf16 in, fp32 accumulate (MFMA 32x32x16).
+ * transA=0: A is [M][K] (lda); transA=1: A is [K][M].  transB=0: B is [N][K] (nn.Linear
+ * weight); transB=1: B is [K][N].  (0,0)=forward, (0,1)=dgrad, (1,1)=wgrad (split-K inside).
+ * Replaces: F.linear / nn.Linear (models/vision_transformer.py:104,108,175,205,250),
+ * nn.MultiheadAttention projections (:353), visual_fc (models/distributed_gpt3.py:111,136),
+ * mpu.Column/RowParallelLinear + LM head (models/modeling_distributed_gpt3.py:562,573,843,852,
+ * 1348), bias_gelu (:586-588), bias_dropout_add (:953-979), and their autograd backward. */
+typedef struct mpv_gemm_epilogue {
+  int a_group, a_stride, a_offset; /* row map on A rows (transA=0 only)                     */
+  int c_group, c_stride, c_offset; /* row map on C / residual / preact rows                  */
+  int k_group, k_stride, k_offset; /* row map on the reduction rows (transposed operands)    */
+  const void* bias;                /* bf16 [N] or NULL                                        */
+  int act;                         /* MPV_ACT_*: y = act(bf16(acc + bias))                    */
+  void* preact_out;                /* optional bf16 copy of (acc + bias) before act (ldc)     */
+  const void* residual;            /* optional bf16 [.,N] added last (leading dim ldr)        */
+  int64_t ldr;
+  const void* act_bwd_z; /* optional bf16 z [M][ldz]: multiply by act'(z) (GELU backward)    */
+  int64_t ldz;
+  int act_bwd;     /* MPV_ACT_* selecting act' for act_bwd_z                                  */
+  float dropout_p; /* dropout on (acc + bias) before the residual add                         */
+  uint64_t seed, offset;
+  const float* alpha_dev; /* optional device scalar multiplier                                */
+  float alpha;            /* host scalar multiplier (0 -> 1)                                  */
+  int out_f32;            /* C is fp32 (no epilogue besides alpha / accumulate)               */
+  int accumulate;         /* C += result                                                      */
+} mpv_gemm_epilogue;
+
+size_t mpv_gemm_workspace_size(int64_t M, int64_t N, int64_t K, int transA, int transB);
+int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                  int64_t ldc, int transA, int transB, const mpv_gemm_epilogue* ep, void* workspace,
+                  size_t workspace_bytes, mpv_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm, fp32 statistics, bf16 in/out.  Replaces LayerNormWithForceFP32
+ * (models/vision_transformer.py:69-71) and megatron MixedFusedLayerNorm
+ * (models/modeling_distributed_gpt3.py:1002,1016,1131).  x rows use xmap, y rows use ymap. */
+int mpv_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
+                      int64_t rows, int64_t cols, int64_t ldx, int64_t ldy, float eps, int x_group, int x_stride,
+                      int x_offset, int y_group, int y_stride, int y_offset, mpv_stream_t stream);
+size_t mpv_layernorm_bwd_workspace_size(int64_t cols);
+/* dx[xmap(r)] = (dres ? dres[xmap(r)] : 0) + LNbwd(dy[ymap(r)]); dx may alias dres.
+ * dx_drop (optional) = dx * keepmask/(1-p) with element index offset + r*cols + c.
+ * dgamma/dbeta (bf16 [cols]) may be NULL (frozen GPT: dgrad only); workspace needed if not. */
+int mpv_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
+                      const void* dres, void* dx, void* dx_drop, float drop_p, uint64_t seed, uint64_t offset,
+                      void* dgamma, void* dbeta, int accumulate_dparams, int64_t rows, int64_t cols, int64_t ldx,
+                      int64_t ldy, int x_group, int x_stride, int x_offset, int y_group, int y_stride, int y_offset,
+                      void* workspace, size_t workspace_bytes, mpv_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused attention (scores never materialised), exact two-pass softmax in fp32, MFMA QK^T / PV.
+ * Replaces: ViT Attention core (models/vision_transformer.py:179-204: q*scale rounded to bf16,
+ * fp32 scores+softmax, bf16 probs), GPT3CoreAttention (models/modeling_distributed_gpt3.py:
+ * 757-804: baddbmm + scale/causal-mask(-10000)/softmax + dropout + bmm), nn.MultiheadAttention
+ * core of AttentionPool (models/vision_transformer.py:353,371).
+ * Element (b,h,row,d) of tensor X lives at X + b*x_bs + h*x_hs + row*x_rs + d. head_dim in
+ * {64,80,96}.  lse is fp32 [batch][heads][sq]. */
+typedef struct mpv_attn_desc {
+  const void *q, *k, *v;
+  void* o;
+  float* lse;
+  int64_t q_bs, q_hs, q_rs, k_bs, k_hs, k_rs, v_bs, v_hs, v_rs, o_bs, o_hs, o_rs;
+  int batch, heads, sq, sk, head_dim;
+  int causal;       /* key j visible to query i iff j <= i + (sk - sq) */
+  float scale;      /* softmax(scale * q.k)                            */
+  int scale_q_bf16; /* 1: q' = bf16(q*scale) first (ViT numerics)      */
+  float dropout_p;  /* on the probabilities                            */
+  uint64_t seed, offset;
+} mpv_attn_desc;
+int mpv_attn_fwd(const mpv_attn_desc* d, mpv_stream_t stream);
+/* dO has o's strides; dq/dk/dv have q/k/v's strides; delta is fp32 scratch [batch][heads][sq]. */
+int mpv_attn_bwd(const mpv_attn_desc* d, const void* dO, void* dq, void* dk, void* dv, float* delta,
+                 mpv_stream_t stream);
+
+/* Divided space-time "temporal" attention: T<=16 tokens per (b,n) sequence, many tiny
+ * problems (models/vision_transformer.py:247-248 with Attention :169-207).  qkv is the packed
+ * [rows][3*D] projection in stream layout; sequence (o,i) (o<n_outer, i<n_inner) has its token
+ * t at row o*outer_stride + inner_offset + i + t*t_stride.  out/dout are [rows][D]. */
+int mpv_temporal_attn_fwd(const void* qkv, void* out, int n_outer, int64_t outer_stride, int n_inner,
+                          int64_t inner_offset, int64_t t_stride, int T, int heads, int head_dim, float scale,
+                          mpv_stream_t stream);
+int mpv_temporal_attn_bwd(const void* qkv, const void* dout, void* dqkv, int n_outer, int64_t outer_stride,
+                          int n_inner, int64_t inner_offset, int64_t t_stride, int T, int heads, int head_dim,
+                          float scale, mpv_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Patch-embed fold: video [B,3,T,H,W] bf16 -> im2col rows (b,t,ph,pw) x (c,i,j) padded to kpad
+ * columns (models/vision_transformer.py:546-548,392-398; models/eva_vit.py:197-203 for P=14). */
+int mpv_im2col_patches(const void* video, void* cols, int B, int C, int T, int H, int W, int P, int kpad,
+                       mpv_stream_t stream);
+/* Token assembly: X[b,t,0] = cls + pos[0]; X[b,t,1+n] = patch[(b,t,n)] + pos[1+n] + temporal[t]
+ * (models/vision_transformer.py:555-565) into the [B,T,1+N,D] stream. */
+int mpv_vit_embed_assemble_fwd(const void* patch, const void* cls_token, const void* pos_embed,
+                               const void* temporal_embed, void* x, int B, int T, int N, int D, mpv_stream_t stream);
+/* dpatch [B*T*N, D], dcls [D], dpos [1+N, D], dtemporal [T, D] from dx [B,T,1+N,D]. */
+int mpv_vit_embed_assemble_bwd(const void* dx, void* dpatch, void* dcls, void* dpos, void* dtemporal, int B, int T,
+                               int N, int D, mpv_stream_t stream);
+/* cls merge after spatial attention (models/vision_transformer.py:263-270): for every b,
+ * m = mean_t a[b,t,0,:];  y[b,t,0,:] = xt[b,t,0,:] + m.  Token rows: y = xt + a (all rows). */
+int mpv_vit_cls_merge_fwd(const void* xt, const void* a, void* y, int B, int T, int N1, int D, mpv_stream_t stream);
+/* backward: dxt = dy (all rows); da[token rows] = dy; da[b,t,0] = (sum_t' dy[b,t',0]) / T. */
+int mpv_vit_cls_merge_bwd(const void* dy, void* da, int B, int T, int N1, int D, mpv_stream_t stream);
+
+/* copy `rows` rows of `cols` bf16 between row-mapped buffers */
+int mpv_copy_rows(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds, int64_t ldd, int s_group,
+                  int s_stride, int s_offset, int d_group, int d_stride, int d_offset, mpv_stream_t stream);
+/* out[c] = sum_r in[map(r)][c] (bf16 in, fp32 accumulate, bf16 out, optional accumulate):
+ * bias gradients and broadcast-parameter gradients. */
+size_t mpv_colsum_workspace_size(int64_t cols);
+int mpv_colsum(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld, int group, int stride, int offset,
+               int accumulate, void* workspace, size_t workspace_bytes, mpv_stream_t stream);
+/* out = a + b (bf16, n elements); used for gradient joins */
+int mpv_add(const void* a, const void* b, void* out, int64_t n, mpv_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GPT-3 embedding front: h[b,s,:] = (s < Q ? query[b,s,:] : wte[ids[b,s-Q],:]) + wpe[s,:], then
+ * dropout (models/distributed_gpt3.py:155-156; models/modeling_distributed_gpt3.py:640-666). */
+int mpv_gpt_embed_fwd(const void* query, const int64_t* ids, const void* wte, const void* wpe, void* h, int B,
+                      int Q, int L, int H, float dropout_p, uint64_t seed, uint64_t offset, mpv_stream_t stream);
+/* dquery[b,q,:] = dh[b,q,:] * keepmask/(1-p) */
+int mpv_gpt_embed_bwd(const void* dh, void* dquery, int B, int Q, int L, int H, float dropout_p, uint64_t seed,
+                      uint64_t offset, mpv_stream_t stream);
+
+/* Masked cross-entropy over bf16 logits in fp32 (models/modeling_distributed_gpt3.py:1352-1359,
+ * 1615-1617): losses[r] = lse(logits[r]) - logits[r][labels[r]];  if dlogits != NULL it is
+ * filled with (softmax - onehot) * weight[r] (weight = loss_mask / sum(loss_mask)), may alias
+ * logits.  loss_sum (fp32 scalar, pre-zeroed) accumulates sum_r losses[r]*weight[r]. */
+int mpv_cross_entropy(const void* logits, const int64_t* labels, const float* weight, float* losses, float* loss_sum,
+                      void* dlogits, int64_t rows, int64_t vocab, int64_t ld, mpv_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimizer (DeepSpeed FusedAdam + global-norm clip, run_pretrain_distributed_gpt3.py:137;
+ * math of optim/adamw.py:66-115; torch.nn.utils.clip_grad_norm_ semantics, utils.py:308).
+ * sumsq (fp32 scalar, pre-zeroed) += sum g^2 over n bf16 gradients. */
+int mpv_grad_sumsq(const void* grad, int64_t n, float* sumsq, mpv_stream_t stream);
+/* One AdamW step over a flat range: master/m/v fp32, grad bf16, param bf16 written back.
+ * clip coefficient = min(1, max_norm / (sqrt(*sumsq) * inv_world ... ) computed in-kernel from
+ * the device scalar; grad_scale multiplies g first (1/world for averaged all-reduce sums). */
+int mpv_adamw_step(void* param_bf16, float* master, float* exp_avg, float* exp_avg_sq, const void* grad_bf16,
+                   int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                   float grad_scale, const float* sumsq, float max_norm, mpv_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPV_H_ */

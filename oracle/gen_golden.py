@@ -1,0 +1,75 @@
+"""TEST INFRASTRUCTURE ONLY -- generate tests/golden/*.pt from the reference's own modules.
+
+Usage (this container only; needs /root/reference):
+    python -m oracle.gen_golden tiny        # full tensors, CONFIG_TINY, B=2, L=8 (ragged mask)
+    python -m oracle.gen_golden configA     # BASELINE.json configs[0]: 1.3B dims, B=2, T=4, L=16
+
+For each case the reference DistributedGPT3_Pretrain (models/distributed_gpt3.py:31-226) is
+run in eval() mode (dropout off -- SURVEY.md section 7 "Dropout parity") in fp32 ("intended
+function") and in bf16 ("reference as run under DeepSpeed bf16"), forward + backward, and a
+compact record is written: loss, per-token losses, (sub-sampled) logits / hidden states /
+visual features, and for every trainable parameter the gradient's L2 norm plus a strided
+sample.  Weights and inputs are NOT stored: they are regenerated bit-identically from
+(cfg, seed) by oracle/weights.py.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+import torch
+
+from .ref_loader import build_reference_model, reference_forward
+from .weights import CONFIG_A, CONFIG_TINY, make_inputs
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+CASES = {
+    # name: (cfg, batch, text_len, weight_seed, input_seed, ragged, logits_stride(seq_from, vocab_step))
+    "tiny": (CONFIG_TINY, 2, 8, 0, 1234, True, (0, 1)),
+    "configA": (CONFIG_A, 2, 16, 0, 1234, False, (128, 50)),
+}
+
+
+def grad_sample(g: torch.Tensor, n: int = 64):
+    f = g.detach().float().reshape(-1)
+    step = max(1, f.numel() // n)
+    return f[::step][:n].clone()
+
+
+def run_case(name: str):
+    cfg, B, L, wseed, iseed, ragged, (sfrom, vstep) = CASES[name]
+    rec = {"meta": dict(case=name, batch=B, text_len=L, weight_seed=wseed, input_seed=iseed,
+                        ragged=ragged, logits_seq_from=sfrom, logits_vocab_step=vstep,
+                        torch=torch.__version__)}
+    for tag, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        t0 = time.time()
+        model, sd = build_reference_model(cfg, wseed, dtype=dtype)
+        video, ids, mask = make_inputs(cfg, B, L, seed=iseed, ragged=ragged)
+        loss, out, input_embeds = reference_forward(model, video.to(dtype), ids, mask, train=False)
+        loss.backward()
+        r = {
+            "loss": loss.detach().float().clone(),
+            "losses": out.losses.detach().float().clone(),
+            "logits": out.logits.detach()[:, sfrom:, ::vstep].float().clone(),
+            "last_hidden_state": out.last_hidden_state.detach()[:, :, ::max(1, cfg.hidden // 256)].float().clone(),
+            "query_features": input_embeds.detach()[:, :cfg.num_queries, ::max(1, cfg.hidden // 256)].float().clone(),
+            "grad_norm": {}, "grad_sample": {},
+        }
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                r["grad_norm"][n] = float(p.grad.float().norm())
+                r["grad_sample"][n] = grad_sample(p.grad)
+        rec[tag] = r
+        print(f"[{name}/{tag}] loss={float(loss):.6f}  {time.time() - t0:.1f}s", flush=True)
+        del model, sd
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    path = os.path.join(GOLDEN_DIR, f"{name}.pt")
+    torch.save(rec, path)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    for c in (sys.argv[1:] or ["tiny"]):
+        run_case(c)

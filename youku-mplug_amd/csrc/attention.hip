@@ -1,0 +1,795 @@
+// attention.hip -- fused attention for gfx950 (CDNA4): scores are never written to HBM.
+//
+// One kernel family serves the four shape classes of the path:
+//   GPT causal self-attention   (Sq=Sk<=208, head_dim 64/80, prob-dropout)
+//   ViT spatial attention       (Sq=Sk=197,  head_dim 96, q pre-scaled in bf16)
+//   AttentionPool cross-attn    (Sq=128, Sk=1+T*196+1, head_dim 96)
+// plus a VALU kernel pair for the divided space-time *temporal* attention (T<=16 tokens,
+// hundreds of thousands of tiny problems, HBM-bound).
+//
+// Layout of the MFMA kernels: a workgroup = 4 waves = 128 query rows (forward, dQ) or 128
+// key rows (dK/dV) of one (batch, head); every wave owns a 32-row tile whose operand
+// fragments stay in registers; the other side streams through LDS in 64-row chunks
+// (register-staged, double-buffered, one barrier per chunk).  QK^T is issued "swapped"
+// (S^T = K Q^T) so a lane owns one query row of the 32x32 score tile: the softmax is
+// lane-local plus one cross-half shuffle, and the probabilities feed the PV MFMA as its
+// B operand straight from registers (the reduction index of an MFMA may be permuted freely
+// as long as both operands agree; V / K^T / Q^T / dO^T fragments are fetched with the gfx950
+// transposing LDS read ds_read_b64_tr_b16 using the matching permutation).
+// Softmax is exact two-pass (pass 1: row max / sum, pass 2: normalised P.V), fp32, which
+// reproduces the reference's "softmax then cast to bf16 then @V" numerics and leaves a
+// per-row log-sum-exp for the backward kernels.
+#include "mpv_common.h"
+#include "mpv_kernels.h"
+
+namespace {
+
+constexpr int CH = 64;          // rows per LDS chunk
+constexpr int ROWB = 208;       // LDS row pitch in bytes (96 bf16 + 16 pad: conflict-free ds_read_b128)
+constexpr int CHUNK_BYTES = CH * ROWB;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+// a wave's DS ops retire in order; wait for them and stop the compiler from moving LDS traffic across
+#define WAVE_SYNC()                                  \
+  do {                                               \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_s_waitcnt(0xc07f);              \
+    __builtin_amdgcn_wave_barrier();                 \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
+
+struct AttnArgs {
+  const bf16 *q, *k, *v;
+  bf16* o;
+  float* lse;
+  long long q_bs, q_hs, q_rs, k_bs, k_hs, k_rs, v_bs, v_hs, v_rs, o_bs, o_hs, o_rs;
+  int heads, sq, sk;
+  int causal;
+  float scale;
+  int scale_q_bf16;
+  float drop_scale;
+  uint32_t drop_thr;
+  uint64_t seed, offset;
+  // backward
+  const bf16* dO;
+  bf16 *dq, *dk, *dv;
+  float* delta;
+};
+
+// ---- chunk staging: 64 rows x HD columns of a [rows][row_stride] bf16 matrix -> LDS -------
+template <int HD>
+struct ChunkStage {
+  static constexpr int NDT = (HD + 31) / 32;
+  static constexpr int CPR = NDT * 4;               // 16-byte chunks per (padded) row
+  static constexpr int NLOAD = (CH * CPR + 255) / 256;
+  i32x4 r[NLOAD];
+
+  __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t src, int tid, int row0, int nrows, long long rs) {
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      const int c = tid + 256 * i;
+      const int row = c / CPR, cc = c - row * CPR;
+      const bool ok = (c < CH * CPR) && (row0 + row < nrows) && (cc * 8 < HD);
+      const uint32_t off = ok ? (uint32_t)(((long long)(row0 + row) * rs + cc * 8) * 2) : 0x80000000u;
+      r[i] = __builtin_amdgcn_raw_buffer_load_b128(src, off, 0, 0);
+    }
+  }
+  // optional in-register transform q' = bf16(q * scale)
+  __device__ __forceinline__ void scale_bf16(float s) {
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      union { i32x4 i; bf16x8 b; } u;
+      u.i = r[i];
+      f32x8 f = cvt8(u.b);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] *= s;
+      u.b = cvt8(f);
+      r[i] = u.i;
+    }
+  }
+  __device__ __forceinline__ void commit(char* lds, int tid) {
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      const int c = tid + 256 * i;
+      const int row = c / CPR, cc = c - row * CPR;
+      if (c < CH * CPR) *(i32x4*)(lds + row * ROWB + cc * 16) = r[i];
+    }
+  }
+};
+
+// fragment with 8 consecutive d for row (lane&31) of 32-row tile `t`, d-step s (ds_read_b128)
+__device__ __forceinline__ bf16x8 frag_rows(const char* lds, int t, int s, int lane) {
+  return *(const bf16x8*)(lds + (t * 32 + (lane & 31)) * ROWB + (s * 16 + (lane >> 5) * 8) * 2);
+}
+// transposed fragment: column d = dt*32 + (lane&31); 8 rows (t*32 + ks*16 + {0..3}+4h, +8) (tr read)
+__device__ __forceinline__ bf16x8 frag_cols(const char* lds, int t, int ks, int dt, int lane) {
+  const int h = lane >> 5;
+  const int rbase = t * 32 + ks * 16 + 4 * h + ((lane & 15) >> 2);
+  const int col = dt * 32 + ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + rbase * ROWB + col * 2));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + (rbase + 8) * ROWB + col * 2));
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo;
+  u.s.b = hi;
+  return u.v;
+}
+// registers of a 32x32 accumulator that form the B-operand for reduction step ks (see header)
+__device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& a, int ks) {
+  f32x8 f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = a[8 * ks + e];
+  return cvt8(f);
+}
+// row index inside a 32-row tile held by accumulator register `reg` of this lane
+__device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// load this lane's B-operand fragments (row = row0 + lane&31, all d) straight from global
+template <int HD>
+__device__ __forceinline__ void load_row_frags(bf16x8 (&f)[HD / 16], const bf16* base, long long rs, int row, int nrows,
+                                               int lane) {
+#pragma unroll
+  for (int s = 0; s < HD / 16; ++s) {
+    union { i32x4 i; bf16x8 b; } u;
+    u.i = i32x4{0, 0, 0, 0};
+    if (row < nrows) u.i = *(const i32x4*)(base + (long long)row * rs + s * 16 + (lane >> 5) * 8);
+    f[s] = u.b;
+  }
+}
+template <int N>
+__device__ __forceinline__ void scale_frags_bf16(bf16x8 (&f)[N], float s) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    f32x8 x = cvt8(f[i]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] *= s;
+    f[i] = cvt8(x);
+  }
+}
+
+__device__ __forceinline__ int last_visible_key(const AttnArgs& p, int qrow) {
+  return p.causal ? min(p.sk - 1, qrow + (p.sk - p.sq)) : p.sk - 1;
+}
+
+// =========================================================================== forward
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
+  constexpr int NS = HD / 16;
+  constexpr int NDT = (HD + 31) / 32;
+  __shared__ __attribute__((aligned(16))) char smem[4 * CHUNK_BYTES];  // [buf][K|V]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int qrow = q0 + (lane & 31);
+  const bf16* qb = p.q + b * p.q_bs + h * p.q_hs;
+  const bf16* kb = p.k + b * p.k_bs + h * p.k_hs;
+  const bf16* vb = p.v + b * p.v_bs + h * p.v_hs;
+  const __amdgpu_buffer_rsrc_t ksrc = make_rsrc(kb, (uint32_t)(((long long)(p.sk - 1) * p.k_rs + HD) * 2));
+  const __amdgpu_buffer_rsrc_t vsrc = make_rsrc(vb, (uint32_t)(((long long)(p.sk - 1) * p.v_rs + HD) * 2));
+
+  bf16x8 qf[NS];
+  load_row_frags<HD>(qf, qb, p.q_rs, qrow, p.sq, lane);
+  float sc = p.scale;
+  if (p.scale_q_bf16) {
+    scale_frags_bf16(qf, p.scale);
+    sc = 1.0f;
+  }
+  // keys needed by this workgroup
+  const int blk_last_q = min(p.sq - 1, blockIdx.x * 128 + 127);
+  const int kmax = last_visible_key(p, blk_last_q);
+  const int nchunk = kmax / CH + 1;
+  const int my_last = last_visible_key(p, qrow);
+
+  ChunkStage<HD> sk_, sv_;
+  float m = -INFINITY, l = 0.f;
+
+  auto scores = [&](const char* kl, int kt, f32x16& s) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+    for (int st = 0; st < NS; ++st) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kl, kt, st, lane), qf[st], s, 0, 0, 0);
+  };
+
+  // ---------------- pass 1: row max and sum
+  sk_.issue(ksrc, tid, 0, p.sk, p.k_rs);
+  sk_.commit(smem, tid);
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    const int cur = c & 1;
+    if (c + 1 < nchunk) sk_.issue(ksrc, tid, (c + 1) * CH, p.sk, p.k_rs);
+    const char* kl = smem + cur * 2 * CHUNK_BYTES;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      f32x16 s;
+      scores(kl, kt, s);
+      float mx = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = c * CH + kt * 32 + acc_row(e, lane);
+        s[e] = key <= my_last ? s[e] * sc : -INFINITY;
+        mx = fmaxf(mx, s[e]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m, mx);
+      if (mn > -INFINITY) {
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sum += __expf(s[e] - mn);
+        sum += __shfl_xor(sum, 32, 64);
+        l = l * __expf(m - mn) + sum;
+        m = mn;
+      }
+    }
+    if (c + 1 < nchunk) sk_.commit(smem + (cur ^ 1) * 2 * CHUNK_BYTES, tid);
+    __syncthreads();
+  }
+  const float inv_l = l > 0.f ? 1.0f / l : 0.f;
+  if (qrow < p.sq && lane < 32 && p.lse) p.lse[(long long)bh * p.sq + qrow] = m + __logf(l);
+
+  // ---------------- pass 2: O = softmax(S) V
+  f32x16 oacc[NDT];
+#pragma unroll
+  for (int d = 0; d < NDT; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+  sk_.issue(ksrc, tid, 0, p.sk, p.k_rs);
+  sv_.issue(vsrc, tid, 0, p.sk, p.v_rs);
+  sk_.commit(smem, tid);
+  sv_.commit(smem + CHUNK_BYTES, tid);
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    const int cur = c & 1;
+    if (c + 1 < nchunk) {
+      sk_.issue(ksrc, tid, (c + 1) * CH, p.sk, p.k_rs);
+      sv_.issue(vsrc, tid, (c + 1) * CH, p.sk, p.v_rs);
+    }
+    const char* kl = smem + cur * 2 * CHUNK_BYTES;
+    const char* vl = kl + CHUNK_BYTES;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      f32x16 s;
+      scores(kl, kt, s);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = c * CH + kt * 32 + acc_row(e, lane);
+        float pr = key <= my_last ? __expf(s[e] * sc - m) * inv_l : 0.f;
+        if (p.drop_thr) {
+          const uint64_t idx = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qrow) * (uint64_t)p.sk + (uint64_t)key;
+          pr = mpv_keep(p.seed, idx, p.drop_thr) ? pr * p.drop_scale : 0.f;
+        }
+        s[e] = pr;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 pf = acc_to_frag(s, ks);
+#pragma unroll
+        for (int d = 0; d < NDT; ++d)
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(vl, kt, ks, d, lane), pf, oacc[d], 0, 0, 0);
+      }
+    }
+    if (c + 1 < nchunk) {
+      sk_.commit(smem + (cur ^ 1) * 2 * CHUNK_BYTES, tid);
+      sv_.commit(smem + (cur ^ 1) * 2 * CHUNK_BYTES + CHUNK_BYTES, tid);
+    }
+    __syncthreads();
+  }
+  if (qrow < p.sq) {
+    bf16* orow = p.o + b * p.o_bs + h * p.o_hs + (long long)qrow * p.o_rs;
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int col = d * 32 + 8 * q4 + 4 * (lane >> 5);
+        if (col < HD) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = oacc[d][4 * q4 + e];
+          *(bf16x4*)(orow + col) = cvt4(v);
+        }
+      }
+  }
+}
+
+// =========================================================================== delta = rowsum(dO * O)
+__global__ void attn_delta_kernel(const AttnArgs p, int hd) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
+  if (row >= p.sq) return;
+  const bf16* o = p.o + b * p.o_bs + h * p.o_hs + (long long)row * p.o_rs;
+  const bf16* d = p.dO + b * p.o_bs + h * p.o_hs + (long long)row * p.o_rs;
+  float s = 0.f;
+  for (int c = lane * 2; c < hd; c += 128) s += bf2f(o[c]) * bf2f(d[c]) + bf2f(o[c + 1]) * bf2f(d[c + 1]);
+  s = wave_sum(s);
+  if (lane == 0) p.delta[(long long)bh * p.sq + row] = s;
+}
+
+// =========================================================================== backward: dQ
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
+  constexpr int NS = HD / 16;
+  constexpr int NDT = (HD + 31) / 32;
+  __shared__ __attribute__((aligned(16))) char smem[4 * CHUNK_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int qrow = q0 + (lane & 31);
+  const bf16* qb = p.q + b * p.q_bs + h * p.q_hs;
+  const bf16* kb = p.k + b * p.k_bs + h * p.k_hs;
+  const bf16* vb = p.v + b * p.v_bs + h * p.v_hs;
+  const bf16* dob = p.dO + b * p.o_bs + h * p.o_hs;
+  const __amdgpu_buffer_rsrc_t ksrc = make_rsrc(kb, (uint32_t)(((long long)(p.sk - 1) * p.k_rs + HD) * 2));
+  const __amdgpu_buffer_rsrc_t vsrc = make_rsrc(vb, (uint32_t)(((long long)(p.sk - 1) * p.v_rs + HD) * 2));
+
+  bf16x8 qf[NS], dof[NS];
+  load_row_frags<HD>(qf, qb, p.q_rs, qrow, p.sq, lane);
+  load_row_frags<HD>(dof, dob, p.o_rs, qrow, p.sq, lane);
+  float sc = p.scale;
+  if (p.scale_q_bf16) {
+    scale_frags_bf16(qf, p.scale);
+    sc = 1.0f;
+  }
+  const bool qok = qrow < p.sq;
+  const float lse = qok ? p.lse[(long long)bh * p.sq + qrow] : INFINITY;
+  const float dl = qok ? p.delta[(long long)bh * p.sq + qrow] : 0.f;
+  const int blk_last_q = min(p.sq - 1, blockIdx.x * 128 + 127);
+  const int nchunk = last_visible_key(p, blk_last_q) / CH + 1;
+  const int my_last = last_visible_key(p, qrow);
+
+  f32x16 dqacc[NDT];
+#pragma unroll
+  for (int d = 0; d < NDT; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dqacc[d][e] = 0.f;
+
+  ChunkStage<HD> sk_, sv_;
+  sk_.issue(ksrc, tid, 0, p.sk, p.k_rs);
+  sv_.issue(vsrc, tid, 0, p.sk, p.v_rs);
+  sk_.commit(smem, tid);
+  sv_.commit(smem + CHUNK_BYTES, tid);
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    const int cur = c & 1;
+    if (c + 1 < nchunk) {
+      sk_.issue(ksrc, tid, (c + 1) * CH, p.sk, p.k_rs);
+      sv_.issue(vsrc, tid, (c + 1) * CH, p.sk, p.v_rs);
+    }
+    const char* kl = smem + cur * 2 * CHUNK_BYTES;
+    const char* vl = kl + CHUNK_BYTES;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
+#pragma unroll
+      for (int st = 0; st < NS; ++st) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kl, kt, st, lane), qf[st], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(vl, kt, st, lane), dof[st], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = c * CH + kt * 32 + acc_row(e, lane);
+        const float pr = key <= my_last ? __expf(s[e] * sc - lse) : 0.f;
+        float dpe = dp[e];
+        if (p.drop_thr) {
+          const uint64_t idx = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qrow) * (uint64_t)p.sk + (uint64_t)key;
+          dpe = mpv_keep(p.seed, idx, p.drop_thr) ? dpe * p.drop_scale : 0.f;
+        }
+        s[e] = pr * (dpe - dl);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 dsf = acc_to_frag(s, ks);
+#pragma unroll
+        for (int d = 0; d < NDT; ++d)
+          dqacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(kl, kt, ks, d, lane), dsf, dqacc[d], 0, 0, 0);
+      }
+    }
+    if (c + 1 < nchunk) {
+      sk_.commit(smem + (cur ^ 1) * 2 * CHUNK_BYTES, tid);
+      sv_.commit(smem + (cur ^ 1) * 2 * CHUNK_BYTES + CHUNK_BYTES, tid);
+    }
+    __syncthreads();
+  }
+  if (qok) {
+    bf16* row = p.dq + b * p.q_bs + h * p.q_hs + (long long)qrow * p.q_rs;
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int col = d * 32 + 8 * q4 + 4 * (lane >> 5);
+        if (col < HD) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = dqacc[d][4 * q4 + e] * p.scale;
+          *(bf16x4*)(row + col) = cvt4(v);
+        }
+      }
+  }
+}
+
+// =========================================================================== backward: dK, dV
+template <int HD>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnArgs p) {
+  constexpr int NS = HD / 16;
+  constexpr int NDT = (HD + 31) / 32;
+  // [buf][Q|dO] chunks + [buf][lse|delta] rows
+  __shared__ __attribute__((aligned(16))) char smem[4 * CHUNK_BYTES + 2 * 2 * CH * 4];
+  float* stat = (float*)(smem + 4 * CHUNK_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
+  const int k0 = blockIdx.x * 128 + wave * 32;
+  const int krow = k0 + (lane & 31);
+  const bf16* qb = p.q + b * p.q_bs + h * p.q_hs;
+  const bf16* kb = p.k + b * p.k_bs + h * p.k_hs;
+  const bf16* vb = p.v + b * p.v_bs + h * p.v_hs;
+  const bf16* dob = p.dO + b * p.o_bs + h * p.o_hs;
+  const __amdgpu_buffer_rsrc_t qsrc = make_rsrc(qb, (uint32_t)(((long long)(p.sq - 1) * p.q_rs + HD) * 2));
+  const __amdgpu_buffer_rsrc_t dosrc = make_rsrc(dob, (uint32_t)(((long long)(p.sq - 1) * p.o_rs + HD) * 2));
+
+  bf16x8 kf[NS], vf[NS];
+  load_row_frags<HD>(kf, kb, p.k_rs, krow, p.sk, lane);
+  load_row_frags<HD>(vf, vb, p.v_rs, krow, p.sk, lane);
+  const float sc = p.scale_q_bf16 ? 1.0f : p.scale;
+  const bool kok = krow < p.sk;
+
+  // query rows that can see any key of this workgroup: q >= first_key - (sk - sq) when causal
+  const int first_q = p.causal ? max(0, blockIdx.x * 128 - (p.sk - p.sq)) : 0;
+  const int c_begin = first_q / CH;
+  const int nchunk = (p.sq + CH - 1) / CH;
+
+  f32x16 dkacc[NDT], dvacc[NDT];
+#pragma unroll
+  for (int d = 0; d < NDT; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dkacc[d][e] = dvacc[d][e] = 0.f;
+
+  ChunkStage<HD> sq_, sd_;
+  float st_l = 0.f, st_d = 0.f;
+  auto issue_stats = [&](int c) {
+    if (tid < CH) {
+      const int qr = c * CH + tid;
+      st_l = qr < p.sq ? p.lse[(long long)bh * p.sq + qr] : INFINITY;
+      st_d = qr < p.sq ? p.delta[(long long)bh * p.sq + qr] : 0.f;
+    }
+  };
+  auto commit_stats = [&](int buf) {
+    if (tid < CH) {
+      stat[buf * 2 * CH + tid] = st_l;
+      stat[buf * 2 * CH + CH + tid] = st_d;
+    }
+  };
+  if (c_begin < nchunk) {
+    sq_.issue(qsrc, tid, c_begin * CH, p.sq, p.q_rs);
+    sd_.issue(dosrc, tid, c_begin * CH, p.sq, p.o_rs);
+    issue_stats(c_begin);
+    if (p.scale_q_bf16) sq_.scale_bf16(p.scale);
+    sq_.commit(smem, tid);
+    sd_.commit(smem + CHUNK_BYTES, tid);
+    commit_stats(0);
+  }
+  __syncthreads();
+  for (int c = c_begin; c < nchunk; ++c) {
+    const int cur = (c - c_begin) & 1;
+    if (c + 1 < nchunk) {
+      sq_.issue(qsrc, tid, (c + 1) * CH, p.sq, p.q_rs);
+      sd_.issue(dosrc, tid, (c + 1) * CH, p.sq, p.o_rs);
+      issue_stats(c + 1);
+    }
+    const char* ql = smem + cur * 2 * CHUNK_BYTES;
+    const char* dl = ql + CHUNK_BYTES;
+    const float* sl = stat + cur * 2 * CH;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
+      // S[q][key]: lane owns key (column), registers run over q rows
+#pragma unroll
+      for (int st = 0; st < NS; ++st) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(ql, qt, st, lane), kf[st], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dl, qt, st, lane), vf[st], dp, 0, 0, 0);
+      }
+      f32x16 pd;  // dropped/scaled probabilities for dV
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ql_ = qt * 32 + acc_row(e, lane);
+        const int qr = c * CH + ql_;
+        const int lastk = p.causal ? qr + (p.sk - p.sq) : p.sk - 1;
+        const bool vis = kok && krow <= lastk;
+        const float pr = vis ? __expf(s[e] * sc - sl[ql_]) : 0.f;
+        float keep = 1.0f;
+        if (p.drop_thr) {
+          const uint64_t idx = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qr) * (uint64_t)p.sk + (uint64_t)krow;
+          keep = mpv_keep(p.seed, idx, p.drop_thr) ? p.drop_scale : 0.f;
+        }
+        pd[e] = pr * keep;
+        s[e] = pr * (dp[e] * keep - sl[CH + ql_]);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 pf = acc_to_frag(pd, ks);
+        const bf16x8 dsf = acc_to_frag(s, ks);
+#pragma unroll
+        for (int d = 0; d < NDT; ++d) {
+          dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(dl, qt, ks, d, lane), pf, dvacc[d], 0, 0, 0);
+          dkacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(ql, qt, ks, d, lane), dsf, dkacc[d], 0, 0, 0);
+        }
+      }
+    }
+    if (c + 1 < nchunk) {
+      if (p.scale_q_bf16) sq_.scale_bf16(p.scale);
+      sq_.commit(smem + (cur ^ 1) * 2 * CHUNK_BYTES, tid);
+      sd_.commit(smem + (cur ^ 1) * 2 * CHUNK_BYTES + CHUNK_BYTES, tid);
+      commit_stats(cur ^ 1);
+    }
+    __syncthreads();
+  }
+  if (kok) {
+    bf16* dkrow = p.dk + b * p.k_bs + h * p.k_hs + (long long)krow * p.k_rs;
+    bf16* dvrow = p.dv + b * p.v_bs + h * p.v_hs + (long long)krow * p.v_rs;
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int col = d * 32 + 8 * q4 + 4 * (lane >> 5);
+        if (col < HD) {
+          f32x4 a, c2;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            a[e] = dkacc[d][4 * q4 + e] * sc;
+            c2[e] = dvacc[d][4 * q4 + e];
+          }
+          *(bf16x4*)(dkrow + col) = cvt4(a);
+          *(bf16x4*)(dvrow + col) = cvt4(c2);
+        }
+      }
+  }
+}
+
+// =========================================================================== temporal attention (VALU)
+struct TempArgs {
+  const bf16* qkv;
+  const bf16* dout;
+  bf16* out;
+  bf16* dqkv;
+  int n_outer, n_inner;
+  long long outer_stride, inner_offset, t_stride;
+  int T, heads, hd;
+  float scale;
+};
+
+// one wave per (sequence, head); T <= 16, hd <= 96.  LDS floats per wave: 3*T*(hd+1) + T*(T+1) (+ bwd extras)
+template <bool BWD>
+__global__ __launch_bounds__(256) void temporal_attn_kernel(const TempArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float tsm[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int T = p.T, hd = p.hd, ld = hd + 1, D = p.heads * hd;
+  const int per_wave = (BWD ? 4 : 3) * T * ld + (BWD ? 2 : 1) * T * (T + 1);
+  float* qs = tsm + wave * per_wave;
+  float* ks = qs + T * ld;
+  float* vs = ks + T * ld;
+  float* ps = vs + T * ld;              // [T][T+1] probabilities
+  float* dos = ps + T * (T + 1);        // BWD: dO [T][ld]
+  float* dss = dos + T * ld;            // BWD: dS [T][T+1]
+  const long long nprob = (long long)p.n_outer * p.n_inner * p.heads;
+  for (long long pr = (long long)blockIdx.x * 4 + wave; pr < nprob; pr += (long long)gridDim.x * 4) {
+    const int h = (int)(pr % p.heads);
+    const long long seq = pr / p.heads;
+    const long long o = seq / p.n_inner, i = seq % p.n_inner;
+    const long long row0 = o * p.outer_stride + p.inner_offset + i;
+    const int nvec = T * (hd / 4);
+    for (int x = lane; x < nvec; x += 64) {
+      const int t = x / (hd / 4), c4 = x % (hd / 4);
+      const bf16* src = p.qkv + (row0 + t * p.t_stride) * (3LL * D) + h * hd + c4 * 4;
+      f32x4 qv = cvt4(*(const bf16x4*)src);
+      const f32x4 kv = cvt4(*(const bf16x4*)(src + D));
+      const f32x4 vv = cvt4(*(const bf16x4*)(src + 2 * D));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        qs[t * ld + c4 * 4 + e] = bf2f(f2bf(qv[e] * p.scale));   // q*scale rounds to bf16 (reference :179)
+        ks[t * ld + c4 * 4 + e] = kv[e];
+        vs[t * ld + c4 * 4 + e] = vv[e];
+      }
+      if constexpr (BWD) {
+        const f32x4 dv = cvt4(*(const bf16x4*)(p.dout + (row0 + t * p.t_stride) * (long long)D + h * hd + c4 * 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dos[t * ld + c4 * 4 + e] = dv[e];
+      }
+    }
+    WAVE_SYNC();
+    for (int x = lane; x < T * T; x += 64) {
+      const int a = x / T, bb = x % T;
+      float s = 0.f;
+      for (int d = 0; d < hd; ++d) s += qs[a * ld + d] * ks[bb * ld + d];
+      ps[a * (T + 1) + bb] = s;
+    }
+    WAVE_SYNC();
+    if (lane < T) {
+      float mx = -INFINITY;
+      for (int j = 0; j < T; ++j) mx = fmaxf(mx, ps[lane * (T + 1) + j]);
+      float sum = 0.f;
+      for (int j = 0; j < T; ++j) sum += __expf(ps[lane * (T + 1) + j] - mx);
+      const float inv = 1.0f / sum;
+      for (int j = 0; j < T; ++j) {
+        const float pv = __expf(ps[lane * (T + 1) + j] - mx) * inv;
+        ps[lane * (T + 1) + j] = BWD ? pv : bf2f(f2bf(pv));      // forward: probs cast to bf16 (:201)
+      }
+    }
+    WAVE_SYNC();
+    if constexpr (!BWD) {
+      for (int x = lane; x < T * hd; x += 64) {
+        const int a = x / hd, d = x % hd;
+        float s = 0.f;
+        for (int j = 0; j < T; ++j) s += ps[a * (T + 1) + j] * vs[j * ld + d];
+        p.out[(row0 + a * p.t_stride) * (long long)D + h * hd + d] = f2bf(s);
+      }
+    } else {
+      // dP = dO V^T ; delta = rowsum(P*dP) ; dS = P*(dP - delta)
+      for (int x = lane; x < T * T; x += 64) {
+        const int a = x / T, bb = x % T;
+        float s = 0.f;
+        for (int d = 0; d < hd; ++d) s += dos[a * ld + d] * vs[bb * ld + d];
+        dss[a * (T + 1) + bb] = s;
+      }
+      WAVE_SYNC();
+      if (lane < T) {
+        float dl = 0.f;
+        for (int j = 0; j < T; ++j) dl += ps[lane * (T + 1) + j] * dss[lane * (T + 1) + j];
+        for (int j = 0; j < T; ++j) dss[lane * (T + 1) + j] = ps[lane * (T + 1) + j] * (dss[lane * (T + 1) + j] - dl);
+      }
+      WAVE_SYNC();
+      for (int x = lane; x < T * hd; x += 64) {
+        const int a = x / hd, d = x % hd;
+        float dq = 0.f, dk = 0.f, dv = 0.f;
+        for (int j = 0; j < T; ++j) {
+          dq += dss[a * (T + 1) + j] * ks[j * ld + d];
+          dk += dss[j * (T + 1) + a] * qs[j * ld + d];
+          dv += ps[j * (T + 1) + a] * dos[j * ld + d];
+        }
+        bf16* dst = p.dqkv + (row0 + a * p.t_stride) * (3LL * D) + h * hd + d;
+        dst[0] = f2bf(dq * p.scale);
+        dst[D] = f2bf(dk);
+        dst[2 * D] = f2bf(dv);
+      }
+    }
+    WAVE_SYNC();
+  }
+}
+
+int fill_args(AttnArgs& a, const mpv_attn_desc* d) {
+  a.q = (const bf16*)d->q;
+  a.k = (const bf16*)d->k;
+  a.v = (const bf16*)d->v;
+  a.o = (bf16*)d->o;
+  a.lse = d->lse;
+  a.q_bs = d->q_bs; a.q_hs = d->q_hs; a.q_rs = d->q_rs;
+  a.k_bs = d->k_bs; a.k_hs = d->k_hs; a.k_rs = d->k_rs;
+  a.v_bs = d->v_bs; a.v_hs = d->v_hs; a.v_rs = d->v_rs;
+  a.o_bs = d->o_bs; a.o_hs = d->o_hs; a.o_rs = d->o_rs;
+  a.heads = d->heads;
+  a.sq = d->sq;
+  a.sk = d->sk;
+  a.causal = d->causal;
+  a.scale = d->scale;
+  a.scale_q_bf16 = d->scale_q_bf16;
+  a.drop_thr = d->dropout_p > 0.f ? mpv_drop_threshold(d->dropout_p) : 0;
+  a.drop_scale = d->dropout_p > 0.f ? 1.0f / (1.0f - d->dropout_p) : 1.0f;
+  a.seed = d->seed;
+  a.offset = d->offset;
+  return 0;
+}
+
+int check_desc(const mpv_attn_desc* d, const char* who) {
+  MPV_REQUIRE(d && d->q && d->k && d->v && d->o, MPV_E_ARG, "%s: null pointer", who);
+  MPV_REQUIRE(d->batch > 0 && d->heads > 0 && d->sq > 0 && d->sk > 0, MPV_E_SHAPE, "%s: empty problem", who);
+  MPV_REQUIRE(d->head_dim == 64 || d->head_dim == 80 || d->head_dim == 96, MPV_E_SHAPE,
+              "%s: head_dim %d not in {64,80,96}", who, d->head_dim);
+  MPV_REQUIRE(d->q_rs % 8 == 0 && d->k_rs % 8 == 0 && d->v_rs % 8 == 0 && d->o_rs % 4 == 0 && d->q_hs % 8 == 0 &&
+                  d->k_hs % 8 == 0 && d->v_hs % 8 == 0 && d->o_hs % 4 == 0 && d->q_bs % 8 == 0 && d->k_bs % 8 == 0 &&
+                  d->v_bs % 8 == 0 && d->o_bs % 4 == 0,
+              MPV_E_ALIGN, "%s: strides must keep rows 16-byte aligned", who);
+  MPV_REQUIRE((((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v) & 15) == 0 && ((uintptr_t)d->o & 7) == 0, MPV_E_ALIGN,
+              "%s: q/k/v must be 16-byte aligned", who);
+  MPV_REQUIRE(d->dropout_p >= 0.f && d->dropout_p < 1.f, MPV_E_ARG, "%s: bad dropout_p", who);
+  MPV_REQUIRE(!d->causal || d->sk >= d->sq, MPV_E_SHAPE, "%s: causal needs sk >= sq", who);
+  return MPV_OK;
+}
+
+}  // namespace
+
+extern "C" int mpv_attn_fwd(const mpv_attn_desc* d, hipStream_t stream) {
+  int rc = check_desc(d, "mpv_attn_fwd");
+  if (rc) return rc;
+  AttnArgs a = {};
+  fill_args(a, d);
+  dim3 grid((d->sq + 127) / 128, d->batch * d->heads), block(256);
+  switch (d->head_dim) {
+    case 64: hipLaunchKernelGGL((attn_fwd_kernel<64>), grid, block, 0, stream, a); break;
+    case 80: hipLaunchKernelGGL((attn_fwd_kernel<80>), grid, block, 0, stream, a); break;
+    default: hipLaunchKernelGGL((attn_fwd_kernel<96>), grid, block, 0, stream, a); break;
+  }
+  return mpv_check_launch("mpv_attn_fwd");
+}
+
+extern "C" int mpv_attn_bwd(const mpv_attn_desc* d, const void* dO, void* dq, void* dk, void* dv, float* delta,
+                            hipStream_t stream) {
+  int rc = check_desc(d, "mpv_attn_bwd");
+  if (rc) return rc;
+  MPV_REQUIRE(dO && dq && dk && dv && delta && d->lse, MPV_E_ARG, "mpv_attn_bwd: null pointer");
+  AttnArgs a = {};
+  fill_args(a, d);
+  a.dO = (const bf16*)dO;
+  a.dq = (bf16*)dq;
+  a.dk = (bf16*)dk;
+  a.dv = (bf16*)dv;
+  a.delta = delta;
+  dim3 block(256);
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((d->sq + 3) / 4, d->batch * d->heads), block, 0, stream, a, d->head_dim);
+  dim3 gq((d->sq + 127) / 128, d->batch * d->heads), gk((d->sk + 127) / 128, d->batch * d->heads);
+  switch (d->head_dim) {
+    case 64:
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), gq, block, 0, stream, a);
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<64>), gk, block, 0, stream, a);
+      break;
+    case 80:
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<80>), gq, block, 0, stream, a);
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<80>), gk, block, 0, stream, a);
+      break;
+    default:
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<96>), gq, block, 0, stream, a);
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<96>), gk, block, 0, stream, a);
+      break;
+  }
+  return mpv_check_launch("mpv_attn_bwd");
+}
+
+static int temporal_common(TempArgs& t, int n_outer, int64_t outer_stride, int n_inner, int64_t inner_offset,
+                           int64_t t_stride, int T, int heads, int head_dim, float scale, const char* who) {
+  MPV_REQUIRE(T >= 1 && T <= 16, MPV_E_SHAPE, "%s: T=%d must be in [1,16]", who, T);
+  MPV_REQUIRE(head_dim % 4 == 0 && head_dim <= 96, MPV_E_SHAPE, "%s: head_dim=%d must be a multiple of 4 and <= 96", who, head_dim);
+  MPV_REQUIRE(n_outer > 0 && n_inner > 0 && heads > 0, MPV_E_SHAPE, "%s: empty problem", who);
+  t.n_outer = n_outer;
+  t.n_inner = n_inner;
+  t.outer_stride = outer_stride;
+  t.inner_offset = inner_offset;
+  t.t_stride = t_stride;
+  t.T = T;
+  t.heads = heads;
+  t.hd = head_dim;
+  t.scale = scale;
+  return MPV_OK;
+}
+
+extern "C" int mpv_temporal_attn_fwd(const void* qkv, void* out, int n_outer, int64_t outer_stride, int n_inner,
+                                     int64_t inner_offset, int64_t t_stride, int T, int heads, int head_dim,
+                                     float scale, hipStream_t stream) {
+  MPV_REQUIRE(qkv && out, MPV_E_ARG, "mpv_temporal_attn_fwd: null pointer");
+  TempArgs t = {};
+  int rc = temporal_common(t, n_outer, outer_stride, n_inner, inner_offset, t_stride, T, heads, head_dim, scale,
+                           "mpv_temporal_attn_fwd");
+  if (rc) return rc;
+  t.qkv = (const bf16*)qkv;
+  t.out = (bf16*)out;
+  const size_t lds = 4 * sizeof(float) * (size_t)(3 * T * (head_dim + 1) + T * (T + 1));
+  const long long nprob = (long long)n_outer * n_inner * heads;
+  const int grid = (int)((nprob + 3) / 4 < 8192 ? (nprob + 3) / 4 : 8192);
+  hipLaunchKernelGGL((temporal_attn_kernel<false>), dim3(grid), dim3(256), lds, stream, t);
+  return mpv_check_launch("mpv_temporal_attn_fwd");
+}
+
+extern "C" int mpv_temporal_attn_bwd(const void* qkv, const void* dout, void* dqkv, int n_outer, int64_t outer_stride,
+                                     int n_inner, int64_t inner_offset, int64_t t_stride, int T, int heads,
+                                     int head_dim, float scale, hipStream_t stream) {
+  MPV_REQUIRE(qkv && dout && dqkv, MPV_E_ARG, "mpv_temporal_attn_bwd: null pointer");
+  TempArgs t = {};
+  int rc = temporal_common(t, n_outer, outer_stride, n_inner, inner_offset, t_stride, T, heads, head_dim, scale,
+                           "mpv_temporal_attn_bwd");
+  if (rc) return rc;
+  t.qkv = (const bf16*)qkv;
+  t.dout = (const bf16*)dout;
+  t.dqkv = (bf16*)dqkv;
+  const size_t lds = 4 * sizeof(float) * (size_t)(4 * T * (head_dim + 1) + 2 * T * (T + 1));
+  const long long nprob = (long long)n_outer * n_inner * heads;
+  const int grid = (int)((nprob + 3) / 4 < 8192 ? (nprob + 3) / 4 : 8192);
+  hipLaunchKernelGGL((temporal_attn_kernel<true>), dim3(grid), dim3(256), lds, stream, t);
+  return mpv_check_launch("mpv_temporal_attn_bwd");
+}

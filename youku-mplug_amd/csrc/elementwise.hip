@@ -1,0 +1,395 @@
+// elementwise.hip -- HBM-bound glue kernels of the mPLUG-Video path for gfx950: patch
+// im2col, token assembly (+cls/pos/temporal embeddings), cls merge, row copies, column sums
+// (bias / broadcast-parameter gradients), GPT embedding front and masked cross-entropy.
+// All of them move 8-16 bytes per lane per access, rows contiguous across a wave.
+#include "mpv_common.h"
+#include "mpv_kernels.h"
+
+namespace {
+
+// ---------------------------------------------------------------- im2col for k=s=P patch conv
+// out row r = (b*T + t)*N + ph*PW + pw ; out col = c*P*P + i*P + j ; zero pad to kpad.
+__global__ void im2col_kernel(const bf16* __restrict__ video, bf16* __restrict__ cols, int B, int C, int T, int H, int W,
+                              int P, int kpad) {
+  const int PH = H / P, PW = W / P;
+  const long long rows = (long long)B * T * PH * PW;
+  const int K = C * P * P;
+  const long long total = rows * kpad;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const long long r = idx / kpad;
+    const int kk = (int)(idx - r * kpad);
+    bf16 v = f2bf(0.f);
+    if (kk < K) {
+      const int c = kk / (P * P), ij = kk - c * P * P, i = ij / P, j = ij - i * P;
+      const int pw = (int)(r % PW);
+      const long long r2 = r / PW;
+      const int ph = (int)(r2 % PH);
+      const long long bt = r2 / PH;
+      const int t = (int)(bt % T);
+      const long long b = bt / T;
+      v = video[(((b * C + c) * T + t) * H + (ph * P + i)) * (long long)W + (pw * P + j)];
+    }
+    cols[idx] = v;
+  }
+}
+
+// ---------------------------------------------------------------- token assembly
+__global__ void embed_assemble_fwd_kernel(const bf16* __restrict__ patch, const bf16* __restrict__ cls,
+                                          const bf16* __restrict__ pos, const bf16* __restrict__ temporal,
+                                          bf16* __restrict__ x, int B, int T, int N, int D) {
+  const int D4 = D / 4;
+  const long long total = (long long)B * T * (N + 1) * D4;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % D4);
+    const long long row = idx / D4;
+    const int s = (int)(row % (N + 1));
+    const long long bt = row / (N + 1);
+    const int t = (int)(bt % T);
+    f32x4 v = cvt4(*(const bf16x4*)(pos + (long long)s * D + c4 * 4));
+    if (s == 0) {
+      v += cvt4(*(const bf16x4*)(cls + c4 * 4));
+    } else {
+      // reference order: (tile_pos + tile_temporal) rounded to bf16, then added to the token (:563-565)
+      v += cvt4(*(const bf16x4*)(temporal + (long long)t * D + c4 * 4));
+      v = cvt4(cvt4(v));
+      v += cvt4(*(const bf16x4*)(patch + (bt * N + (s - 1)) * (long long)D + c4 * 4));
+    }
+    *(bf16x4*)(x + row * D + c4 * 4) = cvt4(v);
+  }
+}
+
+// dpos[s] = sum_{b,t} dx[b,t,s]; dcls = dpos[0]; one block per slot s, threads over D.
+__global__ void embed_bwd_pos_kernel(const bf16* __restrict__ dx, bf16* __restrict__ dcls, bf16* __restrict__ dpos, int B,
+                                     int T, int N, int D) {
+  const int s = blockIdx.x;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    float a = 0.f;
+    for (int bt = 0; bt < B * T; ++bt) a += bf2f(dx[((long long)bt * (N + 1) + s) * D + c]);
+    dpos[(long long)s * D + c] = f2bf(a);
+    if (s == 0) dcls[c] = f2bf(a);
+  }
+}
+// dtemporal[t] = sum_{b,n} dx[b,t,1+n]; grid (T, nsplit) with fp32 atomics into a zeroed scratch is
+// avoided: one block per (t, column stripe) loops over b,n.
+__global__ void embed_bwd_temporal_kernel(const bf16* __restrict__ dx, bf16* __restrict__ dtemporal, int B, int T, int N,
+                                          int D) {
+  const int t = blockIdx.x;
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int part = threadIdx.x >> 6;  // 4 waves split the rows
+  __shared__ float red[4][64];
+  float a = 0.f;
+  if (c < D) {
+    for (int b = 0; b < B; ++b)
+      for (int n = part; n < N; n += 4) a += bf2f(dx[(((long long)b * T + t) * (N + 1) + 1 + n) * D + c]);
+  }
+  red[part][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (part == 0 && c < D) dtemporal[(long long)t * D + c] = f2bf(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ---------------------------------------------------------------- cls merge
+// y = xt + a on token rows; on cls slots y[b,t,0] = xt[b,t,0] + mean_t' a[b,t',0].
+__global__ void cls_merge_fwd_kernel(const bf16* __restrict__ xt, const bf16* __restrict__ a, bf16* __restrict__ y, int B,
+                                     int T, int N1, int D) {
+  const int D4 = D / 4;
+  const long long total = (long long)B * T * N1 * D4;
+  const float invT = 1.0f / (float)T;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % D4);
+    const long long row = idx / D4;
+    const int s = (int)(row % N1);
+    f32x4 v;
+    if (s != 0) {
+      v = cvt4(*(const bf16x4*)(a + row * D + c4 * 4));
+    } else {
+      const long long b = row / ((long long)N1 * T);
+      f32x4 m = {0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < T; ++t) m += cvt4(*(const bf16x4*)(a + ((b * T + t) * N1) * (long long)D + c4 * 4));
+      v = cvt4(cvt4(m * invT));  // torch.mean rounds to bf16 before the residual add (:265,270)
+    }
+    v += cvt4(*(const bf16x4*)(xt + row * D + c4 * 4));
+    *(bf16x4*)(y + row * D + c4 * 4) = cvt4(v);
+  }
+}
+__global__ void cls_merge_bwd_kernel(const bf16* __restrict__ dy, bf16* __restrict__ da, int B, int T, int N1, int D) {
+  const int D4 = D / 4;
+  const long long total = (long long)B * T * N1 * D4;
+  const float invT = 1.0f / (float)T;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % D4);
+    const long long row = idx / D4;
+    const int s = (int)(row % N1);
+    bf16x4 o;
+    if (s != 0) {
+      o = *(const bf16x4*)(dy + row * D + c4 * 4);
+    } else {
+      const long long b = row / ((long long)N1 * T);
+      f32x4 m = {0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < T; ++t) m += cvt4(*(const bf16x4*)(dy + ((b * T + t) * N1) * (long long)D + c4 * 4));
+      o = cvt4(m * invT);
+    }
+    *(bf16x4*)(da + row * D + c4 * 4) = o;
+  }
+}
+
+// ---------------------------------------------------------------- row copy / add / colsum
+__global__ void copy_rows_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, long long rows, int cols, long long lds_,
+                                 long long ldd, RowMap sm, RowMap dm) {
+  const int C4 = cols / 4;
+  const long long total = rows * C4;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % C4);
+    const long long r = idx / C4;
+    *(bf16x4*)(dst + map_row(dm, r) * ldd + c4 * 4) = *(const bf16x4*)(src + map_row(sm, r) * lds_ + c4 * 4);
+  }
+}
+__global__ void add_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, bf16* __restrict__ o, long long n4) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
+    *(bf16x4*)(o + i * 4) = cvt4(cvt4(*(const bf16x4*)(a + i * 4)) + cvt4(*(const bf16x4*)(b + i * 4)));
+}
+constexpr int COLSUM_ROWS_SPLIT = 256;
+// grid (ceil(cols/256), nsplit): thread owns 1 column... 4 columns per thread, loops rows of its split
+__global__ void colsum_partial_kernel(const bf16* __restrict__ in, float* __restrict__ part, long long rows, int cols,
+                                      long long ld, RowMap m) {
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (c >= cols) return;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  for (long long r = blockIdx.y; r < rows; r += gridDim.y) a += cvt4(*(const bf16x4*)(in + map_row(m, r) * ld + c));
+  *(f32x4*)(part + (long long)blockIdx.y * cols + c) = a;
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, bf16* __restrict__ out, int nsplit, int cols, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float a = 0.f;
+  for (int i = 0; i < nsplit; ++i) a += part[(long long)i * cols + c];
+  if (accumulate) a += bf2f(out[c]);
+  out[c] = f2bf(a);
+}
+
+// ---------------------------------------------------------------- GPT embedding front
+__global__ void gpt_embed_fwd_kernel(const bf16* __restrict__ query, const int64_t* __restrict__ ids, const bf16* __restrict__ wte,
+                                     const bf16* __restrict__ wpe, bf16* __restrict__ h, int B, int Q, int L, int H,
+                                     float drop_scale, uint32_t thr, uint64_t seed, uint64_t offset) {
+  const int H8 = H / 8, S = Q + L;
+  const long long total = (long long)B * S * H8;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(idx % H8);
+    const long long row = idx / H8;
+    const int s = (int)(row % S);
+    const long long b = row / S;
+    const bf16* src = s < Q ? query + (b * Q + s) * (long long)H : wte + ids[b * L + (s - Q)] * (long long)H;
+    // reference: words_embeddings + position_embeddings in bf16 (one rounding), then dropout
+    f32x8 v = cvt8(*(const bf16x8*)(src + c8 * 8)) + cvt8(*(const bf16x8*)(wpe + (long long)s * H + c8 * 8));
+    if (thr) {
+      v = cvt8(cvt8(v));
+      const uint64_t base = offset + (uint64_t)row * (uint64_t)H + (uint64_t)(c8 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = mpv_keep(seed, base + e, thr) ? v[e] * drop_scale : 0.f;
+    }
+    *(bf16x8*)(h + row * H + c8 * 8) = cvt8(v);
+  }
+}
+__global__ void gpt_embed_bwd_kernel(const bf16* __restrict__ dh, bf16* __restrict__ dquery, int B, int Q, int L, int H,
+                                     float drop_scale, uint32_t thr, uint64_t seed, uint64_t offset) {
+  const int H8 = H / 8, S = Q + L;
+  const long long total = (long long)B * Q * H8;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(idx % H8);
+    const long long qrow = idx / H8;
+    const int s = (int)(qrow % Q);
+    const long long b = qrow / Q;
+    const long long row = b * S + s;
+    f32x8 v = cvt8(*(const bf16x8*)(dh + row * H + c8 * 8));
+    if (thr) {
+      const uint64_t base = offset + (uint64_t)row * (uint64_t)H + (uint64_t)(c8 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = mpv_keep(seed, base + e, thr) ? v[e] * drop_scale : 0.f;
+    }
+    *(bf16x8*)(dquery + qrow * H + c8 * 8) = cvt8(v);
+  }
+}
+
+// ---------------------------------------------------------------- masked cross-entropy
+// one workgroup per row; two sweeps over the row (second one hits L2): stats, then gradient.
+__global__ __launch_bounds__(256) void cross_entropy_kernel(const bf16* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                            const float* __restrict__ weight, float* __restrict__ losses,
+                                                            float* __restrict__ loss_sum, bf16* dlogits, int vocab,
+                                                            long long ld) {
+  __shared__ float red[8];
+  const long long r = blockIdx.x;
+  const bf16* row = logits + r * ld;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int V8 = vocab / 8;
+  float mx = -INFINITY;
+  for (int c = tid; c < V8; c += 256) {
+    const f32x8 v = cvt8(*(const bf16x8*)(row + c * 8));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mx = fmaxf(mx, v[e]);
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int c = tid; c < V8; c += 256) {
+    const f32x8 v = cvt8(*(const bf16x8*)(row + c * 8));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum += __expf(v[e] - mx);
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  sum = red[4] + red[5] + red[6] + red[7];
+  const int64_t tgt = labels[r];
+  const float w = weight ? weight[r] : 1.0f;
+  const float lse = mx + __logf(sum);
+  if (tid == 0) {
+    const float loss = lse - bf2f(row[tgt]);
+    if (losses) losses[r] = loss;
+    if (loss_sum && w != 0.f) atomicAdd(loss_sum, loss * w);
+  }
+  if (dlogits) {
+    bf16* drow = dlogits + r * ld;
+    const float inv = 1.0f / sum;
+    for (int c = tid; c < V8; c += 256) {
+      const f32x8 v = cvt8(*(const bf16x8*)(row + c * 8));
+      f32x8 g;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float pr = __expf(v[e] - mx) * inv;
+        g[e] = (pr - ((long long)(c * 8 + e) == tgt ? 1.0f : 0.f)) * w;
+      }
+      *(bf16x8*)(drow + c * 8) = cvt8(g);
+    }
+  }
+}
+
+inline int ew_grid(long long work_items, int threads = 256) {
+  long long b = (work_items + threads - 1) / threads;
+  return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+
+}  // namespace
+
+extern "C" int mpv_im2col_patches(const void* video, void* cols, int B, int C, int T, int H, int W, int P, int kpad,
+                                  hipStream_t stream) {
+  MPV_REQUIRE(video && cols, MPV_E_ARG, "mpv_im2col_patches: null pointer");
+  MPV_REQUIRE(B > 0 && C > 0 && T > 0 && P > 0 && H % P == 0 && W % P == 0 && kpad >= C * P * P, MPV_E_SHAPE,
+              "mpv_im2col_patches: bad shape");
+  const long long total = (long long)B * T * (H / P) * (W / P) * kpad;
+  hipLaunchKernelGGL(im2col_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, (const bf16*)video, (bf16*)cols, B, C, T, H, W, P,
+                     kpad);
+  return mpv_check_launch("mpv_im2col_patches");
+}
+
+extern "C" int mpv_vit_embed_assemble_fwd(const void* patch, const void* cls_token, const void* pos_embed,
+                                          const void* temporal_embed, void* x, int B, int T, int N, int D,
+                                          hipStream_t stream) {
+  MPV_REQUIRE(patch && cls_token && pos_embed && temporal_embed && x, MPV_E_ARG, "mpv_vit_embed_assemble_fwd: null pointer");
+  MPV_REQUIRE(D % 4 == 0 && B > 0 && T > 0 && N > 0, MPV_E_SHAPE, "mpv_vit_embed_assemble_fwd: bad shape");
+  const long long total = (long long)B * T * (N + 1) * (D / 4);
+  hipLaunchKernelGGL(embed_assemble_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, (const bf16*)patch,
+                     (const bf16*)cls_token, (const bf16*)pos_embed, (const bf16*)temporal_embed, (bf16*)x, B, T, N, D);
+  return mpv_check_launch("mpv_vit_embed_assemble_fwd");
+}
+
+extern "C" int mpv_vit_embed_assemble_bwd(const void* dx, void* dpatch, void* dcls, void* dpos, void* dtemporal, int B,
+                                          int T, int N, int D, hipStream_t stream) {
+  MPV_REQUIRE(dx && dpatch && dcls && dpos && dtemporal, MPV_E_ARG, "mpv_vit_embed_assemble_bwd: null pointer");
+  MPV_REQUIRE(D % 4 == 0 && B > 0 && T > 0 && N > 0, MPV_E_SHAPE, "mpv_vit_embed_assemble_bwd: bad shape");
+  const long long rows = (long long)B * T * N;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(ew_grid(rows * (D / 4))), dim3(256), 0, stream, (const bf16*)dx, (bf16*)dpatch, rows, D,
+                     (long long)D, (long long)D, RowMap{N, N + 1, 1}, RowMap{0, 0, 0});
+  hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3(N + 1), dim3(256), 0, stream, (const bf16*)dx, (bf16*)dcls, (bf16*)dpos, B, T, N, D);
+  hipLaunchKernelGGL(embed_bwd_temporal_kernel, dim3(T, (D + 63) / 64), dim3(256), 0, stream, (const bf16*)dx, (bf16*)dtemporal, B, T,
+                     N, D);
+  return mpv_check_launch("mpv_vit_embed_assemble_bwd");
+}
+
+extern "C" int mpv_vit_cls_merge_fwd(const void* xt, const void* a, void* y, int B, int T, int N1, int D,
+                                     hipStream_t stream) {
+  MPV_REQUIRE(xt && a && y, MPV_E_ARG, "mpv_vit_cls_merge_fwd: null pointer");
+  MPV_REQUIRE(D % 4 == 0 && B > 0 && T > 0 && N1 > 1, MPV_E_SHAPE, "mpv_vit_cls_merge_fwd: bad shape");
+  hipLaunchKernelGGL(cls_merge_fwd_kernel, dim3(ew_grid((long long)B * T * N1 * (D / 4))), dim3(256), 0, stream, (const bf16*)xt,
+                     (const bf16*)a, (bf16*)y, B, T, N1, D);
+  return mpv_check_launch("mpv_vit_cls_merge_fwd");
+}
+
+extern "C" int mpv_vit_cls_merge_bwd(const void* dy, void* da, int B, int T, int N1, int D, hipStream_t stream) {
+  MPV_REQUIRE(dy && da, MPV_E_ARG, "mpv_vit_cls_merge_bwd: null pointer");
+  MPV_REQUIRE(D % 4 == 0 && B > 0 && T > 0 && N1 > 1, MPV_E_SHAPE, "mpv_vit_cls_merge_bwd: bad shape");
+  hipLaunchKernelGGL(cls_merge_bwd_kernel, dim3(ew_grid((long long)B * T * N1 * (D / 4))), dim3(256), 0, stream, (const bf16*)dy,
+                     (bf16*)da, B, T, N1, D);
+  return mpv_check_launch("mpv_vit_cls_merge_bwd");
+}
+
+extern "C" int mpv_copy_rows(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds, int64_t ldd,
+                             int s_group, int s_stride, int s_offset, int d_group, int d_stride, int d_offset,
+                             hipStream_t stream) {
+  MPV_REQUIRE(src && dst, MPV_E_ARG, "mpv_copy_rows: null pointer");
+  MPV_REQUIRE(cols > 0 && cols % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0 && rows >= 0, MPV_E_SHAPE, "mpv_copy_rows: bad shape");
+  if (rows == 0) return MPV_OK;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(ew_grid(rows * (cols / 4))), dim3(256), 0, stream, (const bf16*)src, (bf16*)dst,
+                     (long long)rows, (int)cols, (long long)lds, (long long)ldd, RowMap{s_group, s_stride, s_offset},
+                     RowMap{d_group, d_stride, d_offset});
+  return mpv_check_launch("mpv_copy_rows");
+}
+
+extern "C" size_t mpv_colsum_workspace_size(int64_t cols) { return (size_t)COLSUM_ROWS_SPLIT * cols * sizeof(float); }
+
+extern "C" int mpv_colsum(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld, int group, int stride,
+                          int offset, int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  MPV_REQUIRE(in && out && workspace, MPV_E_ARG, "mpv_colsum: null pointer");
+  MPV_REQUIRE(cols > 0 && cols % 4 == 0 && ld % 4 == 0 && rows > 0, MPV_E_SHAPE, "mpv_colsum: bad shape");
+  int nsplit = (int)(rows < COLSUM_ROWS_SPLIT ? rows : COLSUM_ROWS_SPLIT);
+  MPV_REQUIRE(workspace_bytes >= (size_t)nsplit * cols * sizeof(float), MPV_E_ARG, "mpv_colsum: workspace too small");
+  const int threads = 64;
+  dim3 grid((unsigned)((cols / 4 + threads - 1) / threads), nsplit);
+  hipLaunchKernelGGL(colsum_partial_kernel, grid, dim3(threads), 0, stream, (const bf16*)in, (float*)workspace, (long long)rows,
+                     (int)cols, (long long)ld, RowMap{group, stride, offset});
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, stream, (const float*)workspace,
+                     (bf16*)out, nsplit, (int)cols, accumulate);
+  return mpv_check_launch("mpv_colsum");
+}
+
+extern "C" int mpv_add(const void* a, const void* b, void* out, int64_t n, hipStream_t stream) {
+  MPV_REQUIRE(a && b && out, MPV_E_ARG, "mpv_add: null pointer");
+  MPV_REQUIRE(n >= 0 && n % 4 == 0, MPV_E_SHAPE, "mpv_add: n must be a multiple of 4");
+  if (n == 0) return MPV_OK;
+  hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, stream, (const bf16*)a, (const bf16*)b, (bf16*)out,
+                     (long long)(n / 4));
+  return mpv_check_launch("mpv_add");
+}
+
+extern "C" int mpv_gpt_embed_fwd(const void* query, const int64_t* ids, const void* wte, const void* wpe, void* h, int B,
+                                 int Q, int L, int H, float dropout_p, uint64_t seed, uint64_t offset,
+                                 hipStream_t stream) {
+  MPV_REQUIRE(ids && wte && wpe && h && (query || Q == 0), MPV_E_ARG, "mpv_gpt_embed_fwd: null pointer");
+  MPV_REQUIRE(H % 8 == 0 && B > 0 && Q >= 0 && L >= 0 && Q + L > 0, MPV_E_SHAPE, "mpv_gpt_embed_fwd: bad shape");
+  MPV_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, MPV_E_ARG, "mpv_gpt_embed_fwd: bad dropout_p");
+  const long long total = (long long)B * (Q + L) * (H / 8);
+  hipLaunchKernelGGL(gpt_embed_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, (const bf16*)query, ids, (const bf16*)wte,
+                     (const bf16*)wpe, (bf16*)h, B, Q, L, H, 1.0f / (1.0f - dropout_p),
+                     dropout_p > 0.f ? mpv_drop_threshold(dropout_p) : 0u, seed, offset);
+  return mpv_check_launch("mpv_gpt_embed_fwd");
+}
+
+extern "C" int mpv_gpt_embed_bwd(const void* dh, void* dquery, int B, int Q, int L, int H, float dropout_p, uint64_t seed,
+                                 uint64_t offset, hipStream_t stream) {
+  MPV_REQUIRE(dh && dquery, MPV_E_ARG, "mpv_gpt_embed_bwd: null pointer");
+  MPV_REQUIRE(H % 8 == 0 && B > 0 && Q > 0 && L >= 0, MPV_E_SHAPE, "mpv_gpt_embed_bwd: bad shape");
+  const long long total = (long long)B * Q * (H / 8);
+  hipLaunchKernelGGL(gpt_embed_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, (const bf16*)dh, (bf16*)dquery, B, Q, L, H,
+                     1.0f / (1.0f - dropout_p), dropout_p > 0.f ? mpv_drop_threshold(dropout_p) : 0u, seed, offset);
+  return mpv_check_launch("mpv_gpt_embed_bwd");
+}
+
+extern "C" int mpv_cross_entropy(const void* logits, const int64_t* labels, const float* weight, float* losses,
+                                 float* loss_sum, void* dlogits, int64_t rows, int64_t vocab, int64_t ld,
+                                 hipStream_t stream) {
+  MPV_REQUIRE(logits && labels, MPV_E_ARG, "mpv_cross_entropy: null pointer");
+  MPV_REQUIRE(rows > 0 && vocab > 0 && vocab % 8 == 0 && ld % 8 == 0, MPV_E_SHAPE, "mpv_cross_entropy: vocab/ld must be multiples of 8");
+  hipLaunchKernelGGL(cross_entropy_kernel, dim3((unsigned)rows), dim3(256), 0, stream, (const bf16*)logits, labels, weight, losses,
+                     loss_sum, (bf16*)dlogits, (int)vocab, (long long)ld);
+  return mpv_check_launch("mpv_cross_entropy");
+}

@@ -1,0 +1,401 @@
+// gemm.hip -- bf16 MFMA GEMM family for gfx950 (CDNA4), hand-written.
+//
+//   C[M,N] = epilogue( sum_k Aop(m,k) * Bop(n,k) )
+//
+// Operand storage ("T" = the reduction index is the SLOW dimension in memory):
+//   TA=0: A stored [M][K] (k contiguous, lda)      TA=1: A stored [K][M] (m contiguous, lda)
+//   TB=0: B stored [N][K] (nn.Linear weight, ldb)  TB=1: B stored [K][N] (n contiguous, ldb)
+// which covers the three passes of a Linear layer without any transposed copies:
+//   forward  Y = X W^T          : TA=0, TB=0   (replaces cuBLAS F.linear, reference
+//                                               models/vision_transformer.py:104,108,175,205,250;
+//                                               models/modeling_distributed_gpt3.py:562,573,843,852,1348)
+//   dgrad    dX = dY W          : TA=0, TB=1   (reduction over N; W is [N][K] = "[red][out]")
+//   wgrad    dW = dY^T X        : TA=1, TB=1   (reduction over rows)
+//
+// Structure: 128x128 block tile, BK=64, 256 threads = 4 waves (2x2), each wave 64x64 =
+// 2x2 v_mfma_f32_32x32x16_bf16 tiles.  Global->LDS staging goes through registers with
+// buffer loads (out-of-range chunks read as zero, so ragged M/N/K edges need no branches),
+// issued for tile k+1 before the MFMAs of tile k and written to the other LDS buffer after
+// them (one barrier per K step).  k-contiguous operands sit in LDS as [row][64] with a
+// 16-byte-chunk XOR swizzle and are read with ds_read_b128; reduction-slow operands sit as
+// [k][128] with a 64-byte-chunk XOR swizzle and are read with ds_read_b64_tr_b16 (the
+// gfx950 transposing LDS read), so neither layout bank-conflicts.  The MFMA is issued with
+// swapped operands (D = Bfrag x Afrag) so every lane ends up owning 4 consecutive output
+// columns of one output row -> 8-byte packed bf16 stores and a cheap fused epilogue
+// (bias, erf/tanh GELU (+pre-activation copy), GELU-backward multiply, dropout, residual).
+// Workgroup ids are remapped so that each XCD (private L2) walks a contiguous range of tiles.
+#include "mpv_common.h"
+#include "mpv_kernels.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand tile
+
+struct GemmArgs {
+  const bf16* A;
+  const bf16* B;
+  void* C;
+  int M, N, K;
+  long long lda, ldb, ldc;
+  RowMap amap, cmap, kmap;
+  uint32_t a_bytes, b_bytes;
+  const bf16* bias;
+  int act;
+  bf16* preact;
+  const bf16* residual;
+  long long ldr;
+  const bf16* actz;
+  long long ldz;
+  int act_bwd;
+  float drop_scale;
+  uint32_t drop_thr;
+  uint64_t seed, drop_offset;
+  const float* alpha_dev;
+  float alpha;
+  int out_f32;
+  int accumulate;
+  int k_per_split;
+  int tiles_n;
+  int nwg;
+};
+
+// LDS byte address of 16-byte chunk `kc` (0..7) of `row` in a k-contiguous [128][64] tile.
+__device__ __forceinline__ int lds_addr_kc(int row, int kc) { return row * 128 + ((kc ^ ((row >> 1) & 7)) << 4); }
+// LDS byte address of byte column `cb` (0..255) of k-row `krow` in a [64][128] tile.
+__device__ __forceinline__ int lds_addr_tr(int krow, int cb) {
+  return krow * 256 + ((((cb >> 6) ^ (krow & 3))) << 6) + (cb & 63);
+}
+
+template <bool T>
+struct Loader {
+  // per-thread constant part of the 4 chunk offsets
+  uint32_t off[4];
+  bool rowok[4];
+  int ldsw[4];
+
+  // k-contiguous: rows = output index (M or N side), tile origin row0, total rows R.
+  __device__ __forceinline__ void init_kc(int tid, int row0, int R, long long ld, RowMap map) {
+    const int kc = tid & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (tid >> 3) + 32 * i;
+      const long long gr = row0 + row;
+      rowok[i] = gr < R;
+      off[i] = (uint32_t)((map_row(map, rowok[i] ? gr : 0) * ld + kc * 8) * 2);
+      ldsw[i] = lds_addr_kc(row, kc);
+    }
+  }
+  // reduction-slow: tile is [64 k][128 cols]; col0 origin along the output index, Cn total cols.
+  __device__ __forceinline__ void init_tr(int tid, int col0, int Cn) {
+    const int cc = tid & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int krow = (tid >> 4) + 16 * i;
+      rowok[i] = (col0 + cc * 8) < Cn;
+      off[i] = (uint32_t)((col0 + cc * 8) * 2);
+      ldsw[i] = lds_addr_tr(krow, cc * 16);
+    }
+  }
+};
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wrow = wave >> 1, wcol = wave & 1;
+
+  // XCD-aware bijective remap: workgroup b runs on XCD b%8; give each XCD a contiguous tile range.
+  const int bid = blockIdx.x;
+  const int nwg = p.nwg;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int pid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tile_m = pid / p.tiles_n, tile_n = pid - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int split = blockIdx.y;
+  const int kbeg = split * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  const __amdgpu_buffer_rsrc_t ra_src = make_rsrc(p.A, p.a_bytes);
+  const __amdgpu_buffer_rsrc_t rb_src = make_rsrc(p.B, p.b_bytes);
+
+  Loader<TA> la;
+  Loader<TB> lb;
+  if constexpr (TA) la.init_tr(tid, m0, p.M); else la.init_kc(tid, m0, p.M, p.lda, p.amap);
+  if constexpr (TB) lb.init_tr(tid, n0, p.N); else lb.init_kc(tid, n0, p.N, p.ldb, RowMap{0, 0, 0});
+
+  i32x4 sa[4], sb[4];
+
+  auto issue = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t va, vb;
+      if constexpr (TA) {
+        const int kr = k0 + (tid >> 4) + 16 * i;
+        const bool ok = la.rowok[i] && kr < kend;
+        va = ok ? (uint32_t)(map_row(p.kmap, kr) * p.lda * 2) + la.off[i] : 0x80000000u;
+      } else {
+        const bool ok = la.rowok[i] && (k0 + (tid & 7) * 8) < kend;
+        va = ok ? la.off[i] + (uint32_t)(k0 * 2) : 0x80000000u;
+      }
+      if constexpr (TB) {
+        const int kr = k0 + (tid >> 4) + 16 * i;
+        const bool ok = lb.rowok[i] && kr < kend;
+        vb = ok ? (uint32_t)(map_row(p.kmap, kr) * p.ldb * 2) + lb.off[i] : 0x80000000u;
+      } else {
+        const bool ok = lb.rowok[i] && (k0 + (tid & 7) * 8) < kend;
+        vb = ok ? lb.off[i] + (uint32_t)(k0 * 2) : 0x80000000u;
+      }
+      sa[i] = __builtin_amdgcn_raw_buffer_load_b128(ra_src, va, 0, 0);
+      sb[i] = __builtin_amdgcn_raw_buffer_load_b128(rb_src, vb, 0, 0);
+    }
+  };
+  auto commit = [&](int buf) {
+    char* pa = smem + buf * 2 * TILE_BYTES;
+    char* pb = pa + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *(i32x4*)(pa + la.ldsw[i]) = sa[i];
+      *(i32x4*)(pb + lb.ldsw[i]) = sb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment fetch: 8 bf16 along k for output index (lane&31) of 32-wide sub-tile `t`
+  auto frag = [&](const char* base, bool tr, int sub0, int s) -> bf16x8 {
+    if (!tr) {
+      const int row = sub0 + (lane & 31);
+      const int chunk = s * 2 + (lane >> 5);
+      return *(const bf16x8*)(base + lds_addr_kc(row, chunk));
+    } else {
+      const int kr = s * 16 + (lane >> 5) * 8 + ((lane & 15) >> 2);
+      const int cb = (sub0 + ((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;
+      typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + lds_addr_tr(kr, cb)));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + lds_addr_tr(kr + 4, cb)));
+      union {
+        struct { s16x4 a, b; } s;
+        bf16x8 v;
+      } u;
+      u.s.a = lo;
+      u.s.b = hi;
+      return u.v;
+    }
+  };
+
+  if (nk > 0) {
+    issue(kbeg);
+    commit(0);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) issue(kbeg + (kt + 1) * BK);
+    const char* pa = smem + cur * 2 * TILE_BYTES;
+    const char* pb = pa + TILE_BYTES;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        fa[t] = frag(pa, TA, wrow * 64 + t * 32, s);
+        fb[t] = frag(pb, TB, wcol * 64 + t * 32, s);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) commit(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  const float alpha = p.alpha * (p.alpha_dev ? *p.alpha_dev : 1.0f);
+  const int half = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + wrow * 64 + i * 32 + (lane & 31);
+    if (m >= p.M) continue;
+    const long long crow = map_row(p.cmap, m);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wcol * 64 + j * 32 + 8 * q + 4 * half;
+        if (n >= p.N) continue;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * alpha;
+        if (p.out_f32) {
+          float* cp = (float*)p.C + (long long)split * p.M * p.N + crow * p.ldc + n;
+          if (p.accumulate) {
+            const f32x4 o = *(const f32x4*)cp;
+            v += o;
+          }
+          *(f32x4*)cp = v;
+          continue;
+        }
+        if (p.bias) v += cvt4(*(const bf16x4*)(p.bias + n));
+        if (p.act) {
+          const bf16x4 zb = cvt4(v);
+          if (p.preact) *(bf16x4*)(p.preact + crow * p.ldc + n) = zb;
+          const f32x4 z = cvt4(zb);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = p.act == 1 ? gelu_erf_f(z[e]) : gelu_tanh_f(z[e]);
+        }
+        if (p.act_bwd) {
+          const f32x4 z = cvt4(*(const bf16x4*)(p.actz + (long long)m * p.ldz + n));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= p.act_bwd == 1 ? gelu_erf_grad_f(z[e]) : gelu_tanh_grad_f(z[e]);
+        }
+        if (p.drop_thr) {
+          const uint64_t base = p.drop_offset + (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = mpv_keep(p.seed, base + e, p.drop_thr) ? v[e] * p.drop_scale : 0.f;
+        }
+        if (p.residual) v += cvt4(*(const bf16x4*)(p.residual + crow * p.ldr + n));
+        bf16* cp = (bf16*)p.C + crow * p.ldc + n;
+        if (p.accumulate) v += cvt4(*(const bf16x4*)cp);
+        *(bf16x4*)cp = cvt4(v);
+      }
+    }
+  }
+}
+
+// sum split-K fp32 partials -> bf16 (optionally accumulating into the existing bf16 value)
+__global__ void splitk_reduce_kernel(const float* part, bf16* out, long long MN, int splits, int accumulate) {
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= MN) return;
+  f32x4 s = *(const f32x4*)(part + i);
+  for (int z = 1; z < splits; ++z) s += *(const f32x4*)(part + (long long)z * MN + i);
+  if (accumulate) s += cvt4(*(const bf16x4*)(out + i));
+  *(bf16x4*)(out + i) = cvt4(s);
+}
+
+}  // namespace
+
+extern "C" size_t mpv_gemm_workspace_size(int64_t M, int64_t N, int64_t K, int transA, int transB) {
+  if (!(transA && transB)) return 0;
+  // wgrad: split the (long) reduction so that >= ~2 workgroups per CU exist
+  return (size_t)M * N * sizeof(float) * 32;
+}
+
+static int choose_splitk(int64_t M, int64_t N, int64_t K, size_t ws_bytes) {
+  const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  int s = 1;
+  while (tiles * s < 512 && s < 32 && K / (s * 2) >= 4 * BK) s *= 2;
+  while (s > 1 && (size_t)M * N * sizeof(float) * s > ws_bytes) s /= 2;
+  return s;
+}
+
+extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                             int64_t ldb, int64_t ldc, int transA, int transB, const mpv_gemm_epilogue* ep,
+                             void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  MPV_REQUIRE(A && B && C, MPV_E_ARG, "mpv_gemm_bf16: null operand");
+  MPV_REQUIRE(M > 0 && N > 0 && K > 0, MPV_E_SHAPE, "mpv_gemm_bf16: empty problem %lld x %lld x %lld", (long long)M,
+              (long long)N, (long long)K);
+  MPV_REQUIRE(!(transA && !transB), MPV_E_ARG, "mpv_gemm_bf16: transA=1,transB=0 is not a Linear pass");
+  MPV_REQUIRE(N % 8 == 0 && ldc % 4 == 0, MPV_E_ALIGN, "mpv_gemm_bf16: N (%lld) must be a multiple of 8", (long long)N);
+  MPV_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, MPV_E_ALIGN, "mpv_gemm_bf16: lda/ldb must be multiples of 8 elements");
+  if (!transA) MPV_REQUIRE(K % 8 == 0, MPV_E_ALIGN, "mpv_gemm_bf16: K (%lld) must be a multiple of 8", (long long)K);
+  if (transA) MPV_REQUIRE(M % 8 == 0, MPV_E_ALIGN, "mpv_gemm_bf16: M (%lld) must be a multiple of 8 when transA", (long long)M);
+  MPV_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0, MPV_E_ALIGN, "mpv_gemm_bf16: operands must be 16-byte aligned");
+
+  GemmArgs g = {};
+  g.A = (const bf16*)A;
+  g.B = (const bf16*)B;
+  g.C = C;
+  g.M = (int)M;
+  g.N = (int)N;
+  g.K = (int)K;
+  g.lda = lda;
+  g.ldb = ldb;
+  g.ldc = ldc;
+  g.alpha = 1.0f;
+  RowMap id = {0, 0, 0};
+  g.amap = g.cmap = g.kmap = id;
+  if (ep) {
+    g.amap = RowMap{ep->a_group, ep->a_stride, ep->a_offset};
+    g.cmap = RowMap{ep->c_group, ep->c_stride, ep->c_offset};
+    g.kmap = RowMap{ep->k_group, ep->k_stride, ep->k_offset};
+    g.bias = (const bf16*)ep->bias;
+    g.act = ep->act;
+    g.preact = (bf16*)ep->preact_out;
+    g.residual = (const bf16*)ep->residual;
+    g.ldr = ep->ldr ? ep->ldr : ldc;
+    g.actz = (const bf16*)ep->act_bwd_z;
+    g.ldz = ep->ldz ? ep->ldz : N;
+    g.act_bwd = ep->act_bwd_z ? ep->act_bwd : 0;
+    if (ep->dropout_p > 0.f) {
+      MPV_REQUIRE(ep->dropout_p < 1.f, MPV_E_ARG, "mpv_gemm_bf16: dropout_p must be < 1");
+      g.drop_thr = mpv_drop_threshold(ep->dropout_p);
+      g.drop_scale = 1.0f / (1.0f - ep->dropout_p);
+      g.seed = ep->seed;
+      g.drop_offset = ep->offset;
+    }
+    g.alpha_dev = ep->alpha_dev;
+    if (ep->alpha != 0.f) g.alpha = ep->alpha;
+    g.out_f32 = ep->out_f32;
+    g.accumulate = ep->accumulate;
+  }
+  // byte extents for the buffer descriptors (rows may be gathered through amap/kmap)
+  const long long a_rows = transA ? map_row(g.kmap, K - 1) + 1 : map_row(g.amap, M - 1) + 1;
+  const long long b_rows = transB ? map_row(g.kmap, K - 1) + 1 : N;
+  const long long a_bytes = ((a_rows - 1) * lda + (transA ? M : K)) * 2;
+  const long long b_bytes = ((b_rows - 1) * ldb + (transB ? N : K)) * 2;
+  MPV_REQUIRE(a_bytes < 0x7FFFFFF0ll && b_bytes < 0x7FFFFFF0ll, MPV_E_SHAPE,
+              "mpv_gemm_bf16: operand larger than 2 GiB (%lld / %lld bytes)", a_bytes, b_bytes);
+  g.a_bytes = (uint32_t)a_bytes;
+  g.b_bytes = (uint32_t)b_bytes;
+
+  const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
+  g.tiles_n = tiles_n;
+  g.nwg = tiles_m * tiles_n;
+  int splitk = 1;
+  if (transA && transB && !g.out_f32) splitk = choose_splitk(M, N, K, workspace ? workspace_bytes : 0);
+  int kps = (int)K;
+  if (splitk > 1) {
+    kps = (int)(((K + splitk - 1) / splitk + BK - 1) / BK * BK);
+    splitk = (int)((K + kps - 1) / kps);
+  }
+  g.k_per_split = kps;
+
+  dim3 grid(g.nwg, splitk), block(256);
+  void* user_c = C;
+  const int user_acc = g.accumulate;
+  if (splitk > 1) {
+    MPV_REQUIRE(!g.bias && !g.act && !g.residual && !g.act_bwd && !g.drop_thr && g.cmap.group == 0 && ldc == N, MPV_E_ARG,
+                "mpv_gemm_bf16: split-K (wgrad) pass takes no fused epilogue");
+    g.C = workspace;
+    g.out_f32 = 1;
+    g.accumulate = 0;
+  }
+  if (!transA && !transB)
+    hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, stream, g);
+  else if (!transA && transB)
+    hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, stream, g);
+  else
+    hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, stream, g);
+  if (splitk > 1) {
+    const long long MN = (long long)M * N;
+    const int thr = 256;
+    const long long blocks = (MN / 4 + thr - 1) / thr;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(thr), 0, stream, (const float*)workspace,
+                       (bf16*)user_c, MN, splitk, user_acc);
+  }
+  return mpv_check_launch("mpv_gemm_bf16");
+}

@@ -1,0 +1,300 @@
+// norm.hip -- fused LayerNorm forward/backward for gfx950.  HBM-bound: one wave owns a row,
+// the row lives in registers (8-byte bf16x4 loads, lanes interleaved over 256-element
+// stripes so every wave-level load is a contiguous 512-byte burst), statistics in fp32 via
+// wave shuffles, affine fused, bf16 out.  Backward fuses the residual-gradient add, an
+// optional dropout-masked copy (for the bias_dropout_add that precedes the LN in the GPT
+// layer) and per-block partial dgamma/dbeta sums (finalised by a second tiny kernel).
+#include "mpv_common.h"
+#include "mpv_kernels.h"
+
+namespace {
+
+struct LnFwdArgs {
+  const bf16* x;
+  const bf16* gamma;
+  const bf16* beta;
+  bf16* y;
+  float* mean;
+  float* rstd;
+  long long rows;
+  int cols;
+  long long ldx, ldy;
+  float eps;
+  RowMap xmap, ymap;
+};
+
+template <int MAXC>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nchunk = p.cols >> 2;
+  const float inv_n = 1.0f / (float)p.cols;
+  for (long long r = (long long)blockIdx.x * 4 + wave; r < p.rows; r += (long long)gridDim.x * 4) {
+    const bf16* xr = p.x + map_row(p.xmap, r) * p.ldx;
+    f32x4 v[MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        v[i] = cvt4(*(const bf16x4*)(xr + c * 4));
+        s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+      } else {
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    const float mu = wave_sum(s) * inv_n;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = v[i][e] - mu;
+          s2 += d * d;
+        }
+      }
+    }
+    const float rs = rsqrtf(wave_sum(s2) * inv_n + p.eps);
+    bf16* yr = p.y + map_row(p.ymap, r) * p.ldy;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        const f32x4 g = cvt4(*(const bf16x4*)(p.gamma + c * 4));
+        const f32x4 b = cvt4(*(const bf16x4*)(p.beta + c * 4));
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs * g[e] + b[e];
+        *(bf16x4*)(yr + c * 4) = cvt4(o);
+      }
+    }
+    if (lane == 0) {
+      if (p.mean) p.mean[r] = mu;
+      if (p.rstd) p.rstd[r] = rs;
+    }
+  }
+}
+
+struct LnBwdArgs {
+  const bf16* dy;
+  const bf16* x;
+  const bf16* gamma;
+  const float* mean;
+  const float* rstd;
+  const bf16* dres;
+  bf16* dx;
+  bf16* dx_drop;
+  float drop_scale;
+  uint32_t drop_thr;
+  uint64_t seed, offset;
+  float* part;  // [gridDim.x][2][cols] fp32 (dgamma, dbeta) or NULL
+  long long rows;
+  int cols;
+  long long ldx, ldy;
+  RowMap xmap, ymap;
+};
+
+template <int MAXC, bool DPARAM>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p) {
+  __shared__ float red[DPARAM ? 2 * MAXC * 256 : 1];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nchunk = p.cols >> 2;
+  const float inv_n = 1.0f / (float)p.cols;
+  f32x4 gacc[DPARAM ? MAXC : 1], bacc[DPARAM ? MAXC : 1];
+  if constexpr (DPARAM) {
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) gacc[i] = bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (long long r = (long long)blockIdx.x * 4 + wave; r < p.rows; r += (long long)gridDim.x * 4) {
+    const long long xrow = map_row(p.xmap, r);
+    const bf16* xr = p.x + xrow * p.ldx;
+    const bf16* dyr = p.dy + map_row(p.ymap, r) * p.ldy;
+    const float mu = p.mean[r], rs = p.rstd[r];
+    f32x4 xh[MAXC], g[MAXC];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        const f32x4 xv = cvt4(*(const bf16x4*)(xr + c * 4));
+        const f32x4 dv = cvt4(*(const bf16x4*)(dyr + c * 4));
+        const f32x4 gm = cvt4(*(const bf16x4*)(p.gamma + c * 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[i][e] = (xv[e] - mu) * rs;
+          g[i][e] = dv[e] * gm[e];
+          c1 += g[i][e];
+          c2 += g[i][e] * xh[i][e];
+          if constexpr (DPARAM) {
+            gacc[i][e] += dv[e] * xh[i][e];
+            bacc[i][e] += dv[e];
+          }
+        }
+      } else {
+        xh[i] = g[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    c1 = wave_sum(c1) * inv_n;
+    c2 = wave_sum(c2) * inv_n;
+    bf16* dxr = p.dx + xrow * p.ldx;
+    const bf16* drr = p.dres ? p.dres + xrow * p.ldx : nullptr;
+    bf16* ddr = p.dx_drop ? p.dx_drop + xrow * p.ldx : nullptr;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
+        if (drr) o += cvt4(*(const bf16x4*)(drr + c * 4));
+        const bf16x4 ob = cvt4(o);
+        *(bf16x4*)(dxr + c * 4) = ob;
+        if (ddr) {
+          const f32x4 of = cvt4(ob);
+          f32x4 od;
+          const uint64_t base = p.offset + (uint64_t)r * (uint64_t)p.cols + (uint64_t)(c * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) od[e] = (p.drop_thr == 0 || mpv_keep(p.seed, base + e, p.drop_thr)) ? of[e] * p.drop_scale : 0.f;
+          *(bf16x4*)(ddr + c * 4) = cvt4(od);
+        }
+      }
+    }
+  }
+  if constexpr (DPARAM) {
+    // block reduce of the 4 waves' partial sums (one wave at a time into one LDS image)
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+      if (wave == w) {
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+          const int c = lane + 64 * i;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (w == 0) {
+              red[c * 4 + e] = gacc[i][e];
+              red[MAXC * 256 + c * 4 + e] = bacc[i][e];
+            } else {
+              red[c * 4 + e] += gacc[i][e];
+              red[MAXC * 256 + c * 4 + e] += bacc[i][e];
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    float* out = p.part + (long long)blockIdx.x * 2 * p.cols;
+    for (int c = threadIdx.x; c < p.cols; c += 256) {
+      out[c] = red[c];
+      out[p.cols + c] = red[MAXC * 256 + c];
+    }
+  }
+}
+
+__global__ void ln_dparam_finalize(const float* part, int nblk, int cols, bf16* dgamma, bf16* dbeta, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float a = 0.f, b = 0.f;
+  for (int i = 0; i < nblk; ++i) {
+    a += part[(long long)i * 2 * cols + c];
+    b += part[(long long)i * 2 * cols + cols + c];
+  }
+  if (accumulate) {
+    a += bf2f(dgamma[c]);
+    b += bf2f(dbeta[c]);
+  }
+  dgamma[c] = f2bf(a);
+  dbeta[c] = f2bf(b);
+}
+
+constexpr int LN_BWD_MAX_BLOCKS = 1024;
+
+template <int MAXC>
+void launch_fwd(const LnFwdArgs& a, int grid, hipStream_t s) {
+  hipLaunchKernelGGL((ln_fwd_kernel<MAXC>), dim3(grid), dim3(256), 0, s, a);
+}
+template <int MAXC>
+void launch_bwd(const LnBwdArgs& a, bool dparam, int grid, hipStream_t s) {
+  if (dparam)
+    hipLaunchKernelGGL((ln_bwd_kernel<MAXC, true>), dim3(grid), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((ln_bwd_kernel<MAXC, false>), dim3(grid), dim3(256), 0, s, a);
+}
+
+}  // namespace
+
+extern "C" int mpv_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
+                                 int64_t rows, int64_t cols, int64_t ldx, int64_t ldy, float eps, int x_group,
+                                 int x_stride, int x_offset, int y_group, int y_stride, int y_offset,
+                                 hipStream_t stream) {
+  MPV_REQUIRE(x && gamma && beta && y, MPV_E_ARG, "mpv_layernorm_fwd: null pointer");
+  MPV_REQUIRE(rows >= 0 && cols > 0 && cols % 4 == 0 && cols <= 4096, MPV_E_SHAPE,
+              "mpv_layernorm_fwd: cols=%lld must be a multiple of 4 and <= 4096", (long long)cols);
+  MPV_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, MPV_E_ALIGN, "mpv_layernorm_fwd: leading dims must be multiples of 4");
+  if (rows == 0) return MPV_OK;
+  LnFwdArgs a = {(const bf16*)x, (const bf16*)gamma, (const bf16*)beta, (bf16*)y, mean, rstd, rows, (int)cols, ldx, ldy, eps,
+                 RowMap{x_group, x_stride, x_offset}, RowMap{y_group, y_stride, y_offset}};
+  const int grid = (int)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);
+  const int nc = (int)((cols / 4 + 63) / 64);
+  if (nc <= 3) launch_fwd<3>(a, grid, stream);
+  else if (nc <= 6) launch_fwd<6>(a, grid, stream);
+  else if (nc <= 8) launch_fwd<8>(a, grid, stream);
+  else if (nc <= 10) launch_fwd<10>(a, grid, stream);
+  else launch_fwd<16>(a, grid, stream);
+  return mpv_check_launch("mpv_layernorm_fwd");
+}
+
+extern "C" size_t mpv_layernorm_bwd_workspace_size(int64_t cols) {
+  return (size_t)LN_BWD_MAX_BLOCKS * 2 * (size_t)cols * sizeof(float);
+}
+
+extern "C" int mpv_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
+                                 const void* dres, void* dx, void* dx_drop, float drop_p, uint64_t seed,
+                                 uint64_t offset, void* dgamma, void* dbeta, int accumulate_dparams, int64_t rows,
+                                 int64_t cols, int64_t ldx, int64_t ldy, int x_group, int x_stride, int x_offset,
+                                 int y_group, int y_stride, int y_offset, void* workspace, size_t workspace_bytes,
+                                 hipStream_t stream) {
+  MPV_REQUIRE(dy && x && gamma && mean && rstd && dx, MPV_E_ARG, "mpv_layernorm_bwd: null pointer");
+  MPV_REQUIRE(rows >= 0 && cols > 0 && cols % 4 == 0 && cols <= 4096, MPV_E_SHAPE,
+              "mpv_layernorm_bwd: cols=%lld must be a multiple of 4 and <= 4096", (long long)cols);
+  MPV_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), MPV_E_ARG, "mpv_layernorm_bwd: dgamma/dbeta must come together");
+  MPV_REQUIRE(drop_p >= 0.f && drop_p < 1.f, MPV_E_ARG, "mpv_layernorm_bwd: bad dropout_p");
+  if (rows == 0) return MPV_OK;
+  const bool dparam = dgamma != nullptr;
+  int grid = (int)((rows + 3) / 4 < LN_BWD_MAX_BLOCKS ? (rows + 3) / 4 : LN_BWD_MAX_BLOCKS);
+  if (dparam)
+    MPV_REQUIRE(workspace && workspace_bytes >= (size_t)grid * 2 * cols * sizeof(float), MPV_E_ARG,
+                "mpv_layernorm_bwd: workspace too small (need %zu bytes)", (size_t)grid * 2 * cols * sizeof(float));
+  LnBwdArgs a = {};
+  a.dy = (const bf16*)dy;
+  a.x = (const bf16*)x;
+  a.gamma = (const bf16*)gamma;
+  a.mean = mean;
+  a.rstd = rstd;
+  a.dres = (const bf16*)dres;
+  a.dx = (bf16*)dx;
+  a.dx_drop = (bf16*)dx_drop;
+  a.drop_thr = drop_p > 0.f ? mpv_drop_threshold(drop_p) : 0;
+  a.drop_scale = 1.0f / (1.0f - drop_p);
+  a.seed = seed;
+  a.offset = offset;
+  a.part = dparam ? (float*)workspace : nullptr;
+  a.rows = rows;
+  a.cols = (int)cols;
+  a.ldx = ldx;
+  a.ldy = ldy;
+  a.xmap = RowMap{x_group, x_stride, x_offset};
+  a.ymap = RowMap{y_group, y_stride, y_offset};
+  const int nc = (int)((cols / 4 + 63) / 64);
+  if (nc <= 3) launch_bwd<3>(a, dparam, grid, stream);
+  else if (nc <= 6) launch_bwd<6>(a, dparam, grid, stream);
+  else if (nc <= 8) launch_bwd<8>(a, dparam, grid, stream);
+  else if (nc <= 10) launch_bwd<10>(a, dparam, grid, stream);
+  else launch_bwd<16>(a, dparam, grid, stream);
+  if (dparam)
+    hipLaunchKernelGGL(ln_dparam_finalize, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, stream,
+                       (const float*)workspace, grid, (int)cols, (bf16*)dgamma, (bf16*)dbeta, accumulate_dparams);
+  return mpv_check_launch("mpv_layernorm_bwd");
+}

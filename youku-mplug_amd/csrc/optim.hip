@@ -1,0 +1,84 @@
+// optim.hip -- flat-buffer AdamW + global gradient norm for gfx950 (HBM-bound, ~30 B/param).
+// Replaces DeepSpeed FusedAdam + bf16 master-weight handling + global-norm clipping
+// (run_pretrain_distributed_gpt3.py:137; utils.py:490-529); math of optim/adamw.py:66-115.
+#include "mpv_common.h"
+#include "mpv_kernels.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void grad_sumsq_kernel(const bf16* __restrict__ g, long long n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const long long n8 = n / 8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    const f32x8 v = cvt8(*(const bf16x8*)(g + i * 8));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += v[e] * v[e];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n - n8 * 8)) {
+    const float v = bf2f(g[n8 * 8 + threadIdx.x]);
+    s += v * v;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(bf16* __restrict__ p16, float* __restrict__ p, float* __restrict__ m,
+                                                    float* __restrict__ v, const bf16* __restrict__ g, long long n, float lr,
+                                                    float b1, float b2, float eps, float wd, float inv_bc1, float inv_sqrt_bc2,
+                                                    float grad_scale, const float* __restrict__ sumsq, float max_norm) {
+  float gs = grad_scale;
+  if (sumsq && max_norm > 0.f) {
+    const float norm = sqrtf(*sumsq) * grad_scale;      // norm of the scaled gradients
+    const float coef = max_norm / (norm + 1e-6f);        // torch.nn.utils.clip_grad_norm_
+    if (coef < 1.0f) gs *= coef;
+  }
+  const long long n4 = n / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 pp = *(const f32x4*)(p + i * 4), mm = *(const f32x4*)(m + i * 4), vv = *(const f32x4*)(v + i * 4);
+    const f32x4 gg = cvt4(*(const bf16x4*)(g + i * 4)) * gs;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      pp[e] *= (1.0f - lr * wd);
+      mm[e] = mm[e] * b1 + (1.0f - b1) * gg[e];
+      vv[e] = vv[e] * b2 + (1.0f - b2) * gg[e] * gg[e];
+      const float denom = sqrtf(vv[e]) * inv_sqrt_bc2 + eps;
+      pp[e] -= (lr * inv_bc1) * mm[e] / denom;
+    }
+    *(f32x4*)(p + i * 4) = pp;
+    *(f32x4*)(m + i * 4) = mm;
+    *(f32x4*)(v + i * 4) = vv;
+    *(bf16x4*)(p16 + i * 4) = cvt4(pp);
+  }
+}
+
+}  // namespace
+
+extern "C" int mpv_grad_sumsq(const void* grad, int64_t n, float* sumsq, hipStream_t stream) {
+  MPV_REQUIRE(grad && sumsq, MPV_E_ARG, "mpv_grad_sumsq: null pointer");
+  MPV_REQUIRE(n >= 0 && (((uintptr_t)grad) & 15) == 0, MPV_E_ALIGN, "mpv_grad_sumsq: grad must be 16-byte aligned");
+  if (n == 0) return MPV_OK;
+  long long blocks = (n / 8 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(grad_sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16*)grad, (long long)n, sumsq);
+  return mpv_check_launch("mpv_grad_sumsq");
+}
+
+extern "C" int mpv_adamw_step(void* param_bf16, float* master, float* exp_avg, float* exp_avg_sq, const void* grad_bf16,
+                              int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                              float grad_scale, const float* sumsq, float max_norm, hipStream_t stream) {
+  MPV_REQUIRE(param_bf16 && master && exp_avg && exp_avg_sq && grad_bf16, MPV_E_ARG, "mpv_adamw_step: null pointer");
+  MPV_REQUIRE(n >= 0 && n % 4 == 0, MPV_E_SHAPE, "mpv_adamw_step: n (%lld) must be a multiple of 4 (pad the flat buffer)", (long long)n);
+  MPV_REQUIRE(step >= 1, MPV_E_ARG, "mpv_adamw_step: step counts from 1");
+  if (n == 0) return MPV_OK;
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  long long blocks = (n / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (bf16*)param_bf16, master, exp_avg, exp_avg_sq,
+                     (const bf16*)grad_bf16, (long long)n, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1),
+                     (float)(1.0 / sqrt(bc2)), grad_scale, sumsq, max_norm);
+  return mpv_check_launch("mpv_adamw_step");
+}
