@@ -1,0 +1,383 @@
+"""GPU parity tests of every C-ABI kernel against plain PyTorch fp32 references of the same op
+(bf16 tolerance stated per test).  Run on the MI355X box: pytest -m gpu."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def close(a, b, tol, what=""):
+    e = rel_err(a, b)
+    assert math.isfinite(e) and e <= tol, f"{what}: max-abs error / max-abs ref = {e:.3e} > {tol}"
+
+
+def rn(*shape, dev, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).to(dev)
+
+
+# ------------------------------------------------------------------------------ GEMM
+GEMM_SHAPES = [(128, 128, 64), (256, 384, 768), (200, 136, 72), (1576, 768, 768), (288, 2304, 768), (130, 1024, 2048),
+               (8, 8, 8)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_forward_nt(dev, M, N, K):
+    from youku_mplug_amd import ops
+    a, w = rn(M, K, dev=dev, seed=1), rn(N, K, dev=dev, seed=2)     # asymmetric operands (transpose-detecting)
+    out = ops.gemm(a, w, M, N, K)
+    close(out, a.float() @ w.float().t(), 1e-2, "Y = X W^T")
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_dgrad_nn(dev, M, N, K):
+    from youku_mplug_amd import ops
+    dy, w = rn(M, K, dev=dev, seed=3), rn(K, N, dev=dev, seed=4)    # dX[M,N] = dY[M,K] W[K,N]
+    out = ops.gemm(dy, w, M, N, K, trans_b=True)
+    close(out, dy.float() @ w.float(), 1e-2, "dX = dY W")
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (768, 2304, 1576), (136, 72, 200), (768, 768, 50176 // 8), (8, 8, 8)])
+def test_gemm_wgrad_tn(dev, M, N, K):
+    from youku_mplug_amd import ops
+    dy, x = rn(K, M, dev=dev, seed=5), rn(K, N, dev=dev, seed=6)    # dW[M,N] = dY^T[M,K] X[K,N]
+    out = ops.gemm(dy, x, M, N, K, trans_a=True, trans_b=True)
+    close(out, dy.float().t() @ x.float(), 1e-2, "dW = dY^T X")
+
+
+def test_gemm_epilogues(dev):
+    from youku_mplug_amd import ops
+    M, N, K = 300, 256, 192
+    a, w, bias, res = rn(M, K, dev=dev, seed=7), rn(N, K, dev=dev, seed=8, scale=0.1), rn(N, dev=dev, seed=9), rn(M, N, dev=dev, seed=10)
+    z_ref = (a.float() @ w.float().t() + bias.float())
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    out = ops.gemm(a, w, M, N, K, bias=bias, act=ops.ACT_GELU_ERF, preact_out=pre)
+    close(pre, z_ref, 1e-2, "preact")
+    close(out, F.gelu(pre.float()), 1e-2, "gelu_erf(bf16(z))")
+    out = ops.gemm(a, w, M, N, K, bias=bias, act=ops.ACT_GELU_TANH)
+    close(out, F.gelu(z_ref.bfloat16().float(), approximate="tanh"), 1e-2, "gelu_tanh")
+    out = ops.gemm(a, w, M, N, K, bias=bias, residual=res)
+    close(out, z_ref + res.float(), 1e-2, "bias+residual")
+    # GELU backward multiply: dZ = (dG W) * gelu'(z)
+    z = rn(M, N, dev=dev, seed=11)
+    for act, approx in ((ops.ACT_GELU_ERF, "none"), (ops.ACT_GELU_TANH, "tanh")):
+        zz = z.float().requires_grad_(True)
+        F.gelu(zz, approximate=approx).sum().backward()
+        out = ops.gemm(a, w, M, N, K, act_bwd_z=z, act_bwd=act)
+        close(out, (a.float() @ w.float().t()) * zz.grad, 1e-2, f"gelu' {approx}")
+    # device alpha + accumulate
+    alpha = torch.tensor(0.5, device=dev)
+    base = res.clone()
+    ops.gemm(a, w, M, N, K, out=base, alpha_dev=alpha, accumulate=True)
+    close(base, res.float() + 0.5 * (a.float() @ w.float().t()), 1e-2, "alpha_dev+accumulate")
+
+
+def test_gemm_row_maps(dev):
+    from youku_mplug_amd import ops
+    B, T, N1, D, Nout = 2, 3, 5, 64, 128          # token rows of a [B*T, 1+4, D] stream
+    n = N1 - 1
+    rows = B * T * n
+    tok = (n, N1, 1)
+    x, w = rn(B * T * N1, D, dev=dev, seed=12), rn(Nout, D, dev=dev, seed=13)
+    out = torch.zeros(B * T * N1, Nout, dtype=torch.bfloat16, device=dev)
+    ops.gemm(x, w, rows, Nout, D, out=out, amap=tok, cmap=tok)
+    ref = x.float() @ w.float().t()
+    mask = torch.ones(B * T * N1, dtype=torch.bool, device=dev)
+    mask[::N1] = False
+    close(out[mask], ref[mask], 1e-2, "mapped rows")
+    assert out[~mask].abs().max().item() == 0.0, "cls slots must be untouched"
+    # wgrad over token rows only (kmap)
+    dy = rn(B * T * N1, Nout, dev=dev, seed=14)
+    dw = ops.gemm(dy, x, Nout, D, rows, trans_a=True, trans_b=True, lda=Nout, ldb=D, kmap=tok)
+    close(dw, dy.float()[mask].t() @ x.float()[mask], 1e-2, "wgrad with kmap")
+
+
+def test_gemm_dropout_epilogue(dev):
+    from youku_mplug_amd import ops
+    M, N, K = 512, 512, 64
+    a, w, res = rn(M, K, dev=dev, seed=15), rn(N, K, dev=dev, seed=16), rn(M, N, dev=dev, seed=17)
+    plain = ops.gemm(a, w, M, N, K).float()
+    d1 = ops.gemm(a, w, M, N, K, residual=res, dropout_p=0.25, seed=1234, offset=77).float() - res.float()
+    d2 = ops.gemm(a, w, M, N, K, residual=res, dropout_p=0.25, seed=1234, offset=77).float() - res.float()
+    assert torch.equal(d1, d2), "dropout must be a pure function of (seed, offset, index)"
+    kept = d1.abs() > 1e-3 * plain.abs().max()
+    frac = 1.0 - kept.float().mean().item()
+    assert abs(frac - 0.25) < 0.02, f"drop fraction {frac}"
+    close(d1[kept], (plain / 0.75)[kept], 3e-2, "kept values scaled by 1/(1-p)")
+
+
+# ------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("rows,cols", [(37, 768), (64, 2048), (9, 2560), (5, 1408), (3, 192), (4, 256)])
+def test_layernorm_fwd_bwd(dev, rows, cols):
+    from youku_mplug_amd import ops
+    x, g, b, dy, dres = (rn(rows, cols, dev=dev, seed=20, scale=2.0), (1 + 0.1 * torch.randn(cols)).bfloat16().to(dev),
+                         rn(cols, dev=dev, seed=21, scale=0.1), rn(rows, cols, dev=dev, seed=22), rn(rows, cols, dev=dev, seed=23))
+    y, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-5, rows, cols)
+    xf = x.float().requires_grad_(True)
+    gf, bf_ = g.float().requires_grad_(True), b.float().requires_grad_(True)
+    ref = F.layer_norm(xf, (cols,), gf, bf_, 1e-5)
+    close(y, ref, 1e-2, "LN fwd")
+    ref.backward(dy.float())
+    dgamma = torch.empty(cols, dtype=torch.bfloat16, device=dev)
+    dbeta = torch.empty(cols, dtype=torch.bfloat16, device=dev)
+    dx = ops.layernorm_bwd(dy, x, g, mean, rstd, rows, cols, dres=dres, dgamma=dgamma, dbeta=dbeta)
+    close(dx, xf.grad + dres.float(), 1.5e-2, "LN dx (+dres)")
+    close(dgamma, gf.grad, 1.5e-2, "LN dgamma")
+    close(dbeta, bf_.grad, 1.5e-2, "LN dbeta")
+    dx2 = ops.layernorm_bwd(dy, x, g, mean, rstd, rows, cols)           # dgrad only (frozen GPT)
+    close(dx2, xf.grad, 1.5e-2, "LN dx")
+
+
+def test_layernorm_row_maps(dev):
+    from youku_mplug_amd import ops
+    BT, N1, D = 6, 5, 192
+    n = N1 - 1
+    x, g, b = rn(BT * N1, D, dev=dev, seed=24), rn(D, dev=dev, seed=25), rn(D, dev=dev, seed=26)
+    y = torch.zeros(BT * n + 2, D, dtype=torch.bfloat16, device=dev)
+    ops.layernorm_fwd(x, g, b, 1e-6, BT * n, D, out=y, xmap=(n, N1, 1), ymap=(BT * n, BT * n + 1, 1))
+    ref = F.layer_norm(x.float().view(BT, N1, D)[:, 1:].reshape(-1, D), (D,), g.float(), b.float(), 1e-6)
+    close(y[1:1 + BT * n], ref, 1e-2, "LN mapped")
+    assert y[0].abs().max().item() == 0
+
+
+# ------------------------------------------------------------------------------ attention
+def ref_attention(q, k, v, causal, scale, scale_q_bf16):
+    qf = (q * scale).float() if scale_q_bf16 else q.float() * scale      # q is bf16: q*scale rounds to bf16
+    s = qf @ k.float().transpose(-1, -2)
+    if causal:
+        sq, sk = s.shape[-2:]
+        m = torch.ones(sq, sk, dtype=torch.bool, device=s.device).tril(sk - sq)
+        s = s.masked_fill(~m, float("-inf"))
+    p = s.softmax(-1)
+    return p @ v.float(), p
+
+
+ATTN_CASES = [  # B, H, Sq, Sk, hd, causal, scale_q_bf16
+    (2, 4, 160, 160, 64, True, False),
+    (2, 2, 144, 144, 80, True, False),
+    (3, 2, 197, 197, 96, False, True),
+    (2, 2, 128, 786, 96, False, False),
+    (1, 1, 5, 7, 64, False, False),
+    (1, 2, 33, 33, 96, True, False),
+]
+
+
+@pytest.mark.parametrize("B,H,Sq,Sk,hd,causal,sqb", ATTN_CASES)
+def test_attention_fwd_bwd(dev, B, H, Sq, Sk, hd, causal, sqb):
+    from youku_mplug_amd import ops
+    q, k, v = rn(B, Sq, H, hd, dev=dev, seed=30), rn(B, Sk, H, hd, dev=dev, seed=31), rn(B, Sk, H, hd, dev=dev, seed=32)
+    do = rn(B, Sq, H, hd, dev=dev, seed=33)
+    o = torch.empty_like(q)
+    scale = hd ** -0.5
+    lay = ops.AttnLayout((Sq * H * hd, hd, H * hd), (Sk * H * hd, hd, H * hd), (Sk * H * hd, hd, H * hd), (Sq * H * hd, hd, H * hd))
+    lse = ops.attn_fwd(q, k, v, o, lay, B, H, Sq, Sk, hd, causal=causal, scale=scale, scale_q_bf16=sqb)
+    qt, kt, vt = (t.permute(0, 2, 1, 3) for t in (q, k, v))
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (qt, kt, vt))
+    if sqb:
+        qs = (qt * scale).float()
+        s = qs @ kr.transpose(-1, -2)
+    else:
+        s = (qr * scale) @ kr.transpose(-1, -2)
+    if causal:
+        m = torch.ones(Sq, Sk, dtype=torch.bool, device=dev).tril(Sk - Sq)
+        s = s.masked_fill(~m, float("-inf"))
+    ref = s.softmax(-1) @ vr
+    close(o.permute(0, 2, 1, 3), ref, 1.5e-2, "attention out")
+    close(lse, torch.logsumexp(s, -1), 1e-2, "lse")
+    if sqb:
+        return_q = False
+    ref.backward(do.permute(0, 2, 1, 3).float())
+    dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+    ops.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, lay, B, H, Sq, Sk, hd, causal=causal, scale=scale, scale_q_bf16=sqb)
+    close(dv.permute(0, 2, 1, 3), vr.grad, 2e-2, "dV")
+    close(dk.permute(0, 2, 1, 3), kr.grad, 2e-2, "dK")
+    if not sqb:
+        close(dq.permute(0, 2, 1, 3), qr.grad, 2e-2, "dQ")
+    else:
+        # q' = bf16(q*scale) is non-differentiable through the rounding; compare against the smooth scale path
+        q2 = qt.float().requires_grad_(True)
+        s2 = (q2 * scale) @ kt.float().transpose(-1, -2)
+        (s2.softmax(-1) @ vt.float()).backward(do.permute(0, 2, 1, 3).float())
+        close(dq.permute(0, 2, 1, 3), q2.grad, 3e-2, "dQ (pre-scaled q)")
+
+
+def test_attention_packed_gpt_layout_and_dropout(dev):
+    """GPT layout: qkv [B,S,np,3*hn] head-interleaved (modeling_distributed_gpt3.py:895-902)."""
+    from youku_mplug_amd import ops
+    B, S, np_, hn = 2, 96, 4, 64
+    Hh = np_ * hn
+    qkv = rn(B, S, np_, 3 * hn, dev=dev, seed=40)
+    o = torch.empty(B, S, Hh, dtype=torch.bfloat16, device=dev)
+    st = (S * 3 * Hh, 3 * hn, 3 * Hh)
+    lay = ops.AttnLayout(st, st, st, (S * Hh, hn, Hh))
+    q, k, v = qkv[..., :hn], qkv[..., hn:2 * hn], qkv[..., 2 * hn:]
+    ops.attn_fwd(q, k, v, o, lay, B, np_, S, S, hn, causal=True, scale=hn ** -0.5)
+    ref, _ = ref_attention(q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3), True, hn ** -0.5, False)
+    close(o.view(B, S, np_, hn).permute(0, 2, 1, 3), ref, 1.5e-2, "packed layout")
+    # dropout: deterministic in (seed, offset); mean preserved; backward consistent with forward mask
+    o1, o2 = torch.empty_like(o), torch.empty_like(o)
+    lse = ops.attn_fwd(q, k, v, o1, lay, B, np_, S, S, hn, causal=True, scale=hn ** -0.5, dropout_p=0.1, seed=5, offset=9)
+    ops.attn_fwd(q, k, v, o2, lay, B, np_, S, S, hn, causal=True, scale=hn ** -0.5, dropout_p=0.1, seed=5, offset=9)
+    assert torch.equal(o1, o2)
+    assert rel_err(o1, o) > 1e-3
+    # finite-difference-free check of backward under dropout: linearity in V.  O is linear in V for a fixed mask,
+    # so dV must equal the gradient of <dO, O(V)> = sum over q of P_drop^T dO; test via a second forward.
+    do = rn(B, S, Hh, dev=dev, seed=41)
+    dqkv = torch.zeros_like(qkv)
+    ops.attn_bwd(q, k, v, o1, lse, do, dqkv[..., :hn], dqkv[..., hn:2 * hn], dqkv[..., 2 * hn:], lay, B, np_, S, S, hn,
+                 causal=True, scale=hn ** -0.5, dropout_p=0.1, seed=5, offset=9)
+    dv = dqkv[..., 2 * hn:].float()
+    probe = rn(B, S, np_, 3 * hn, dev=dev, seed=42)
+    qkv2 = qkv.clone()
+    qkv2[..., 2 * hn:] = probe[..., 2 * hn:]
+    o3 = torch.empty_like(o)
+    ops.attn_fwd(qkv2[..., :hn], qkv2[..., hn:2 * hn], qkv2[..., 2 * hn:], o3, lay, B, np_, S, S, hn, causal=True,
+                 scale=hn ** -0.5, dropout_p=0.1, seed=5, offset=9)
+    lhs = (do.float() * o3.float()).sum().item()                      # <dO, O(V')>
+    rhs = (dv * probe[..., 2 * hn:].float()).sum().item()              # <dV, V'>
+    assert abs(lhs - rhs) <= 2e-2 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)
+
+
+@pytest.mark.parametrize("T", [4, 8, 16])
+def test_temporal_attention(dev, T):
+    from youku_mplug_amd import ops
+    B, N, heads, hd = 2, 6, 2, 96
+    D = heads * hd
+    N1 = N + 1
+    qkv = rn(B * T * N1, 3 * D, dev=dev, seed=50)
+    out = torch.zeros(B * T * N1, D, dtype=torch.bfloat16, device=dev)
+    scale = hd ** -0.5
+    ops.temporal_attn_fwd(qkv, out, B, T * N1, N, 1, N1, T, heads, hd, scale)
+    x = qkv.view(B, T, N1, 3, heads, hd)[:, :, 1:]                    # [B,T,N,3,h,d]
+    q, k, v = (x[:, :, :, i].permute(0, 2, 3, 1, 4) for i in range(3))  # [B,N,h,T,d]
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    s = (qr * scale) @ kr.transpose(-1, -2)
+    ref = s.softmax(-1) @ vr
+    got = out.view(B, T, N1, heads, hd)[:, :, 1:].permute(0, 2, 3, 1, 4)
+    close(got, ref, 1.5e-2, "temporal out")
+    assert out.view(B, T, N1, D)[:, :, 0].abs().max().item() == 0
+    dout = rn(B * T * N1, D, dev=dev, seed=51)
+    dqkv = torch.zeros_like(qkv)
+    ops.temporal_attn_bwd(qkv, dout, dqkv, B, T * N1, N, 1, N1, T, heads, hd, scale)
+    ref.backward(dout.view(B, T, N1, heads, hd)[:, :, 1:].permute(0, 2, 3, 1, 4).float())
+    g = dqkv.view(B, T, N1, 3, heads, hd)[:, :, 1:]
+    for i, (name, r) in enumerate((("dq", qr), ("dk", kr), ("dv", vr))):
+        close(g[:, :, :, i].permute(0, 2, 3, 1, 4), r.grad, 3e-2, "temporal " + name)
+
+
+# ------------------------------------------------------------------------------ glue kernels
+def test_im2col_and_assemble(dev):
+    from youku_mplug_amd import ops
+    B, Cc, T, H, W, P, D = 2, 3, 2, 32, 32, 16, 64
+    N = (H // P) * (W // P)
+    video = rn(B, Cc, T, H, W, dev=dev, seed=60)
+    cols = ops.im2col_patches(video, B, Cc, T, H, W, P, Cc * P * P)
+    ref = F.unfold(video.permute(0, 2, 1, 3, 4).reshape(B * T, Cc, H, W).float(), P, stride=P).transpose(1, 2).reshape(-1, Cc * P * P)
+    assert torch.equal(cols.float(), ref)
+    cols14 = ops.im2col_patches(rn(1, 3, 1, 28, 28, dev=dev, seed=61), 1, 3, 1, 28, 28, 14, 592)   # EVA patch 14, padded K
+    assert cols14.shape == (4, 592) and cols14[:, 588:].abs().max().item() == 0
+    patch, cls, pos, tmp = rn(B * T * N, D, dev=dev, seed=62), rn(D, dev=dev, seed=63), rn(N + 1, D, dev=dev, seed=64), rn(T, D, dev=dev, seed=65)
+    x = ops.vit_embed_assemble_fwd(patch, cls, pos, tmp, B, T, N, D).view(B, T, N + 1, D)
+    ref_tok = patch.view(B, T, N, D).float() + (pos[1:].float()[None, None] + tmp.float()[None, :, None]).bfloat16().float()
+    close(x[:, :, 1:], ref_tok, 1e-2, "assemble tokens")
+    close(x[:, :, 0], (cls.float() + pos[0].float()).expand(B, T, D), 1e-2, "assemble cls")
+    dx = rn(B * T * (N + 1), D, dev=dev, seed=66)
+    dpatch, dcls, dpos, dtmp = (torch.empty(B * T * N, D, dtype=torch.bfloat16, device=dev), torch.empty(D, dtype=torch.bfloat16, device=dev),
+                                torch.empty(N + 1, D, dtype=torch.bfloat16, device=dev), torch.empty(T, D, dtype=torch.bfloat16, device=dev))
+    ops.vit_embed_assemble_bwd(dx, dpatch, dcls, dpos, dtmp, B, T, N, D)
+    dxv = dx.view(B, T, N + 1, D).float()
+    assert torch.equal(dpatch.view(B, T, N, D).float(), dxv[:, :, 1:])
+    close(dpos, dxv.sum((0, 1)), 1e-2, "dpos")
+    close(dcls, dxv[:, :, 0].sum((0, 1)), 1e-2, "dcls")
+    close(dtmp, dxv[:, :, 1:].sum((0, 2)), 1e-2, "dtemporal")
+
+
+def test_cls_merge_copy_colsum_add(dev):
+    from youku_mplug_amd import ops
+    B, T, N1, D = 2, 3, 4, 64
+    xt, a = rn(B * T * N1, D, dev=dev, seed=70), rn(B * T * N1, D, dev=dev, seed=71)
+    y = ops.vit_cls_merge_fwd(xt, a, B, T, N1, D).view(B, T, N1, D).float()
+    xv, av = xt.view(B, T, N1, D).float(), a.view(B, T, N1, D).float()
+    close(y[:, :, 1:], xv[:, :, 1:] + av[:, :, 1:], 1e-2, "merge tokens")
+    close(y[:, :, 0], xv[:, :, 0] + av[:, :, 0].mean(1, keepdim=True), 1e-2, "merge cls")
+    dy = rn(B * T * N1, D, dev=dev, seed=72)
+    da = ops.vit_cls_merge_bwd(dy, B, T, N1, D).view(B, T, N1, D).float()
+    dyv = dy.view(B, T, N1, D).float()
+    assert torch.equal(da[:, :, 1:], dyv[:, :, 1:])
+    close(da[:, :, 0], (dyv[:, :, 0].sum(1, keepdim=True) / T).expand(B, T, D), 1e-2, "merge bwd cls")
+    s = ops.colsum(dy, B * T * N1, D)
+    close(s, dyv.sum((0, 1, 2)), 1e-2, "colsum")
+    s2 = ops.colsum(dy, B * T * (N1 - 1), D, rmap=(N1 - 1, N1, 1))
+    close(s2, dyv[:, :, 1:].sum((0, 1, 2)), 1e-2, "colsum mapped")
+    close(ops.add(xt, a), xv.view(-1, D) + av.view(-1, D), 1e-2, "add")
+    dst = torch.zeros(B * T * N1, D, dtype=torch.bfloat16, device=dev)
+    ops.copy_rows(xt, dst, B * T, D, smap=(1, N1, 0), dmap=(1, N1, 0))
+    assert torch.equal(dst.view(B * T, N1, D)[:, 0], xt.view(B * T, N1, D)[:, 0]) and dst.view(B * T, N1, D)[:, 1:].abs().max().item() == 0
+
+
+def test_gpt_embed_and_cross_entropy(dev):
+    from youku_mplug_amd import ops
+    B, Q, L, H, V = 2, 8, 6, 256, 1024
+    query, wte, wpe = rn(B * Q, H, dev=dev, seed=80), rn(V, H, dev=dev, seed=81), rn(64, H, dev=dev, seed=82)
+    ids = torch.randint(0, V, (B, L), device=dev)
+    h = ops.gpt_embed_fwd(query, ids, wte, wpe, B, Q, L, H).view(B, Q + L, H)
+    ref = torch.cat([query.view(B, Q, H).float(), wte[ids].float()], 1) + wpe[:Q + L].float()[None]
+    close(h, ref, 1e-2, "gpt embed")
+    dh = rn(B * (Q + L), H, dev=dev, seed=83)
+    dq = ops.gpt_embed_bwd(dh, B, Q, L, H)
+    assert torch.equal(dq.view(B, Q, H), dh.view(B, Q + L, H)[:, :Q])
+    hd_ = ops.gpt_embed_fwd(query, ids, wte, wpe, B, Q, L, H, dropout_p=0.5, seed=3, offset=11)
+    dqd = ops.gpt_embed_bwd(dh, B, Q, L, H, dropout_p=0.5, seed=3, offset=11)
+    kept_f = hd_.view(B, Q + L, H)[:, :Q] != 0
+    kept_b = dqd.view(B, Q, H) != 0
+    assert (kept_f == kept_b).float().mean().item() > 0.995          # same mask fwd/bwd (zeros in data are rare)
+    # cross entropy
+    rows = 37
+    logits = rn(rows, V, dev=dev, seed=84, scale=3.0)
+    labels = torch.randint(0, V, (rows,), device=dev)
+    w = (torch.rand(rows, device=dev) > 0.3).float()
+    w = w / w.sum()
+    dlogits = torch.empty_like(logits)
+    losses, loss_sum = ops.cross_entropy(logits, labels, w, rows, V, dlogits=dlogits)
+    lf = logits.float().requires_grad_(True)
+    ref_l = F.cross_entropy(lf, labels, reduction="none")
+    close(losses, ref_l, 1e-3, "CE losses")
+    (ref_l * w).sum().backward()
+    assert abs(loss_sum.item() - (ref_l * w).sum().item()) < 1e-3 * abs(loss_sum.item())
+    close(dlogits, lf.grad, 1e-2, "CE dlogits")
+
+
+def test_adamw_and_gradnorm(dev):
+    from youku_mplug_amd import ops
+    n = 4096 * 3 + 8
+    torch.manual_seed(0)
+    master = torch.randn(n, device=dev)
+    p16 = master.bfloat16()
+    m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    g = (torch.randn(n, device=dev) * 3).bfloat16()
+    ref_p, ref_m, ref_v = master.clone(), m.clone(), v.clone()
+    sumsq = torch.zeros((), device=dev)
+    ops.grad_sumsq(g, sumsq)
+    assert abs(sumsq.item() - (g.float() ** 2).sum().item()) < 1e-3 * sumsq.item()
+    lr, b1, b2, eps, wd, clip = 1e-3, 0.9, 0.999, 1e-6, 0.05, 3.0
+    for step in (1, 2, 3):
+        ops.adamw_step(p16, master, m, v, g, lr, b1, b2, eps, wd, step, 1.0, sumsq, clip)
+        gn = g.float().norm()
+        gg = g.float() * min(1.0, (clip / (gn + 1e-6)).item())
+        ref_p.mul_(1 - lr * wd)
+        ref_m.mul_(b1).add_(gg, alpha=1 - b1)
+        ref_v.mul_(b2).addcmul_(gg, gg, value=1 - b2)
+        denom = (ref_v.sqrt() / math.sqrt(1 - b2 ** step)).add_(eps)
+        ref_p.addcdiv_(ref_m, denom, value=-lr / (1 - b1 ** step))
+    close(master, ref_p, 1e-4, "AdamW master")
+    close(m, ref_m, 1e-4, "AdamW m")
+    close(v, ref_v, 1e-4, "AdamW v")
+    assert torch.equal(p16, master.bfloat16())

@@ -1,0 +1,102 @@
+"""ctypes binding of libmpv_hip.so (the C ABI declared in include/mpv.h).
+
+The product path has NO CPU / PyTorch fallback: if the library is missing or a call fails
+this module raises.  Build with `python __graft_entry__.py` (or `make -C youku-mplug_amd/csrc`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmpv_hip.so")
+
+c_void_p, c_int, c_int64, c_float, c_uint64, c_size_t = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
+
+
+class GemmEpilogue(C.Structure):
+    _fields_ = [
+        ("a_group", c_int), ("a_stride", c_int), ("a_offset", c_int),
+        ("c_group", c_int), ("c_stride", c_int), ("c_offset", c_int),
+        ("k_group", c_int), ("k_stride", c_int), ("k_offset", c_int),
+        ("bias", c_void_p), ("act", c_int), ("preact_out", c_void_p),
+        ("residual", c_void_p), ("ldr", c_int64),
+        ("act_bwd_z", c_void_p), ("ldz", c_int64), ("act_bwd", c_int),
+        ("dropout_p", c_float), ("seed", c_uint64), ("offset", c_uint64),
+        ("alpha_dev", c_void_p), ("alpha", c_float), ("out_f32", c_int), ("accumulate", c_int),
+    ]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [
+        ("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("o", c_void_p), ("lse", c_void_p),
+        ("q_bs", c_int64), ("q_hs", c_int64), ("q_rs", c_int64),
+        ("k_bs", c_int64), ("k_hs", c_int64), ("k_rs", c_int64),
+        ("v_bs", c_int64), ("v_hs", c_int64), ("v_rs", c_int64),
+        ("o_bs", c_int64), ("o_hs", c_int64), ("o_rs", c_int64),
+        ("batch", c_int), ("heads", c_int), ("sq", c_int), ("sk", c_int), ("head_dim", c_int),
+        ("causal", c_int), ("scale", c_float), ("scale_q_bf16", c_int),
+        ("dropout_p", c_float), ("seed", c_uint64), ("offset", c_uint64),
+    ]
+
+
+_RM = [c_int, c_int, c_int]
+_SIGS = {
+    "mpv_version": (c_int, []),
+    "mpv_last_error": (C.c_char_p, []),
+    "mpv_check_device": (c_int, []),
+    "mpv_gemm_workspace_size": (c_size_t, [c_int64, c_int64, c_int64, c_int, c_int]),
+    "mpv_gemm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64,
+                              c_int, c_int, C.POINTER(GemmEpilogue), c_void_p, c_size_t, c_void_p]),
+    "mpv_layernorm_fwd": (c_int, [c_void_p] * 6 + [c_int64] * 4 + [c_float] + _RM + _RM + [c_void_p]),
+    "mpv_layernorm_bwd_workspace_size": (c_size_t, [c_int64]),
+    "mpv_layernorm_bwd": (c_int, [c_void_p] * 8 + [c_float, c_uint64, c_uint64, c_void_p, c_void_p, c_int] +
+                          [c_int64] * 4 + _RM + _RM + [c_void_p, c_size_t, c_void_p]),
+    "mpv_attn_fwd": (c_int, [C.POINTER(AttnDesc), c_void_p]),
+    "mpv_attn_bwd": (c_int, [C.POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mpv_temporal_attn_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int64, c_int64, c_int, c_int, c_int,
+                                      c_float, c_void_p]),
+    "mpv_temporal_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int64, c_int64, c_int,
+                                      c_int, c_int, c_float, c_void_p]),
+    "mpv_im2col_patches": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    "mpv_vit_embed_assemble_fwd": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
+    "mpv_vit_embed_assemble_bwd": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
+    "mpv_vit_cls_merge_fwd": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
+    "mpv_vit_cls_merge_bwd": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
+    "mpv_copy_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64] + _RM + _RM + [c_void_p]),
+    "mpv_colsum_workspace_size": (c_size_t, [c_int64]),
+    "mpv_colsum": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64] + _RM + [c_int, c_void_p, c_size_t, c_void_p]),
+    "mpv_add": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mpv_gpt_embed_fwd": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_float, c_uint64, c_uint64, c_void_p]),
+    "mpv_gpt_embed_bwd": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_float, c_uint64, c_uint64, c_void_p]),
+    "mpv_cross_entropy": (c_int, [c_void_p] * 6 + [c_int64] * 3 + [c_void_p]),
+    "mpv_grad_sumsq": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "mpv_adamw_step": (c_int, [c_void_p] * 5 + [c_int64] + [c_float] * 5 + [c_int, c_float, c_void_p, c_float, c_void_p]),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+class MpvError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise MpvError(f"{LIB_PATH} not found: the HIP kernels are not built. "
+                           "Run `python __graft_entry__.py` (build()) first; there is no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)      # AttributeError if a declared symbol is missing
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        raise MpvError(f"{what} failed ({rc}): {lib().mpv_last_error().decode()}")

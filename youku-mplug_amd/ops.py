@@ -1,0 +1,264 @@
+"""Tensor-level wrappers over the C ABI (include/mpv.h).  PyTorch is used only for device
+memory and streams; every function here launches hand-written gfx950 kernels on the current
+stream.  No CPU / eager fallback exists: non-CUDA tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import AttnDesc, GemmEpilogue, check
+
+ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH = 0, 1, 2
+RowMap = Tuple[int, int, int]
+IDENT: RowMap = (0, 0, 0)
+
+_ws = {}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.MpvError("mpv ops run on the GPU only (no CPU fallback): got a CPU tensor")
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Stream-ordered scratch shared by all ops on a device (grown on demand)."""
+    key = torch.device(device).index or 0
+    w = _ws.get(key)
+    if w is None or w.numel() < nbytes:
+        w = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = w
+    return w
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: Optional[torch.Tensor] = None,
+         trans_a: bool = False, trans_b: bool = False, lda: Optional[int] = None, ldb: Optional[int] = None,
+         ldc: Optional[int] = None, bias=None, act: int = 0, preact_out=None, residual=None, ldr: int = 0,
+         act_bwd_z=None, act_bwd: int = 0, ldz: int = 0, dropout_p: float = 0.0, seed: int = 0, offset: int = 0,
+         alpha_dev=None, alpha: float = 0.0, amap: RowMap = IDENT, cmap: RowMap = IDENT, kmap: RowMap = IDENT,
+         out_rows: Optional[int] = None, accumulate: bool = False, out_f32: bool = False) -> torch.Tensor:
+    """C[M,N] = epilogue(sum_k A(m,k) B(n,k)).  See include/mpv.h:mpv_gemm_bf16."""
+    _need_cuda(a, b)
+    lda = lda if lda is not None else (M if trans_a else K)
+    ldb = ldb if ldb is not None else (N if trans_b else K)
+    ldc = ldc if ldc is not None else N
+    if out is None:
+        rows = out_rows if out_rows is not None else M
+        out = torch.empty((rows, ldc), dtype=torch.float32 if out_f32 else torch.bfloat16, device=a.device)
+    ep = GemmEpilogue()
+    ep.a_group, ep.a_stride, ep.a_offset = amap
+    ep.c_group, ep.c_stride, ep.c_offset = cmap
+    ep.k_group, ep.k_stride, ep.k_offset = kmap
+    ep.bias = _p(bias)
+    ep.act = act
+    ep.preact_out = _p(preact_out)
+    ep.residual = _p(residual)
+    ep.ldr = ldr
+    ep.act_bwd_z = _p(act_bwd_z)
+    ep.ldz = ldz
+    ep.act_bwd = act_bwd
+    ep.dropout_p = dropout_p
+    ep.seed = seed
+    ep.offset = offset
+    ep.alpha_dev = _p(alpha_dev)
+    ep.alpha = alpha
+    ep.out_f32 = int(out_f32)
+    ep.accumulate = int(accumulate)
+    ws, wsn = None, 0
+    if trans_a and trans_b and not out_f32:
+        wsn = _lib.lib().mpv_gemm_workspace_size(M, N, K, 1, 1)
+        ws = workspace(wsn, a.device)
+        wsn = ws.numel()
+    check(_lib.lib().mpv_gemm_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, lda, ldb, ldc, int(trans_a),
+                                   int(trans_b), C.byref(ep), _p(ws), wsn, _stream()), "mpv_gemm_bf16")
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, eps: float, rows: int, cols: int, *, out=None, xmap: RowMap = IDENT,
+                  ymap: RowMap = IDENT, out_rows: Optional[int] = None, ldx: Optional[int] = None,
+                  ldy: Optional[int] = None, want_stats: bool = True):
+    _need_cuda(x, gamma, beta)
+    ldx = ldx or cols
+    ldy = ldy or cols
+    if out is None:
+        out = torch.empty((out_rows if out_rows is not None else rows, ldy), dtype=torch.bfloat16, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if want_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if want_stats else None
+    check(_lib.lib().mpv_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), _p(mean), _p(rstd),
+                                       rows, cols, ldx, ldy, eps, *xmap, *ymap, _stream()), "mpv_layernorm_fwd")
+    return out, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, rows: int, cols: int, *, dres=None, dx=None, dx_drop=None,
+                  dropout_p: float = 0.0, seed: int = 0, offset: int = 0, dgamma=None, dbeta=None,
+                  accumulate_dparams: bool = False, xmap: RowMap = IDENT, ymap: RowMap = IDENT,
+                  ldx: Optional[int] = None, ldy: Optional[int] = None, dx_rows: Optional[int] = None):
+    _need_cuda(dy, x, gamma)
+    ldx = ldx or cols
+    ldy = ldy or cols
+    if dx is None:
+        dx = torch.empty((dx_rows if dx_rows is not None else rows, ldx), dtype=torch.bfloat16, device=x.device)
+    ws, wsn = None, 0
+    if dgamma is not None:
+        wsn = _lib.lib().mpv_layernorm_bwd_workspace_size(cols)
+        ws = workspace(wsn, x.device)
+        wsn = ws.numel()
+    check(_lib.lib().mpv_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                       _p(dres), dx.data_ptr(), _p(dx_drop), dropout_p, seed, offset, _p(dgamma), _p(dbeta),
+                                       int(accumulate_dparams), rows, cols, ldx, ldy, *xmap, *ymap, _p(ws), wsn, _stream()),
+          "mpv_layernorm_bwd")
+    return dx
+
+
+class AttnLayout:
+    """Strides (in elements) of q/k/v/o for mpv_attn_*: (batch, head, row)."""
+
+    def __init__(self, q, k, v, o):
+        self.q, self.k, self.v, self.o = q, k, v, o
+
+
+def _attn_desc(q, k, v, o, lse, lay: AttnLayout, batch, heads, sq, sk, hd, causal, scale, scale_q_bf16, dropout_p, seed,
+               offset):
+    d = AttnDesc()
+    d.q, d.k, d.v, d.o, d.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), _p(lse)
+    d.q_bs, d.q_hs, d.q_rs = lay.q
+    d.k_bs, d.k_hs, d.k_rs = lay.k
+    d.v_bs, d.v_hs, d.v_rs = lay.v
+    d.o_bs, d.o_hs, d.o_rs = lay.o
+    d.batch, d.heads, d.sq, d.sk, d.head_dim = batch, heads, sq, sk, hd
+    d.causal, d.scale, d.scale_q_bf16 = int(causal), scale, int(scale_q_bf16)
+    d.dropout_p, d.seed, d.offset = dropout_p, seed, offset
+    return d
+
+
+def attn_fwd(q, k, v, o, lay: AttnLayout, batch, heads, sq, sk, hd, *, causal=False, scale=1.0, scale_q_bf16=False,
+             dropout_p=0.0, seed=0, offset=0):
+    """q/k/v/o are tensors whose data_ptr() is element (0,0,0,0) under `lay`; returns lse [batch, heads, sq]."""
+    _need_cuda(q, k, v, o)
+    lse = torch.empty((batch, heads, sq), dtype=torch.float32, device=q.device)
+    d = _attn_desc(q, k, v, o, lse, lay, batch, heads, sq, sk, hd, causal, scale, scale_q_bf16, dropout_p, seed, offset)
+    check(_lib.lib().mpv_attn_fwd(C.byref(d), _stream()), "mpv_attn_fwd")
+    return lse
+
+
+def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, lay: AttnLayout, batch, heads, sq, sk, hd, *, causal=False, scale=1.0,
+             scale_q_bf16=False, dropout_p=0.0, seed=0, offset=0):
+    _need_cuda(q, k, v, o, do, dq, dk, dv)
+    delta = torch.empty((batch, heads, sq), dtype=torch.float32, device=q.device)
+    d = _attn_desc(q, k, v, o, lse, lay, batch, heads, sq, sk, hd, causal, scale, scale_q_bf16, dropout_p, seed, offset)
+    check(_lib.lib().mpv_attn_bwd(C.byref(d), do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(),
+                                  _stream()), "mpv_attn_bwd")
+
+
+def temporal_attn_fwd(qkv, out, n_outer, outer_stride, n_inner, inner_offset, t_stride, T, heads, hd, scale):
+    _need_cuda(qkv, out)
+    check(_lib.lib().mpv_temporal_attn_fwd(qkv.data_ptr(), out.data_ptr(), n_outer, outer_stride, n_inner, inner_offset,
+                                           t_stride, T, heads, hd, scale, _stream()), "mpv_temporal_attn_fwd")
+
+
+def temporal_attn_bwd(qkv, dout, dqkv, n_outer, outer_stride, n_inner, inner_offset, t_stride, T, heads, hd, scale):
+    _need_cuda(qkv, dout, dqkv)
+    check(_lib.lib().mpv_temporal_attn_bwd(qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), n_outer, outer_stride, n_inner,
+                                           inner_offset, t_stride, T, heads, hd, scale, _stream()), "mpv_temporal_attn_bwd")
+
+
+def im2col_patches(video, B, Cc, T, H, W, P, kpad):
+    _need_cuda(video)
+    rows = B * T * (H // P) * (W // P)
+    cols = torch.empty((rows, kpad), dtype=torch.bfloat16, device=video.device)
+    check(_lib.lib().mpv_im2col_patches(video.data_ptr(), cols.data_ptr(), B, Cc, T, H, W, P, kpad, _stream()),
+          "mpv_im2col_patches")
+    return cols
+
+
+def vit_embed_assemble_fwd(patch, cls_token, pos_embed, temporal_embed, B, T, N, D):
+    x = torch.empty((B * T * (N + 1), D), dtype=torch.bfloat16, device=patch.device)
+    check(_lib.lib().mpv_vit_embed_assemble_fwd(patch.data_ptr(), cls_token.data_ptr(), pos_embed.data_ptr(),
+                                                temporal_embed.data_ptr(), x.data_ptr(), B, T, N, D, _stream()),
+          "mpv_vit_embed_assemble_fwd")
+    return x
+
+
+def vit_embed_assemble_bwd(dx, dpatch, dcls, dpos, dtemporal, B, T, N, D):
+    check(_lib.lib().mpv_vit_embed_assemble_bwd(dx.data_ptr(), dpatch.data_ptr(), dcls.data_ptr(), dpos.data_ptr(),
+                                                dtemporal.data_ptr(), B, T, N, D, _stream()), "mpv_vit_embed_assemble_bwd")
+
+
+def vit_cls_merge_fwd(xt, a, B, T, N1, D, out=None):
+    y = out if out is not None else torch.empty_like(xt)
+    check(_lib.lib().mpv_vit_cls_merge_fwd(xt.data_ptr(), a.data_ptr(), y.data_ptr(), B, T, N1, D, _stream()),
+          "mpv_vit_cls_merge_fwd")
+    return y
+
+
+def vit_cls_merge_bwd(dy, B, T, N1, D, out=None):
+    da = out if out is not None else torch.empty_like(dy)
+    check(_lib.lib().mpv_vit_cls_merge_bwd(dy.data_ptr(), da.data_ptr(), B, T, N1, D, _stream()), "mpv_vit_cls_merge_bwd")
+    return da
+
+
+def copy_rows(src, dst, rows, cols, smap: RowMap = IDENT, dmap: RowMap = IDENT, lds=None, ldd=None):
+    check(_lib.lib().mpv_copy_rows(src.data_ptr(), dst.data_ptr(), rows, cols, lds or cols, ldd or cols, *smap, *dmap,
+                                   _stream()), "mpv_copy_rows")
+    return dst
+
+
+def colsum(x, rows, cols, *, out=None, ld=None, rmap: RowMap = IDENT, accumulate=False):
+    if out is None:
+        out = torch.empty(cols, dtype=torch.bfloat16, device=x.device)
+    wsn = _lib.lib().mpv_colsum_workspace_size(cols)
+    ws = workspace(wsn, x.device)
+    check(_lib.lib().mpv_colsum(x.data_ptr(), out.data_ptr(), rows, cols, ld or cols, *rmap, int(accumulate), ws.data_ptr(),
+                                ws.numel(), _stream()), "mpv_colsum")
+    return out
+
+
+def add(a, b, out=None):
+    out = out if out is not None else torch.empty_like(a)
+    check(_lib.lib().mpv_add(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "mpv_add")
+    return out
+
+
+def gpt_embed_fwd(query, ids, wte, wpe, B, Q, L, H, dropout_p=0.0, seed=0, offset=0):
+    h = torch.empty((B * (Q + L), H), dtype=torch.bfloat16, device=wte.device)
+    check(_lib.lib().mpv_gpt_embed_fwd(_p(query), ids.data_ptr(), wte.data_ptr(), wpe.data_ptr(), h.data_ptr(), B, Q, L, H,
+                                       dropout_p, seed, offset, _stream()), "mpv_gpt_embed_fwd")
+    return h
+
+
+def gpt_embed_bwd(dh, B, Q, L, H, dropout_p=0.0, seed=0, offset=0):
+    dq = torch.empty((B * Q, H), dtype=torch.bfloat16, device=dh.device)
+    check(_lib.lib().mpv_gpt_embed_bwd(dh.data_ptr(), dq.data_ptr(), B, Q, L, H, dropout_p, seed, offset, _stream()),
+          "mpv_gpt_embed_bwd")
+    return dq
+
+
+def cross_entropy(logits, labels, weight, rows, vocab, *, ld=None, dlogits=None, want_losses=True):
+    """Returns (losses[rows] fp32, loss_sum fp32 scalar tensor)."""
+    losses = torch.empty(rows, dtype=torch.float32, device=logits.device) if want_losses else None
+    loss_sum = torch.zeros((), dtype=torch.float32, device=logits.device)
+    check(_lib.lib().mpv_cross_entropy(logits.data_ptr(), labels.data_ptr(), _p(weight), _p(losses), loss_sum.data_ptr(),
+                                       _p(dlogits), rows, vocab, ld or vocab, _stream()), "mpv_cross_entropy")
+    return losses, loss_sum
+
+
+def grad_sumsq(grad_flat, sumsq):
+    check(_lib.lib().mpv_grad_sumsq(grad_flat.data_ptr(), grad_flat.numel(), sumsq.data_ptr(), _stream()), "mpv_grad_sumsq")
+
+
+def adamw_step(p16, master, m, v, g16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, sumsq=None, max_norm=0.0):
+    check(_lib.lib().mpv_adamw_step(p16.data_ptr(), master.data_ptr(), m.data_ptr(), v.data_ptr(), g16.data_ptr(), p16.numel(),
+                                    lr, beta1, beta2, eps, wd, step, grad_scale, _p(sumsq), max_norm, _stream()),
+          "mpv_adamw_step")
