@@ -191,6 +191,16 @@ int mpv_adamw_step(void* param_bf16, float* master, float* exp_avg, float* exp_a
                    int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                    float grad_scale, const float* sumsq, float max_norm, mpv_stream_t stream);
 
+/* Grouped AdamW over a flat buffer laid out in backward-completion order (so data-parallel
+ * gradient buckets are contiguous slices): tile_group[i] (device, uint8) is the parameter-group
+ * id (0..ngroups-1; >= 8 = skip) of the i-th 256-element tile; lrs/wds are HOST arrays of the
+ * per-group learning rate (lr_schedule * lr_scale, run_pretrain_distributed_gpt3.py:88-96) and
+ * weight decay (optim/optim_factory.py:219-265). */
+int mpv_adamw_step_grouped(void* param_bf16, float* master, float* exp_avg, float* exp_avg_sq, const void* grad_bf16,
+                           int64_t n, const uint8_t* tile_group, const float* lrs, const float* wds, int ngroups,
+                           float beta1, float beta2, float eps, int step, float grad_scale, const float* sumsq,
+                           float max_norm, mpv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

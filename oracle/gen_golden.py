@@ -42,7 +42,7 @@ def run_case(name: str):
     cfg, B, L, wseed, iseed, ragged, (sfrom, vstep) = CASES[name]
     rec = {"meta": dict(case=name, batch=B, text_len=L, weight_seed=wseed, input_seed=iseed,
                         ragged=ragged, logits_seq_from=sfrom, logits_vocab_step=vstep,
-                        torch=torch.__version__)}
+                        torch=str(torch.__version__))}
     for tag, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
         t0 = time.time()
         model, sd = build_reference_model(cfg, wseed, dtype=dtype)

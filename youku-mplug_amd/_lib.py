@@ -72,6 +72,8 @@ _SIGS = {
     "mpv_cross_entropy": (c_int, [c_void_p] * 6 + [c_int64] * 3 + [c_void_p]),
     "mpv_grad_sumsq": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "mpv_adamw_step": (c_int, [c_void_p] * 5 + [c_int64] + [c_float] * 5 + [c_int, c_float, c_void_p, c_float, c_void_p]),
+    "mpv_adamw_step_grouped": (c_int, [c_void_p] * 5 + [c_int64, c_void_p, C.POINTER(c_float), C.POINTER(c_float), c_int,
+                                       c_float, c_float, c_float, c_int, c_float, c_void_p, c_float, c_void_p]),
 }
 EXPORTS = tuple(_SIGS)
 

@@ -54,7 +54,74 @@ __global__ __launch_bounds__(256) void adamw_kernel(bf16* __restrict__ p16, floa
   }
 }
 
+struct GroupHyper {
+  float lr[8];
+  float wd[8];
+};
+
+// Grouped variant: the flat buffer is laid out in backward-completion order (so DP buckets are
+// contiguous slices); every 256-element tile carries the id of its parameter group.
+__global__ __launch_bounds__(256) void adamw_grouped_kernel(bf16* __restrict__ p16, float* __restrict__ p, float* __restrict__ m,
+                                                            float* __restrict__ v, const bf16* __restrict__ g, long long ntiles,
+                                                            const uint8_t* __restrict__ tile_group, GroupHyper hp, float b1,
+                                                            float b2, float eps, float inv_bc1, float inv_sqrt_bc2,
+                                                            float grad_scale, const float* __restrict__ sumsq, float max_norm) {
+  float gs = grad_scale;
+  if (sumsq && max_norm > 0.f) {
+    const float norm = sqrtf(*sumsq) * grad_scale;
+    const float coef = max_norm / (norm + 1e-6f);
+    if (coef < 1.0f) gs *= coef;
+  }
+  const int lane4 = threadIdx.x & 63;       // 64 lanes x 4 elements = one 256-element tile per wave
+  const int wave = threadIdx.x >> 6;
+  for (long long t = (long long)blockIdx.x * 4 + wave; t < ntiles; t += (long long)gridDim.x * 4) {
+    const int grp = tile_group[t];
+    if (grp >= 8) continue;                  // padding / frozen tile
+    const float lr = hp.lr[grp], wd = hp.wd[grp];
+    const long long i = t * 256 + lane4 * 4;
+    f32x4 pp = *(const f32x4*)(p + i), mm = *(const f32x4*)(m + i), vv = *(const f32x4*)(v + i);
+    const f32x4 gg = cvt4(*(const bf16x4*)(g + i)) * gs;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      pp[e] *= (1.0f - lr * wd);
+      mm[e] = mm[e] * b1 + (1.0f - b1) * gg[e];
+      vv[e] = vv[e] * b2 + (1.0f - b2) * gg[e] * gg[e];
+      const float denom = sqrtf(vv[e]) * inv_sqrt_bc2 + eps;
+      pp[e] -= (lr * inv_bc1) * mm[e] / denom;
+    }
+    *(f32x4*)(p + i) = pp;
+    *(f32x4*)(m + i) = mm;
+    *(f32x4*)(v + i) = vv;
+    *(bf16x4*)(p16 + i) = cvt4(pp);
+  }
+}
+
 }  // namespace
+
+extern "C" int mpv_adamw_step_grouped(void* param_bf16, float* master, float* exp_avg, float* exp_avg_sq,
+                                      const void* grad_bf16, int64_t n, const uint8_t* tile_group, const float* lrs,
+                                      const float* wds, int ngroups, float beta1, float beta2, float eps, int step,
+                                      float grad_scale, const float* sumsq, float max_norm, hipStream_t stream) {
+  MPV_REQUIRE(param_bf16 && master && exp_avg && exp_avg_sq && grad_bf16 && tile_group && lrs && wds, MPV_E_ARG,
+              "mpv_adamw_step_grouped: null pointer");
+  MPV_REQUIRE(n >= 0 && n % 256 == 0, MPV_E_SHAPE, "mpv_adamw_step_grouped: n (%lld) must be a multiple of the 256-element tile", (long long)n);
+  MPV_REQUIRE(ngroups >= 1 && ngroups <= 8, MPV_E_ARG, "mpv_adamw_step_grouped: 1..8 parameter groups");
+  MPV_REQUIRE(step >= 1, MPV_E_ARG, "mpv_adamw_step_grouped: step counts from 1");
+  if (n == 0) return MPV_OK;
+  GroupHyper hp = {};
+  for (int i = 0; i < ngroups; ++i) {
+    hp.lr[i] = lrs[i];
+    hp.wd[i] = wds[i];
+  }
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  const long long ntiles = n / 256;
+  long long blocks = (ntiles + 3) / 4;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(adamw_grouped_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (bf16*)param_bf16, master, exp_avg,
+                     exp_avg_sq, (const bf16*)grad_bf16, ntiles, tile_group, hp, beta1, beta2, eps, (float)(1.0 / bc1),
+                     (float)(1.0 / sqrt(bc2)), grad_scale, sumsq, max_norm);
+  return mpv_check_launch("mpv_adamw_step_grouped");
+}
 
 extern "C" int mpv_grad_sumsq(const void* grad, int64_t n, float* sumsq, hipStream_t stream) {
   MPV_REQUIRE(grad && sumsq, MPV_E_ARG, "mpv_grad_sumsq: null pointer");

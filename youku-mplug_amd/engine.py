@@ -1,0 +1,271 @@
+"""Native data-parallel engine with the DeepSpeed-shaped surface the reference loop uses
+(run_pretrain_distributed_gpt3.py:46-53,72-73,88-96,109,136-137,263-267; utils.py:379-480):
+
+    engine, optimizer, _, _ = initialize(args=args, model=model, model_parameters=param_groups)
+    loss, _ = engine(video, text); engine.backward(loss); engine.step()
+
+MI355X-first design (not a DeepSpeed translation):
+  * all trainable parameters / gradients live in ONE flat bf16 buffer each, laid out in
+    backward-completion order (head -> ViT block 11 ... 0 -> stem); fp32 master/m/v are flat too.
+    Parameters and their .grad are views, so the backward kernels write gradients in place.
+  * a DP bucket is a contiguous slice of the flat gradient buffer: as soon as a stage's backward
+    has been launched the engine issues an RCCL all-reduce of that slice (torch.distributed
+    'nccl' == RCCL; ProcessGroupNCCL runs it on its own HIP stream, ordered after the compute
+    stream's work so far), so every bucket overlaps the remaining backward.  The frozen
+    GPT's dgrad runs first and produces no gradients, so all traffic hides under the ViT
+    backward.  No ZeRO sharding: 130 M trainable params -> 1.6 GB of state.
+  * step(): one sum-of-squares kernel + ONE grouped AdamW launch over the flat buffer
+    (per-256-element-tile group ids select lr*lr_scale / weight decay), global-norm clip
+    folded in, bf16 parameter write-back fused.
+The bucketing / averaging logic is device-agnostic (CPU + gloo in tests); the optimizer
+kernels exist only as HIP (no CPU fallback).
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+TILE = 256
+
+
+def get_parameter_groups(model: nn.Module, weight_decay=0.05, skip_list=(), visual_backbone_scale=False):
+    """optim/optim_factory.py:219-265 restated: decay / no_decay (1-D, *.bias, skip list, names
+    containing 'bias' or 'LayerNorm.weight') x optional 'visual_encoder_' lr_scale 0.1 groups."""
+    groups: Dict[str, dict] = {}
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        nd = p.dim() == 1 or name.endswith(".bias") or name in skip_list or "bias" in name or "LayerNorm.weight" in name
+        g = "no_decay" if nd else "decay"
+        vis = visual_backbone_scale and "visual_encoder." in name and "temporal" not in name
+        if vis:
+            g = "visual_encoder_" + g
+        if g not in groups:
+            groups[g] = {"weight_decay": 0.0 if nd else weight_decay, "params": [], "lr_scale": 0.1 if vis else 1.0, "name": g}
+        groups[g]["params"].append(p)
+    return list(groups.values())
+
+
+def default_stages(model: nn.Module) -> List[Tuple[str, List[nn.Parameter]]]:
+    """Backward-completion order of a DistributedGPT3_Pretrain-shaped model; any other module is one stage."""
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    ve = getattr(model, "visual_encoder", None)
+    if ve is None or not hasattr(ve, "blocks"):
+        return [("all", [p for _, p in named])]
+    depth = len(ve.blocks)
+    stages: List[Tuple[str, List[nn.Parameter]]] = [("head", [])] + [(f"block{i}", []) for i in range(depth - 1, -1, -1)] + [("stem", [])]
+    index = {name: i for i, (name, _) in enumerate(stages)}
+    for n, p in named:
+        if n.startswith("visual_encoder.blocks."):
+            bi = int(n.split(".")[2])
+            stages[index[f"block{bi}"]][1].append(p)
+        elif n.startswith("visual_encoder.norm."):
+            stages[index[f"block{depth - 1}"]][1].append(p)      # final LN grads are complete before block depth-1's
+        elif n.startswith("visual_encoder."):
+            stages[index["stem"]][1].append(p)
+        else:
+            stages[index["head"]][1].append(p)
+    return [s for s in stages if s[1]]
+
+
+class FlatParams:
+    """Flat bf16 parameter/gradient buffers (+ stage slices) with the parameters re-pointed at views."""
+
+    def __init__(self, stages: Sequence[Tuple[str, Sequence[nn.Parameter]]], group_of: Optional[Dict[int, int]] = None,
+                 dtype=None):
+        params = [p for _, ps in stages for p in ps]
+        assert params, "no trainable parameters"
+        self.device = params[0].device
+        self.dtype = dtype or params[0].dtype
+        off = 0
+        self.slots: List[Tuple[nn.Parameter, int, int]] = []
+        self.stage_slices: Dict[str, Tuple[int, int]] = {}
+        for name, ps in stages:
+            start = off
+            for p in ps:
+                n = p.numel()
+                self.slots.append((p, off, n))
+                off += (n + TILE - 1) // TILE * TILE
+            self.stage_slices[name] = (start, off)
+        self.numel = off
+        self.params = torch.zeros(off, dtype=self.dtype, device=self.device)
+        self.grads = torch.zeros(off, dtype=self.dtype, device=self.device)
+        tiles = torch.full((off // TILE,), 255, dtype=torch.uint8)
+        for p, o, n in self.slots:
+            self.params[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.params[o:o + n].view(p.shape)
+            p.grad = self.grads[o:o + n].view(p.shape)
+            if group_of is not None:
+                tiles[o // TILE:(o + n + TILE - 1) // TILE] = group_of[id(p)]
+        self.tile_group = tiles.to(self.device)
+
+
+class DPReducer:
+    """Bucketed gradient all-reduce over contiguous slices of FlatParams.grads (sum; the 1/world
+    average is folded into the optimizer's grad_scale).  Device-agnostic: RCCL on GPU, gloo on CPU."""
+
+    def __init__(self, flat: FlatParams, process_group=None):
+        self.flat = flat
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.pending = []
+        self.launched = set()
+
+    def stage_ready(self, name: str):
+        if self.world == 1 or name in self.launched or name not in self.flat.stage_slices:
+            return
+        a, b = self.flat.stage_slices[name]
+        self.launched.add(name)
+        self.pending.append(dist.all_reduce(self.flat.grads[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def finish(self):
+        """Launch whatever was not announced, then make the current stream wait for every bucket."""
+        if self.world > 1:
+            for name in self.flat.stage_slices:
+                self.stage_ready(name)
+            for w in self.pending:
+                w.wait()
+        self.pending.clear()
+        self.launched.clear()
+
+
+class FlatAdamW:
+    """torch.optim-shaped facade (param_groups with lr / lr_scale / weight_decay / betas mutated by the
+    training loop every step) over the grouped HIP AdamW kernel."""
+
+    def __init__(self, flat: FlatParams, param_groups: List[dict], lr=1e-4, betas=(0.9, 0.999), eps=1e-6, clip_grad=0.0):
+        assert len(param_groups) <= 8
+        self.flat = flat
+        self.param_groups = param_groups
+        for g in param_groups:
+            g.setdefault("lr", lr * g.get("lr_scale", 1.0))
+            g.setdefault("betas", list(betas))
+            g.setdefault("eps", eps)
+        self.clip_grad = clip_grad
+        self.master = flat.params.float()
+        self.exp_avg = torch.zeros_like(self.master)
+        self.exp_avg_sq = torch.zeros_like(self.master)
+        self.sumsq = torch.zeros((), dtype=torch.float32, device=flat.device)
+        self.step_count = 0
+        self.cur_scale = self.loss_scale = 1.0
+        self._grad_scale = 1.0
+
+    @property
+    def _global_grad_norm(self):
+        return math.sqrt(max(float(self.sumsq.item()), 0.0)) * self._grad_scale
+
+    def step(self, grad_scale: float = 1.0):
+        from . import ops
+        self.step_count += 1
+        self._grad_scale = grad_scale
+        self.sumsq.zero_()
+        ops.grad_sumsq(self.flat.grads, self.sumsq)
+        g0 = self.param_groups[0]
+        ops.adamw_step_grouped(self.flat.params, self.master, self.exp_avg, self.exp_avg_sq, self.flat.grads, self.flat.tile_group,
+                               [float(g["lr"]) for g in self.param_groups], [float(g["weight_decay"]) for g in self.param_groups],
+                               float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]), self.step_count, grad_scale,
+                               self.sumsq, float(self.clip_grad or 0.0))
+
+    def state_dict(self):
+        return {"master": self.master, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count,
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self.master.copy_(sd["master"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.step_count = sd["step"]
+        self.flat.params.copy_(self.master)
+
+
+class MplugEngine(nn.Module):
+    def __init__(self, model: nn.Module, param_groups: List[dict], lr=1e-4, betas=(0.9, 0.999), eps=1e-6, clip_grad=0.0,
+                 process_group=None):
+        super().__init__()
+        self.module = model
+        group_of = {id(p): gi for gi, g in enumerate(param_groups) for p in g["params"]}
+        stages = default_stages(model)
+        stages = [(n, [p for p in ps if id(p) in group_of]) for n, ps in stages]
+        stages = [s for s in stages if s[1]]
+        self.flat = FlatParams(stages, group_of)
+        self.reducer = DPReducer(self.flat, process_group)
+        self.optimizer = FlatAdamW(self.flat, param_groups, lr=lr, betas=betas, eps=eps, clip_grad=clip_grad)
+        self.micro_steps = 0
+        self.global_steps = 0
+        ve = getattr(model, "visual_encoder", None)
+        if ve is not None and hasattr(ve, "on_block_grads_ready"):
+            depth = len(ve.blocks)
+            ve.on_block_grads_ready = lambda bi: self.reducer.stage_ready("stem" if bi < 0 else f"block{bi}")
+            assert depth > 0
+        if hasattr(model, "on_stage_grads_ready"):
+            model.on_stage_grads_ready = self.reducer.stage_ready
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+    def backward(self, loss):
+        loss.backward()
+        self.micro_steps += 1
+
+    def step(self):
+        self.reducer.finish()
+        self.optimizer.step(grad_scale=1.0 / self.reducer.world)
+        self.global_steps += 1
+        td = getattr(self.module, "text_decoder", None)
+        if td is not None and hasattr(td, "step_seed"):
+            td.step_seed = self.global_steps * 0x9E3779B1 + (dist.get_rank() if dist.is_initialized() else 0)
+
+    def zero_grad(self):
+        pass      # every gradient is overwritten (never accumulated) by the next backward
+
+    # ---- DeepSpeed-layout checkpoints: <dir>/<tag>/mp_rank_00_model_states.pt with key 'module' (utils.py:476-480)
+    def save_checkpoint(self, save_dir, tag=None, client_state=None):
+        tag = tag or f"global_step{self.global_steps}"
+        d = os.path.join(save_dir, str(tag))
+        if not dist.is_initialized() or dist.get_rank() == 0:
+            os.makedirs(d, exist_ok=True)
+            state = {"module": {k: v.detach().cpu() for k, v in self.module.state_dict().items()}}
+            state.update(client_state or {})
+            torch.save(state, os.path.join(d, "mp_rank_00_model_states.pt"))
+            torch.save({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in self.optimizer.state_dict().items()},
+                       os.path.join(d, "mp_rank_00_optim_states.pt"))
+            with open(os.path.join(save_dir, "latest"), "w") as f:
+                f.write(str(tag))
+        if dist.is_initialized():
+            dist.barrier()
+        return True
+
+    def load_checkpoint(self, load_dir, tag=None):
+        if tag is None:
+            with open(os.path.join(load_dir, "latest")) as f:
+                tag = f.read().strip()
+        d = os.path.join(load_dir, str(tag))
+        state = torch.load(os.path.join(d, "mp_rank_00_model_states.pt"), map_location="cpu")
+        self.module.load_state_dict(state.pop("module"), strict=False)
+        op = os.path.join(d, "mp_rank_00_optim_states.pt")
+        if os.path.isfile(op):
+            self.optimizer.load_state_dict(torch.load(op, map_location=self.flat.device))
+        else:
+            self.optimizer.master.copy_(self.flat.params.float())
+        return d, state
+
+
+def initialize(args=None, model=None, model_parameters=None, dist_init_required=None, mpu=None, config=None, **kw):
+    """deepspeed.initialize-shaped entry (run_pretrain_distributed_gpt3.py:263-267)."""
+    cfg = dict(config or {})
+
+    def pick(name, default):
+        if name in cfg:
+            return cfg[name]
+        return getattr(args, name, default) if args is not None else default
+
+    groups = list(model_parameters) if model_parameters is not None else get_parameter_groups(model, pick("weight_decay", 0.05))
+    groups = [g if isinstance(g, dict) else {"params": [g], "weight_decay": 0.0, "lr_scale": 1.0} for g in groups]
+    engine = MplugEngine(model, groups, lr=pick("lr", 1e-4), betas=tuple(pick("opt_betas", (0.9, 0.999))), eps=pick("opt_eps", 1e-6),
+                         clip_grad=pick("clip_grad", 0.0) or 0.0)
+    return engine, engine.optimizer, None, None

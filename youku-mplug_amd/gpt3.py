@@ -1,0 +1,294 @@
+"""Frozen GPT-3 causal LM (Megatron-style decoder) on the gfx950 kernels.
+
+Mirrors models/modeling_distributed_gpt3.py: GPT3Config :459-547, GPT3Embedding :598-666,
+GPT3ParallelAttention :820-938 (+ GPT3CoreAttention :689-817), GPT3ParallelMLP :550-595,
+GPT3ParallelTransformerLayer :982-1089, GPT3ParallelTransformer :1092-1186, GPT3Model
+:1272-1366, DistributedGPT3 :1522-1618 -- same attribute paths and state-dict keys
+(text_decoder.dist_model.language_model.{embedding,encoder}...), TP=1/PP=1.
+
+Rows are kept batch-major [B*S, H] (the reference's [s,b,h] transpose :653 is a pure
+permutation of rows; every op here is row-wise or addressed by strides).  The decoder is
+frozen in the pre-train recipe (models/distributed_gpt3.py:91-93), so backward computes
+dgrad only -- no weight gradients through 24 layers (the reference computes and discards
+them).  Dropout (hidden 0.1, attention-prob 0.1) is live in train() mode even though the
+weights are frozen and is regenerated from (seed, offset) in backward.
+"""
+from __future__ import annotations
+
+import json
+import math
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from .ops import ACT_GELU_TANH
+from .vision import Linear, _param
+
+
+class GPT3Config:
+    """Field names of configs/models/config_gpt3_*.json; every GPT3Config default (:463-496) overridable."""
+
+    def __init__(self, vocab_size=25600, hidden_size=768, ffn_hidden_size=None, num_hidden_layers=12, num_attention_heads=12,
+                 max_position_embeddings=2048, layernorm_epsilon=1e-12, hidden_dropout=0.1, attention_dropout=0.1,
+                 init_method_std=0.02, bias_gelu_fusion=True, apply_query_key_layer_scaling=True, **kw):
+        self.vocab_size, self.hidden_size = vocab_size, hidden_size
+        self.ffn_hidden_size = ffn_hidden_size or 4 * hidden_size
+        self.num_hidden_layers, self.num_attention_heads = num_hidden_layers, num_attention_heads
+        self.max_position_embeddings = max_position_embeddings
+        self.layernorm_epsilon = layernorm_epsilon
+        self.hidden_dropout, self.attention_dropout = hidden_dropout, attention_dropout
+        self.init_method_std = init_method_std
+        self.bias_gelu_fusion = bias_gelu_fusion
+        self.apply_query_key_layer_scaling = apply_query_key_layer_scaling
+        self.kv_channels = hidden_size // num_attention_heads
+        self.extra = kw
+
+    @classmethod
+    def from_json_file(cls, path):
+        with open(path) as f:
+            return cls(**json.load(f))
+
+    @classmethod
+    def from_pretrained(cls, model_dir):
+        import os
+        return cls.from_json_file(os.path.join(model_dir, "config.json"))
+
+
+class _LN(nn.Module):
+    def __init__(self, dim, eps, device=None):
+        super().__init__()
+        self.eps = eps
+        self.weight = _param(dim, const=1.0, device=device)
+        self.bias = _param(dim, const=0.0, device=device)
+
+
+class _WordEmbeddings(nn.Module):
+    """mpu.VocabParallelEmbedding at TP=1 (:619).  Callable like the reference's
+    (models/distributed_gpt3.py:155) -- the gather runs on the HIP embedding kernel."""
+
+    def __init__(self, vocab, hidden, std, device=None):
+        super().__init__()
+        self.weight = _param(vocab, hidden, std=std, device=device)
+        self._zero_pos = None
+
+    def forward(self, ids: torch.Tensor):
+        B, L = ids.shape
+        H = self.weight.shape[1]
+        if self._zero_pos is None or self._zero_pos.shape[0] < L:
+            self._zero_pos = torch.zeros((L, H), dtype=torch.bfloat16, device=self.weight.device)
+        return ops.gpt_embed_fwd(None, ids.contiguous(), self.weight, self._zero_pos, B, 0, L, H).view(B, L, H)
+
+
+class GPT3Embedding(nn.Module):
+    def __init__(self, cfg: GPT3Config, device=None):
+        super().__init__()
+        self.word_embeddings = _WordEmbeddings(cfg.vocab_size, cfg.hidden_size, cfg.init_method_std, device)
+        self.position_embeddings = nn.Module()
+        self.position_embeddings.weight = _param(cfg.max_position_embeddings, cfg.hidden_size, std=cfg.init_method_std, device=device)
+
+
+class GPT3ParallelAttention(nn.Module):
+    def __init__(self, cfg, layer_number, std, out_std, device=None):
+        super().__init__()
+        self.layer_number = max(1, layer_number)
+        H = cfg.hidden_size
+        self.query_key_value = Linear(H, 3 * H, std=std, device=device)     # rows head-major [h0:q,k,v | h1:q,k,v ...] (:895-902)
+        self.dense = Linear(H, H, std=out_std, device=device)
+
+
+class GPT3ParallelMLP(nn.Module):
+    def __init__(self, cfg, std, out_std, device=None):
+        super().__init__()
+        self.dense_h_to_4h = Linear(cfg.hidden_size, cfg.ffn_hidden_size, std=std, device=device)
+        self.dense_4h_to_h = Linear(cfg.ffn_hidden_size, cfg.hidden_size, std=out_std, device=device)
+
+
+class GPT3ParallelTransformerLayer(nn.Module):
+    def __init__(self, cfg, layer_number, std, out_std, device=None):
+        super().__init__()
+        self.layer_number = layer_number
+        self.input_layernorm = _LN(cfg.hidden_size, cfg.layernorm_epsilon, device)
+        self.self_attention = GPT3ParallelAttention(cfg, layer_number, std, out_std, device)
+        self.post_attention_layernorm = _LN(cfg.hidden_size, cfg.layernorm_epsilon, device)
+        self.mlp = GPT3ParallelMLP(cfg, std, out_std, device)
+
+
+class GPT3ParallelTransformer(nn.Module):
+    def __init__(self, cfg, device=None):
+        super().__init__()
+        std = cfg.init_method_std
+        out_std = std / math.sqrt(2.0 * cfg.num_hidden_layers)
+        self.layers = nn.ModuleList([GPT3ParallelTransformerLayer(cfg, i + 1, std, out_std, device)
+                                     for i in range(cfg.num_hidden_layers)])
+        self.final_layernorm = _LN(cfg.hidden_size, cfg.layernorm_epsilon, device)
+
+
+class GPT3TransformerLanguageModel(nn.Module):
+    def __init__(self, cfg, device=None):
+        super().__init__()
+        self.embedding = GPT3Embedding(cfg, device)
+        self.encoder = GPT3ParallelTransformer(cfg, device)
+
+
+class GPT3Model(nn.Module):
+    def __init__(self, cfg: GPT3Config, device=None):
+        super().__init__()
+        self.config = cfg
+        self.language_model = GPT3TransformerLanguageModel(cfg, device)
+
+    def word_embeddings_weight(self):
+        return self.language_model.embedding.word_embeddings.weight
+
+
+_SITE_EMBED, _SITE_ATTN, _SITE_DROP1, _SITE_DROP2 = 0, 1, 2, 3
+
+
+def _offset(layer: int, site: int) -> int:
+    return (layer * 4 + site) << 36
+
+
+class DistributedGPT3(nn.Module):
+    """Drop-in for models/modeling_distributed_gpt3.py:1522 at TP=1 (checkpoint loading of
+    `<model_dir>/model/mp_rank_00_model_states.pt['module']` :431-441 is kept)."""
+
+    def __init__(self, model_dir=None, rank=0, path_load_tag="model", config: Optional[GPT3Config] = None, device=None,
+                 load_state_dict=True, **kwargs):
+        super().__init__()
+        import os
+        self.config = config if config is not None else GPT3Config.from_pretrained(model_dir)
+        assert self.config.kv_channels in (64, 80, 96), "fused attention kernels are built for head_dim 64/80/96"
+        self.dist_model = GPT3Model(self.config, device=device)
+        if config is None and load_state_dict and model_dir is not None:
+            path = os.path.join(model_dir, str(path_load_tag), "mp_rank_00_model_states.pt")
+            if os.path.isfile(path):
+                sd = torch.load(path, map_location="cpu")["module"]
+                self.dist_model.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()})
+        self.inference_params = None
+        self.step_seed = 0        # bumped by the engine every step -> fresh dropout masks
+
+    # -------------------------------------------------------------- explicit forward / backward
+    def forward_lm(self, query_features: Optional[torch.Tensor], ids: torch.Tensor, labels: torch.Tensor,
+                   loss_mask: torch.Tensor, tape: dict, want_logits: bool = False):
+        """query_features [B*Q, H] (or None), ids [B,L] int64, labels [B,S] int64, loss_mask [B,S-1].
+        Returns dict(loss fp32 scalar, losses [B,S-1] fp32, logits?, last_hidden_state [B,S,H])."""
+        cfg = self.config
+        lm = self.dist_model.language_model
+        B, L = ids.shape
+        H, np_, hn, V = cfg.hidden_size, cfg.num_attention_heads, cfg.kv_channels, cfg.vocab_size
+        Q = 0 if query_features is None else query_features.shape[0] // B
+        S, R = Q + L, B * (Q + L)
+        train = self.training
+        p_h = cfg.hidden_dropout if train else 0.0
+        p_a = cfg.attention_dropout if train else 0.0
+        seed = self.step_seed
+        h = ops.gpt_embed_fwd(query_features, ids.contiguous(), lm.embedding.word_embeddings.weight,
+                              lm.embedding.position_embeddings.weight, B, Q, L, H, dropout_p=p_h, seed=seed,
+                              offset=_offset(0, _SITE_EMBED))
+        st3 = (S * 3 * H, 3 * hn, 3 * H)
+        lay = ops.AttnLayout(st3, st3, st3, (S * H, hn, H))
+        scale = 1.0 / math.sqrt(hn)       # alpha=1/(sqrt(hn)*l) then *l inside the softmax (:718-727,757-762): net 1/sqrt(hn)
+        layers = []
+        for li, layer in enumerate(lm.encoder.layers):
+            ln = li + 1
+            att, mlp = layer.self_attention, layer.mlp
+            x1, m1, r1 = ops.layernorm_fwd(h, layer.input_layernorm.weight, layer.input_layernorm.bias, layer.input_layernorm.eps, R, H)
+            qkv = ops.gemm(x1, att.query_key_value.weight, R, 3 * H, H, bias=att.query_key_value.bias)
+            ctx = torch.empty((R, H), dtype=torch.bfloat16, device=h.device)
+            lse = ops.attn_fwd(qkv, qkv[:, hn:], qkv[:, 2 * hn:], ctx, lay, B, np_, S, S, hn, causal=True, scale=scale,
+                               dropout_p=p_a, seed=seed, offset=_offset(ln, _SITE_ATTN))
+            h1 = ops.gemm(ctx, att.dense.weight, R, H, H, bias=att.dense.bias, residual=h, dropout_p=p_h, seed=seed,
+                          offset=_offset(ln, _SITE_DROP1))
+            x2, m2, r2 = ops.layernorm_fwd(h1, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.bias,
+                                           layer.post_attention_layernorm.eps, R, H)
+            F4 = mlp.dense_h_to_4h.out_features
+            z = torch.empty((R, F4), dtype=torch.bfloat16, device=h.device)
+            g = ops.gemm(x2, mlp.dense_h_to_4h.weight, R, F4, H, bias=mlp.dense_h_to_4h.bias, act=ACT_GELU_TANH, preact_out=z)
+            h2 = ops.gemm(g, mlp.dense_4h_to_h.weight, R, H, F4, bias=mlp.dense_4h_to_h.bias, residual=h1, dropout_p=p_h,
+                          seed=seed, offset=_offset(ln, _SITE_DROP2))
+            layers.append(dict(h=h, s1=(m1, r1), qkv=qkv, ctx=ctx, lse=lse, h1=h1, s2=(m2, r2), z=z))
+            h = h2
+        fl = lm.encoder.final_layernorm
+        xf, mf, rf = ops.layernorm_fwd(h, fl.weight, fl.bias, fl.eps, R, H)
+        logits = ops.gemm(xf, lm.embedding.word_embeddings.weight, R, V, H)          # tied LM head (:1348-1350)
+        # masked mean of per-token CE over positions 0..S-2 (:1615-1617)
+        lmf = loss_mask.to(torch.float32)
+        denom = lmf.sum()
+        w = torch.zeros((B, S), dtype=torch.float32, device=h.device)
+        w[:, :S - 1] = lmf / denom
+        keep_logits = logits.clone() if want_logits else None
+        losses, loss = ops.cross_entropy(logits, labels.contiguous().view(-1), w.view(-1), R, V, dlogits=logits)
+        tape.update(B=B, Q=Q, L=L, S=S, layers=layers, h_last=h, sf=(mf, rf), dlogits=logits, lay=lay, scale=scale, seed=seed,
+                    p_h=p_h, p_a=p_a)
+        out = dict(loss=loss, losses=losses.view(B, S)[:, :S - 1], last_hidden_state=xf.view(B, S, H))
+        if want_logits:
+            out["logits"] = keep_logits.view(B, S, V)
+        return out
+
+    def backward_lm(self, tape: dict, grad_loss: Optional[torch.Tensor] = None):
+        """-> d(query_features) [B*Q, H] (dgrad only: the decoder is frozen)."""
+        cfg = self.config
+        lm = self.dist_model.language_model
+        B, Q, L, S = tape["B"], tape["Q"], tape["L"], tape["S"]
+        H, np_, hn, V = cfg.hidden_size, cfg.num_attention_heads, cfg.kv_channels, cfg.vocab_size
+        R = B * S
+        p_h, p_a, seed, lay, scale = tape["p_h"], tape["p_a"], tape["seed"], tape["lay"], tape["scale"]
+        nl = len(lm.encoder.layers)
+        fl = lm.encoder.final_layernorm
+        dxf = ops.gemm(tape["dlogits"], lm.embedding.word_embeddings.weight, R, H, V, trans_b=True, alpha_dev=grad_loss)
+        tape["dlogits"] = None
+        drop = p_h > 0.0
+        dh_m = torch.empty((R, H), dtype=torch.bfloat16, device=dxf.device) if drop else None
+        dh = ops.layernorm_bwd(dxf, tape["h_last"], fl.weight, *tape["sf"], R, H, dx_drop=dh_m, dropout_p=p_h, seed=seed,
+                               offset=_offset(nl, _SITE_DROP2))
+        for li in range(nl - 1, -1, -1):
+            layer, s = lm.encoder.layers[li], tape["layers"][li]
+            ln = li + 1
+            att, mlp = layer.self_attention, layer.mlp
+            F4 = mlp.dense_h_to_4h.out_features
+            do = dh_m if drop else dh
+            dz = ops.gemm(do, mlp.dense_4h_to_h.weight, R, F4, H, trans_b=True, act_bwd_z=s["z"], act_bwd=ACT_GELU_TANH)
+            dx2 = ops.gemm(dz, mlp.dense_h_to_4h.weight, R, H, F4, trans_b=True)
+            dh1_m = torch.empty((R, H), dtype=torch.bfloat16, device=dh.device) if drop else None
+            dh1 = ops.layernorm_bwd(dx2, s["h1"], layer.post_attention_layernorm.weight, *s["s2"], R, H, dres=dh, dx_drop=dh1_m,
+                                    dropout_p=p_h, seed=seed, offset=_offset(ln, _SITE_DROP1))
+            da = dh1_m if drop else dh1
+            dctx = ops.gemm(da, att.dense.weight, R, H, H, trans_b=True)
+            qkv = s["qkv"]
+            dqkv = torch.empty_like(qkv)
+            ops.attn_bwd(qkv, qkv[:, hn:], qkv[:, 2 * hn:], s["ctx"], s["lse"], dctx, dqkv, dqkv[:, hn:], dqkv[:, 2 * hn:], lay,
+                         B, np_, S, S, hn, causal=True, scale=scale, dropout_p=p_a, seed=seed, offset=_offset(ln, _SITE_ATTN))
+            dx1 = ops.gemm(dqkv, att.query_key_value.weight, R, H, 3 * H, trans_b=True)
+            prev_off = _offset(li, _SITE_DROP2) if li > 0 else 0
+            want_mask = drop and li > 0
+            dh_m = torch.empty((R, H), dtype=torch.bfloat16, device=dh.device) if want_mask else None
+            dh = ops.layernorm_bwd(dx1, s["h"], layer.input_layernorm.weight, *s["s1"], R, H, dres=dh1, dx_drop=dh_m,
+                                   dropout_p=p_h if want_mask else 0.0, seed=seed, offset=prev_off)
+            tape["layers"][li] = None
+        if Q == 0:
+            return None
+        return ops.gpt_embed_bwd(dh, B, Q, L, H, dropout_p=p_h, seed=seed, offset=_offset(0, _SITE_EMBED))
+
+    # -------------------------------------------------------------- reference-shaped API
+    def forward(self, tokens=None, input_embeds=None, query_embeds=None, attention_mask=None, position_ids=None, labels=None,
+                prompt_length=None, loss_mask=None, is_pair=(False,)):
+        """models/modeling_distributed_gpt3.py:1578-1618 signature (no-grad / evaluation use).  The
+        training path goes through DistributedGPT3_Pretrain, which drives forward_lm/backward_lm."""
+        if tokens is None:
+            raise NotImplementedError("pass `tokens` (optionally `query_embeds`); raw input_embeds enter via DistributedGPT3_Pretrain")
+        B, L = tokens.shape
+        qf = None
+        if query_embeds is not None:
+            qf = query_embeds.reshape(-1, query_embeds.shape[-1]).contiguous()
+        Q = 0 if qf is None else qf.shape[0] // B
+        if labels is None:
+            labels = torch.zeros((B, Q + L), dtype=torch.long, device=tokens.device)
+        if loss_mask is None:
+            loss_mask = attention_mask[:, 1:].contiguous() if attention_mask is not None else \
+                torch.ones((B, Q + L - 1), dtype=torch.long, device=tokens.device)
+        out = self.forward_lm(qf, tokens, labels, loss_mask, {}, want_logits=True)
+
+        class _Out(dict):
+            __getattr__ = dict.__getitem__
+        return _Out(logits=out["logits"], loss=out["loss"], losses=out["losses"], last_hidden_state=out["last_hidden_state"])

@@ -262,3 +262,12 @@ def adamw_step(p16, master, m, v, g16, lr, beta1, beta2, eps, wd, step, grad_sca
     check(_lib.lib().mpv_adamw_step(p16.data_ptr(), master.data_ptr(), m.data_ptr(), v.data_ptr(), g16.data_ptr(), p16.numel(),
                                     lr, beta1, beta2, eps, wd, step, grad_scale, _p(sumsq), max_norm, _stream()),
           "mpv_adamw_step")
+
+
+def adamw_step_grouped(p16, master, m, v, g16, tile_group, lrs, wds, beta1, beta2, eps, step, grad_scale=1.0, sumsq=None,
+                       max_norm=0.0):
+    n = len(lrs)
+    arr = (C.c_float * n)
+    check(_lib.lib().mpv_adamw_step_grouped(p16.data_ptr(), master.data_ptr(), m.data_ptr(), v.data_ptr(), g16.data_ptr(),
+                                            p16.numel(), tile_group.data_ptr(), arr(*lrs), arr(*wds), n, beta1, beta2, eps, step,
+                                            grad_scale, _p(sumsq), max_norm, _stream()), "mpv_adamw_step_grouped")

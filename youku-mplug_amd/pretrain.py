@@ -1,0 +1,145 @@
+"""DistributedGPT3_Pretrain on the gfx950 kernels -- drop-in for models/distributed_gpt3.py:31-226.
+
+Same constructor contract (config dict with visual_cfg / text_cfg / text_decoder / megatron_cfg /
+freeze_* / num_learnable_token keys, or an explicit PathShapes for synthetic runs), same
+forward(video, text) -> (loss_caption, loss_contrastive), same parameter names/shapes.
+forward() returns a loss tensor that is attached to autograd through ONE Function whose
+backward replays the hand-written backward pipeline (vision.py / gpt3.py) and writes the
+parameter gradients in place, so `loss.backward()` / `engine.backward(loss)` work unchanged.
+"""
+from __future__ import annotations
+
+import json
+from types import SimpleNamespace
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from .gpt3 import DistributedGPT3, GPT3Config
+from .vision import AttentionPool, Linear, TimeSformer, _param, grad_of
+
+
+class _StepFn(torch.autograd.Function):
+    """Bridges the explicit forward/backward pipeline into autograd (one node per step)."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, video, ids, mask):
+        loss, tape = model._forward_pipeline(video, ids, mask)
+        ctx.model, ctx.tape = model, tape
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        ctx.model._backward_pipeline(ctx.tape, grad_loss.contiguous().float())
+        ctx.tape = None
+        return torch.zeros(1, device=grad_loss.device), None, None, None, None
+
+
+class DistributedGPT3_Pretrain(nn.Module):
+    def __init__(self, config: Optional[dict] = None, tokenizer=None, *, visual_cfg: Optional[dict] = None,
+                 text_cfg: Optional[GPT3Config] = None, device="cuda"):
+        super().__init__()
+        config = dict(config or {})
+        self.tokenizer = tokenizer
+        if visual_cfg is None:
+            visual_cfg = json.load(open(config["visual_cfg"], "r"))                       # :36
+        if text_cfg is None:
+            text_cfg = GPT3Config.from_json_file(config["text_cfg"])                      # :37
+        self.visual_encoder = TimeSformer(
+            img_size=visual_cfg["img_size"], num_frames=visual_cfg["num_frames"], patch_size=visual_cfg["patch_size"],
+            embed_dim=visual_cfg["embed_dim"], depth=visual_cfg["depth"], num_heads=visual_cfg["num_heads"],
+            mlp_ratio=visual_cfg["mlp_ratio"], eps=1e-6, init_std=0.015, clip_model=visual_cfg.get("clip_model", False),
+            device=device)                                                                # :39-54
+        if config.get("text_decoder") and not config.get("_synthetic", False):
+            self.text_decoder = DistributedGPT3(model_dir=config["text_decoder"], device=device)          # :78-84
+        else:
+            self.text_decoder = DistributedGPT3(config=text_cfg, device=device)
+        if config.get("freeze_vit", False):                                               # :86-89
+            for name, p in self.visual_encoder.named_parameters():
+                if not any(x in name for x in ("time", "temporal")):
+                    p.requires_grad = False
+        if not config.get("freeze_text_decoder", True):
+            raise NotImplementedError("the gfx950 path implements the frozen-decoder recipe (freeze_text_decoder: true, "
+                                      "configs/pretrain/gpt3_1.3B/pretrain_gpt3_freezeGPT_youku_v0.yaml:23)")
+        for p in self.text_decoder.parameters():                                          # :91-93
+            p.requires_grad = False
+        self.vision_width = visual_cfg["embed_dim"]
+        self.text_width = self.text_decoder.config.hidden_size
+        self.num_learnable_token = config.get("num_learnable_token", 256)                 # :102
+        self.learnable_queries = _param(1, self.num_learnable_token, self.vision_width, std=0.015, device=device)
+        self.attn_pool = AttentionPool(self.vision_width, num_heads=visual_cfg["num_heads"], mlp_ratio=visual_cfg["mlp_ratio"],
+                                       eps=1e-6, std=0.02, device=device)                 # :106-109
+        self.visual_fc = Linear(self.vision_width, self.text_width, std=0.015, device=device)   # :111,116
+        self.visual_norm = nn.Identity()
+        if visual_cfg.get("connect_ln", False):
+            raise NotImplementedError("connect_ln is not set by any shipped visual config")
+        self.use_contrastive = config.get("use_contrastive", False)
+        if self.use_contrastive:
+            raise NotImplementedError("use_contrastive is false in the pre-train recipe (…yaml:26); ITC lives in the retrieval model")
+        self.prompt = config.get("prompt", "")
+        self._anchor = torch.zeros(1, device=device, requires_grad=True)
+        self.on_stage_grads_ready = None      # engine hook(stage_name)
+
+    def no_weight_decay(self):
+        return {"visual_encoder.pos_embed", "visual_encoder.cls_token", "visual_encoder.temporal_embed"}       # :224-226
+
+    # ---------------------------------------------------------------- pipeline
+    def _forward_pipeline(self, video, ids, mask, want_logits=False):
+        B = video.shape[0]
+        Q, Hh = self.num_learnable_token, self.text_width
+        tape = {"vit": {}, "pool": {}, "gpt": {}}
+        emb = self.visual_encoder.forward_features(video.to(torch.bfloat16), tape["vit"])
+        S_img = emb.shape[0] // B
+        image_query = self.attn_pool.forward_pool(self.learnable_queries, emb, B, S_img, tape["pool"])      # :134
+        qf = ops.gemm(image_query, self.visual_fc.weight, B * Q, Hh, self.vision_width, bias=self.visual_fc.bias)   # :136
+        tape["image_query"] = image_query
+        # targets / loss mask exactly as :142-159 (filler id 100 is always masked)
+        targets = torch.cat([ids[:, 1:], ids[:, 1:2]], dim=1)
+        targets = torch.cat([torch.full((B, Q), 100, dtype=torch.long, device=ids.device), targets], dim=1)
+        loss_mask = torch.cat([torch.zeros((B, Q), dtype=torch.long, device=ids.device), mask[:, 1:]], dim=1)
+        out = self.text_decoder.forward_lm(qf, ids, targets, loss_mask, tape["gpt"], want_logits=want_logits)
+        tape["out"] = out
+        return out["loss"], tape
+
+    def _backward_pipeline(self, tape, grad_loss):
+        B = tape["vit"]["B"]
+        Q, Hh, D = self.num_learnable_token, self.text_width, self.vision_width
+        dqf = self.text_decoder.backward_lm(tape["gpt"], grad_loss)
+        iq = tape["image_query"]
+        ops.colsum(dqf, B * Q, Hh, out=grad_of(self.visual_fc.bias))
+        ops.gemm(dqf, iq, Hh, D, B * Q, trans_a=True, trans_b=True, out=grad_of(self.visual_fc.weight))
+        diq = ops.gemm(dqf, self.visual_fc.weight, B * Q, D, Hh, trans_b=True)
+        demb = self.attn_pool.backward_pool(diq, self.learnable_queries, tape["pool"])
+        if self.on_stage_grads_ready is not None:
+            self.on_stage_grads_ready("head")
+        self.visual_encoder.backward_features(demb, tape["vit"])
+
+    # ---------------------------------------------------------------- reference-shaped API
+    def forward(self, image, text):
+        ids, mask = text.input_ids, text.attention_mask
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            loss = _StepFn.apply(self._anchor, self, image, ids, mask)
+        else:
+            loss, _ = self._forward_pipeline(image, ids, mask)
+        return loss, torch.zeros((), device=loss.device)                                   # :218-221
+
+    @torch.no_grad()
+    def forward_outputs(self, image, text):
+        """Evaluation helper: full decoder outputs (logits, losses, last_hidden_state, loss)."""
+        _, tape = self._forward_pipeline(image, text.input_ids, text.attention_mask, want_logits=True)
+        return SimpleNamespace(**tape["out"])
+
+
+def synthetic_model(shapes, device="cuda", num_frames=None) -> DistributedGPT3_Pretrain:
+    """Random-init model from a shapes object with the fields of oracle.weights.PathConfig (the
+    product never imports oracle/: tests pass the dataclass in)."""
+    vis = dict(img_size=shapes.img_size, patch_size=shapes.patch_size, depth=shapes.vit_depth,
+               num_frames=num_frames or shapes.num_frames, embed_dim=shapes.vit_dim, num_heads=shapes.vit_heads,
+               mlp_ratio=shapes.vit_mlp_ratio, clip_model=True)
+    txt = GPT3Config(vocab_size=shapes.vocab, hidden_size=shapes.hidden, ffn_hidden_size=shapes.ffn,
+                     num_hidden_layers=shapes.layers, num_attention_heads=shapes.heads, max_position_embeddings=shapes.max_pos,
+                     layernorm_epsilon=shapes.gpt_ln_eps)
+    return DistributedGPT3_Pretrain({"num_learnable_token": shapes.num_queries, "_synthetic": True}, visual_cfg=vis,
+                                    text_cfg=txt, device=device)

@@ -1,0 +1,397 @@
+"""TimeSformer video encoder + AttentionPool visual abstractor on the gfx950 kernels.
+
+Mirrors the reference module tree / parameter names (state-dict drop-in):
+  TimeSformer   models/vision_transformer.py:440-592   (Block :211-275, Attention :113-207,
+                Mlp :93-110, PatchEmbed :377-398, LayerNormWithForceFP32 :43-71)
+  AttentionPool models/vision_transformer.py:341-374   (nn.MultiheadAttention add_bias_kv, :353)
+
+Execution model (MI355X-first, not a translation): the modules only HOLD parameters; the
+forward/backward are explicit launch sequences over a single token stream laid out as
+[B, T, 1+N, D] (frame-major, one cls slot per frame, replicated cls) so that
+  * spatial attention / MLP / LayerNorm / their GEMMs run over ALL rows with no gather,
+  * the temporal branch addresses token rows through the GEMM/LN row maps (no permute copies;
+    the reference performs ~10 rearrange/cat/repeat copies per block, :247-274),
+  * gradients of the replicated cls slots simply add up (every consumer is linear in them).
+Nothing here uses autograd: backward() consumes the tape saved by forward() and writes
+parameter gradients straight into the parameters' .grad buffers (views of the engine's flat
+gradient buffer when the DP engine is used).  torch.utils.checkpoint of the reference (:575-577)
+is dropped: 288 GB of HBM hold every activation.
+"""
+from __future__ import annotations
+
+import math
+from typing import List
+
+import torch
+from torch import nn
+
+from . import ops
+from .ops import ACT_GELU_ERF
+
+
+def _param(*shape, std=0.02, device=None, dtype=torch.bfloat16, const=None):
+    if const is not None:
+        t = torch.full(shape, const, dtype=dtype, device=device)
+    else:
+        t = (torch.randn(*shape, device=device, dtype=torch.float32) * std).to(dtype)
+    return nn.Parameter(t)
+
+
+def grad_of(p: nn.Parameter) -> torch.Tensor:
+    """The buffer backward() writes into (allocated lazily when no engine pre-assigned one)."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
+class Linear(nn.Module):
+    def __init__(self, inp, out, bias=True, std=0.02, device=None):
+        super().__init__()
+        self.in_features, self.out_features = inp, out
+        self.weight = _param(out, inp, std=std, device=device)
+        self.bias = _param(out, const=0.0, device=device) if bias else None
+
+
+class LayerNormWithForceFP32(nn.Module):
+    """Parameter holder; the fp32-statistics LN itself is mpv_layernorm_{fwd,bwd}."""
+
+    def __init__(self, dim, eps=1e-6, device=None):
+        super().__init__()
+        self.eps = eps
+        self.normalized_shape = (dim,)
+        self.weight = _param(dim, const=1.0, device=device)
+        self.bias = _param(dim, const=0.0, device=device)
+
+
+class Mlp(nn.Module):
+    def __init__(self, dim, hidden, std, device=None):
+        super().__init__()
+        self.fc1 = Linear(dim, hidden, std=std, device=device)
+        self.fc2 = Linear(hidden, dim, std=std, device=device)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, heads, std, device=None):
+        super().__init__()
+        self.num_heads = heads
+        self.scale = (dim // heads) ** -0.5
+        self.qkv = Linear(dim, 3 * dim, bias=False, std=std, device=device)
+        self.q_bias = _param(dim, const=0.0, device=device)
+        self.v_bias = _param(dim, const=0.0, device=device)
+        self.proj = Linear(dim, dim, std=std, device=device)
+
+
+class Block(nn.Module):
+    def __init__(self, dim, heads, mlp_ratio, eps, std, device=None):
+        super().__init__()
+        self.norm1 = LayerNormWithForceFP32(dim, eps, device)
+        self.attn = Attention(dim, heads, std, device)
+        self.norm2 = LayerNormWithForceFP32(dim, eps, device)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio), std, device)
+        self.temporal_attn = Attention(dim, heads, std, device)
+        self.temporal_ln = LayerNormWithForceFP32(dim, eps, device)
+        self.temporal_fc = Linear(dim, dim, std=std, device=device)
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, img_size, patch_size, in_chans, dim, bias, std, device=None):
+        super().__init__()
+        self.img_size, self.patch_size = (img_size, img_size), (patch_size, patch_size)
+        self.num_patches = (img_size // patch_size) ** 2
+        self.proj = nn.Module()
+        self.proj.weight = _param(dim, in_chans, patch_size, patch_size, std=std, device=device)
+        self.proj.bias = _param(dim, const=0.0, device=device) if bias else None
+
+
+def _qkv_bias(att: Attention):
+    # models/vision_transformer.py:173: cat(q_bias, zeros, v_bias)
+    return torch.cat([att.q_bias.detach(), torch.zeros_like(att.v_bias), att.v_bias.detach()])
+
+
+class TimeSformer(nn.Module):
+    def __init__(self, img_size=224, num_frames=4, patch_size=16, in_chans=3, embed_dim=768, depth=12, num_heads=8,
+                 mlp_ratio=4.0, eps=1e-6, init_std=0.015, clip_model=True, device=None, **_):
+        super().__init__()
+        D = embed_dim
+        assert (D // num_heads) in (64, 80, 96), "fused attention kernels are built for head_dim 64/80/96"
+        self.embed_dim = self.num_features = D
+        self.num_frames, self.num_heads, self.depth = num_frames, num_heads, depth
+        self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, D, bias=not clip_model, std=init_std, device=device)
+        N = self.patch_embed.num_patches
+        if clip_model:
+            self.norm_pre = LayerNormWithForceFP32(D, eps, device)
+        self.cls_token = _param(1, 1, D, std=init_std, device=device)
+        self.pos_embed = _param(1, N + 1, D, std=init_std, device=device)
+        self.temporal_embed = _param(1, num_frames, D, const=0.0, device=device)
+        self.blocks = nn.ModuleList([Block(D, num_heads, mlp_ratio, eps, init_std, device) for _ in range(depth)])
+        self.norm = LayerNormWithForceFP32(D, eps, device)
+        with torch.no_grad():   # fix_init_weight (:513-519) and the temporal_fc zero-init quirk (:491-498)
+            for i, blk in enumerate(self.blocks):
+                blk.attn.proj.weight.div_(math.sqrt(2.0 * (i + 1)))
+                blk.mlp.fc2.weight.div_(math.sqrt(2.0 * (i + 1)))
+                blk.temporal_fc.weight.zero_()
+                blk.temporal_fc.bias.zero_()
+        self.on_block_grads_ready = None   # engine hook: called with the block index after its backward
+
+    def no_weight_decay(self):
+        return {"temporal_embed", "pos_embed", "cls_token"}
+
+    # ------------------------------------------------------------------ forward
+    def forward_features(self, video: torch.Tensor, tape: dict):
+        """video [B,3,T,H,W] bf16 -> image_embeds [B*(1+T*N), D] (cls first, then frame-major tokens,
+        exactly the reference's `b (t n) c` order, :582-585)."""
+        B, Cc, T, H, W = video.shape
+        assert T == self.num_frames, (T, self.num_frames)
+        D, P = self.embed_dim, self.patch_embed.patch_size[0]
+        N = self.patch_embed.num_patches
+        N1, heads, hd = N + 1, self.num_heads, self.embed_dim // self.num_heads
+        R, Rt = B * T * N1, B * T * N
+        tok = (N, N1, 1)
+        Kc = Cc * P * P
+        Kp = (Kc + 7) // 8 * 8
+        video = video.contiguous()
+        cols = ops.im2col_patches(video, B, Cc, T, H, W, P, Kp)
+        wpe = self.patch_embed.proj.weight.detach().view(D, Kc)
+        if Kp != Kc:
+            wpe = torch.nn.functional.pad(wpe, (0, Kp - Kc))
+        patch = ops.gemm(cols, wpe, Rt, D, Kp, bias=self.patch_embed.proj.bias)
+        x0 = ops.vit_embed_assemble_fwd(patch, self.cls_token, self.pos_embed, self.temporal_embed, B, T, N, D)
+        tape.update(B=B, T=T, N=N, cols=cols, Kp=Kp, Kc=Kc, x0=x0)
+        if hasattr(self, "norm_pre"):
+            x, m, r = ops.layernorm_fwd(x0, self.norm_pre.weight, self.norm_pre.bias, self.norm_pre.eps, R, D)
+            tape["pre_stats"] = (m, r)
+        else:
+            x = x0
+        blocks: List[dict] = []
+        for blk in self.blocks:
+            s = {}
+            # ---- temporal branch on token rows (:247-251)
+            lt, s["mt"], s["rt"] = ops.layernorm_fwd(x, blk.temporal_ln.weight, blk.temporal_ln.bias, blk.temporal_ln.eps,
+                                                     Rt, D, xmap=tok, ymap=tok, out_rows=R)
+            qkv_t = ops.gemm(lt, blk.temporal_attn.qkv.weight, Rt, 3 * D, D, bias=_qkv_bias(blk.temporal_attn),
+                             amap=tok, cmap=tok, out_rows=R)
+            at = torch.empty((R, D), dtype=torch.bfloat16, device=x.device)
+            ops.temporal_attn_fwd(qkv_t, at, B, T * N1, N, 1, N1, T, heads, hd, blk.temporal_attn.scale)
+            pt = ops.gemm(at, blk.temporal_attn.proj.weight, Rt, D, D, bias=blk.temporal_attn.proj.bias, amap=tok, cmap=tok,
+                          out_rows=R)
+            xt = torch.empty_like(x)
+            ops.gemm(pt, blk.temporal_fc.weight, Rt, D, D, bias=blk.temporal_fc.bias, residual=x, amap=tok, cmap=tok, out=xt)
+            ops.copy_rows(x, xt, B * T, D, smap=(1, N1, 0), dmap=(1, N1, 0))          # cls slots pass through
+            # ---- spatial branch on all rows (:254-267)
+            l1, s["m1"], s["r1"] = ops.layernorm_fwd(xt, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, R, D)
+            qkv_s = ops.gemm(l1, blk.attn.qkv.weight, R, 3 * D, D, bias=_qkv_bias(blk.attn))
+            a_s = torch.empty((R, D), dtype=torch.bfloat16, device=x.device)
+            st3 = (N1 * 3 * D, hd, 3 * D)
+            lay = ops.AttnLayout(st3, st3, st3, (N1 * D, hd, D))
+            lse = ops.attn_fwd(qkv_s, qkv_s[:, D:], qkv_s[:, 2 * D:], a_s, lay, B * T, heads, N1, N1, hd,
+                               scale=blk.attn.scale, scale_q_bf16=True)
+            ps = ops.gemm(a_s, blk.attn.proj.weight, R, D, D, bias=blk.attn.proj.bias)
+            y = ops.vit_cls_merge_fwd(xt, ps, B, T, N1, D)                               # :263-270
+            # ---- MLP (:271)
+            l2, s["m2"], s["r2"] = ops.layernorm_fwd(y, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, R, D)
+            hid = blk.mlp.fc1.out_features
+            z = torch.empty((R, hid), dtype=torch.bfloat16, device=x.device)
+            h1 = ops.gemm(l2, blk.mlp.fc1.weight, R, hid, D, bias=blk.mlp.fc1.bias, act=ACT_GELU_ERF, preact_out=z)
+            out = ops.gemm(h1, blk.mlp.fc2.weight, R, D, hid, bias=blk.mlp.fc2.bias, residual=y)
+            s.update(x=x, lt=lt, qkv_t=qkv_t, at=at, pt=pt, xt=xt, l1=l1, qkv_s=qkv_s, a_s=a_s, lse=lse, lay=lay, y=y, l2=l2,
+                     z=z, h1=h1)
+            blocks.append(s)
+            x = out
+        tape["blocks"] = blocks
+        tape["x_last"] = x
+        # ---- final LN + compaction to [B, 1+T*N, D] (:582-585)
+        S = 1 + T * N
+        emb = torch.empty((B * S, D), dtype=torch.bfloat16, device=x.device)
+        _, mt_, rt_ = ops.layernorm_fwd(x, self.norm.weight, self.norm.bias, self.norm.eps, Rt, D, out=emb, xmap=tok,
+                                        ymap=(T * N, S, 1))
+        _, mc_, rc_ = ops.layernorm_fwd(x, self.norm.weight, self.norm.bias, self.norm.eps, B, D, out=emb,
+                                        xmap=(1, T * N1, 0), ymap=(1, S, 0))
+        tape["final_stats"] = (mt_, rt_, mc_, rc_)
+        return emb
+
+    # ------------------------------------------------------------------ backward
+    def backward_features(self, demb: torch.Tensor, tape: dict):
+        B, T, N = tape["B"], tape["T"], tape["N"]
+        D, heads, hd = self.embed_dim, self.num_heads, self.embed_dim // self.num_heads
+        N1, R, Rt, S = N + 1, B * T * (N + 1), B * T * N, 1 + T * N
+        tok = (N, N1, 1)
+        x_last = tape["x_last"]
+        mt_, rt_, mc_, rc_ = tape["final_stats"]
+        dx = torch.zeros((R, D), dtype=torch.bfloat16, device=demb.device)     # cls slots t>0 get no final-LN grad
+        gw, gb = grad_of(self.norm.weight), grad_of(self.norm.bias)
+        ops.layernorm_bwd(demb, x_last, self.norm.weight, mt_, rt_, Rt, D, dx=dx, dgamma=gw, dbeta=gb, xmap=tok,
+                          ymap=(T * N, S, 1))
+        ops.layernorm_bwd(demb, x_last, self.norm.weight, mc_, rc_, B, D, dx=dx, dgamma=gw, dbeta=gb, accumulate_dparams=True,
+                          xmap=(1, T * N1, 0), ymap=(1, S, 0))
+        for bi in range(len(self.blocks) - 1, -1, -1):
+            blk, s = self.blocks[bi], tape["blocks"][bi]
+            hid = blk.mlp.fc1.out_features
+            dout = dx
+            # ---- MLP
+            ops.colsum(dout, R, D, out=grad_of(blk.mlp.fc2.bias))
+            ops.gemm(dout, s["h1"], D, hid, R, trans_a=True, trans_b=True, out=grad_of(blk.mlp.fc2.weight))
+            dz = ops.gemm(dout, blk.mlp.fc2.weight, R, hid, D, trans_b=True, act_bwd_z=s["z"], act_bwd=ACT_GELU_ERF)
+            ops.colsum(dz, R, hid, out=grad_of(blk.mlp.fc1.bias))
+            ops.gemm(dz, s["l2"], hid, D, R, trans_a=True, trans_b=True, out=grad_of(blk.mlp.fc1.weight))
+            dl2 = ops.gemm(dz, blk.mlp.fc1.weight, R, D, hid, trans_b=True)
+            dy = ops.layernorm_bwd(dl2, s["y"], blk.norm2.weight, s["m2"], s["r2"], R, D, dres=dout,
+                                   dgamma=grad_of(blk.norm2.weight), dbeta=grad_of(blk.norm2.bias))
+            # ---- cls merge + spatial attention
+            dps = ops.vit_cls_merge_bwd(dy, B, T, N1, D)
+            ops.colsum(dps, R, D, out=grad_of(blk.attn.proj.bias))
+            ops.gemm(dps, s["a_s"], D, D, R, trans_a=True, trans_b=True, out=grad_of(blk.attn.proj.weight))
+            das = ops.gemm(dps, blk.attn.proj.weight, R, D, D, trans_b=True)
+            qkv_s = s["qkv_s"]
+            dqkv = torch.empty_like(qkv_s)
+            ops.attn_bwd(qkv_s, qkv_s[:, D:], qkv_s[:, 2 * D:], s["a_s"], s["lse"], das, dqkv, dqkv[:, D:], dqkv[:, 2 * D:],
+                         s["lay"], B * T, heads, N1, N1, hd, scale=blk.attn.scale, scale_q_bf16=True)
+            ops.colsum(dqkv, R, D, ld=3 * D, out=grad_of(blk.attn.q_bias))
+            ops.colsum(dqkv[:, 2 * D:], R, D, ld=3 * D, out=grad_of(blk.attn.v_bias))
+            ops.gemm(dqkv, s["l1"], 3 * D, D, R, trans_a=True, trans_b=True, out=grad_of(blk.attn.qkv.weight))
+            dl1 = ops.gemm(dqkv, blk.attn.qkv.weight, R, D, 3 * D, trans_b=True)
+            dxt = ops.layernorm_bwd(dl1, s["xt"], blk.norm1.weight, s["m1"], s["r1"], R, D, dres=dy,
+                                    dgamma=grad_of(blk.norm1.weight), dbeta=grad_of(blk.norm1.bias))
+            # ---- temporal branch (token rows)
+            ops.colsum(dxt, Rt, D, rmap=tok, out=grad_of(blk.temporal_fc.bias))
+            ops.gemm(dxt, s["pt"], D, D, Rt, trans_a=True, trans_b=True, kmap=tok, out=grad_of(blk.temporal_fc.weight))
+            dpt = ops.gemm(dxt, blk.temporal_fc.weight, Rt, D, D, trans_b=True, amap=tok, cmap=tok, out_rows=R)
+            ops.colsum(dpt, Rt, D, rmap=tok, out=grad_of(blk.temporal_attn.proj.bias))
+            ops.gemm(dpt, s["at"], D, D, Rt, trans_a=True, trans_b=True, kmap=tok, out=grad_of(blk.temporal_attn.proj.weight))
+            dat = ops.gemm(dpt, blk.temporal_attn.proj.weight, Rt, D, D, trans_b=True, amap=tok, cmap=tok, out_rows=R)
+            dqkv_t = torch.empty_like(s["qkv_t"])
+            ops.temporal_attn_bwd(s["qkv_t"], dat, dqkv_t, B, T * N1, N, 1, N1, T, heads, hd, blk.temporal_attn.scale)
+            ops.colsum(dqkv_t, Rt, D, ld=3 * D, rmap=tok, out=grad_of(blk.temporal_attn.q_bias))
+            ops.colsum(dqkv_t[:, 2 * D:], Rt, D, ld=3 * D, rmap=tok, out=grad_of(blk.temporal_attn.v_bias))
+            ops.gemm(dqkv_t, s["lt"], 3 * D, D, Rt, trans_a=True, trans_b=True, kmap=tok,
+                     out=grad_of(blk.temporal_attn.qkv.weight))
+            dlt = ops.gemm(dqkv_t, blk.temporal_attn.qkv.weight, Rt, D, 3 * D, trans_b=True, amap=tok, cmap=tok, out_rows=R)
+            # dx = dxt (all rows) + LN_t-backward on token rows, accumulated in place
+            ops.layernorm_bwd(dlt, s["x"], blk.temporal_ln.weight, s["mt"], s["rt"], Rt, D, dres=dxt, dx=dxt,
+                              dgamma=grad_of(blk.temporal_ln.weight), dbeta=grad_of(blk.temporal_ln.bias), xmap=tok, ymap=tok)
+            dx = dxt
+            tape["blocks"][bi] = None          # release activations
+            if self.on_block_grads_ready is not None:
+                self.on_block_grads_ready(bi)
+        if hasattr(self, "norm_pre"):
+            m, r = tape["pre_stats"]
+            dx = ops.layernorm_bwd(dx, tape["x0"], self.norm_pre.weight, m, r, R, D, dgamma=grad_of(self.norm_pre.weight),
+                                   dbeta=grad_of(self.norm_pre.bias))
+        dpatch = torch.empty((Rt, D), dtype=torch.bfloat16, device=dx.device)
+        ops.vit_embed_assemble_bwd(dx, dpatch, grad_of(self.cls_token), grad_of(self.pos_embed), grad_of(self.temporal_embed),
+                                   B, T, N, D)
+        Kp, Kc = tape["Kp"], tape["Kc"]
+        gw = grad_of(self.patch_embed.proj.weight)
+        if Kp == Kc:
+            ops.gemm(dpatch, tape["cols"], D, Kp, Rt, trans_a=True, trans_b=True, out=gw)
+        else:
+            tmp = ops.gemm(dpatch, tape["cols"], D, Kp, Rt, trans_a=True, trans_b=True)
+            gw.view(D, Kc).copy_(tmp[:, :Kc])
+        if self.patch_embed.proj.bias is not None:
+            ops.colsum(dpatch, Rt, D, out=grad_of(self.patch_embed.proj.bias))
+        if self.on_block_grads_ready is not None:
+            self.on_block_grads_ready(-1)
+
+
+class _MHAParams(nn.Module):
+    """Parameter holder with nn.MultiheadAttention's names (in_proj_weight/bias, bias_k/v, out_proj)."""
+
+    def __init__(self, dim, heads, std, device=None):
+        super().__init__()
+        self.embed_dim, self.num_heads = dim, heads
+        self.in_proj_weight = _param(3 * dim, dim, std=std, device=device)
+        self.in_proj_bias = _param(3 * dim, const=0.0, device=device)
+        self.bias_k = _param(1, 1, dim, std=std, device=device)
+        self.bias_v = _param(1, 1, dim, std=std, device=device)
+        self.out_proj = Linear(dim, dim, std=std, device=device)
+
+
+class AttentionPool(nn.Module):
+    """models/vision_transformer.py:341-374: x = LN1(q); k = LNk(tokens); x = x + MHA(x,k,k) with one
+    learned extra kv token; x = x + Mlp(LN2(x))."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, eps=1e-6, std=0.02, device=None):
+        super().__init__()
+        self.dim, self.num_heads = dim, num_heads
+        self.norm1 = LayerNormWithForceFP32(dim, eps, device)
+        self.normk = LayerNormWithForceFP32(dim, eps, device)
+        self.attn = _MHAParams(dim, num_heads, std, device)
+        self.norm2 = LayerNormWithForceFP32(dim, eps, device)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio), std, device)
+
+    def forward_pool(self, queries: torch.Tensor, emb: torch.Tensor, B: int, S: int, tape: dict):
+        """queries [1,Q,D] parameter, emb [B*S, D] -> [B*Q, D]."""
+        D, heads = self.dim, self.num_heads
+        hd = D // heads
+        Q = queries.shape[1]
+        a = self.attn
+        xin = torch.empty((B * Q, D), dtype=torch.bfloat16, device=emb.device)
+        ops.copy_rows(queries.detach().view(Q, D), xin, B * Q, D, smap=(Q, 0, 0))   # queries.repeat(B,1,1) (distributed_gpt3.py:134)
+        x, m1, r1 = ops.layernorm_fwd(xin, self.norm1.weight, self.norm1.bias, self.norm1.eps, B * Q, D)
+        kn, mk, rk = ops.layernorm_fwd(emb, self.normk.weight, self.normk.bias, self.normk.eps, B * S, D)
+        Wi, bi = a.in_proj_weight.detach(), a.in_proj_bias.detach()
+        q = ops.gemm(x, Wi[:D], B * Q, D, D, bias=bi[:D])
+        kv = ops.gemm(kn, Wi[D:], B * S, 2 * D, D, bias=bi[D:], cmap=(S, S + 1, 0), out_rows=B * (S + 1))
+        bkv = torch.cat([a.bias_k.detach().view(1, D), a.bias_v.detach().view(1, D)], dim=1)
+        ops.copy_rows(bkv, kv, B, 2 * D, smap=(1, 0, 0), dmap=(1, S + 1, S))           # add_bias_kv token (last key)
+        o = torch.empty((B * Q, D), dtype=torch.bfloat16, device=emb.device)
+        lay = ops.AttnLayout((Q * D, hd, D), ((S + 1) * 2 * D, hd, 2 * D), ((S + 1) * 2 * D, hd, 2 * D), (Q * D, hd, D))
+        lse = ops.attn_fwd(q, kv, kv[:, D:], o, lay, B, heads, Q, S + 1, hd, scale=hd ** -0.5)
+        x2 = ops.gemm(o, a.out_proj.weight, B * Q, D, D, bias=a.out_proj.bias, residual=x)      # residual from NORMED x
+        l2, m2, r2 = ops.layernorm_fwd(x2, self.norm2.weight, self.norm2.bias, self.norm2.eps, B * Q, D)
+        hid = self.mlp.fc1.out_features
+        z = torch.empty((B * Q, hid), dtype=torch.bfloat16, device=emb.device)
+        h1 = ops.gemm(l2, self.mlp.fc1.weight, B * Q, hid, D, bias=self.mlp.fc1.bias, act=ACT_GELU_ERF, preact_out=z)
+        out = ops.gemm(h1, self.mlp.fc2.weight, B * Q, D, hid, bias=self.mlp.fc2.bias, residual=x2)
+        tape.update(B=B, S=S, Q=Q, xin=xin, x=x, s1=(m1, r1), emb=emb, kn=kn, sk=(mk, rk), q=q, kv=kv, o=o, lse=lse, lay=lay,
+                    x2=x2, l2=l2, s2=(m2, r2), z=z, h1=h1)
+        return out
+
+    def backward_pool(self, dout: torch.Tensor, queries: nn.Parameter, tape: dict):
+        """-> d(emb) [B*S, D]; writes all AttentionPool grads and d(queries)."""
+        B, S, Q = tape["B"], tape["S"], tape["Q"]
+        D, heads = self.dim, self.num_heads
+        hd, hid = D // heads, self.mlp.fc1.out_features
+        a = self.attn
+        R = B * Q
+        ops.colsum(dout, R, D, out=grad_of(self.mlp.fc2.bias))
+        ops.gemm(dout, tape["h1"], D, hid, R, trans_a=True, trans_b=True, out=grad_of(self.mlp.fc2.weight))
+        dz = ops.gemm(dout, self.mlp.fc2.weight, R, hid, D, trans_b=True, act_bwd_z=tape["z"], act_bwd=ACT_GELU_ERF)
+        ops.colsum(dz, R, hid, out=grad_of(self.mlp.fc1.bias))
+        ops.gemm(dz, tape["l2"], hid, D, R, trans_a=True, trans_b=True, out=grad_of(self.mlp.fc1.weight))
+        dl2 = ops.gemm(dz, self.mlp.fc1.weight, R, D, hid, trans_b=True)
+        dx2 = ops.layernorm_bwd(dl2, tape["x2"], self.norm2.weight, *tape["s2"], R, D, dres=dout,
+                                dgamma=grad_of(self.norm2.weight), dbeta=grad_of(self.norm2.bias))
+        ops.colsum(dx2, R, D, out=grad_of(a.out_proj.bias))
+        ops.gemm(dx2, tape["o"], D, D, R, trans_a=True, trans_b=True, out=grad_of(a.out_proj.weight))
+        do = ops.gemm(dx2, a.out_proj.weight, R, D, D, trans_b=True)
+        kv = tape["kv"]
+        dq = torch.empty_like(tape["q"])
+        dkv = torch.empty_like(kv)
+        ops.attn_bwd(tape["q"], kv, kv[:, D:], tape["o"], tape["lse"], do, dq, dkv, dkv[:, D:], tape["lay"], B, heads, Q, S + 1, hd,
+                     scale=hd ** -0.5)
+        gW, gb = grad_of(a.in_proj_weight), grad_of(a.in_proj_bias)
+        # q projection
+        ops.colsum(dq, R, D, out=gb[:D])
+        ops.gemm(dq, tape["x"], D, D, R, trans_a=True, trans_b=True, out=gW[:D])
+        dx = ops.gemm(dq, a.in_proj_weight.detach()[:D], R, D, D, trans_b=True, residual=dx2)      # + residual path x -> x2
+        # k/v projection over the S real tokens of every batch; the bias-kv row goes to bias_k / bias_v
+        kmap = (S, S + 1, 0)
+        ops.colsum(dkv, B * S, 2 * D, rmap=kmap, out=gb[D:])
+        self._kv_wgrad(dkv, tape["kn"], gW[D:], B, S, D)
+        ops.colsum(dkv, B, D, ld=2 * D, rmap=(1, S + 1, S), out=grad_of(a.bias_k).view(D))
+        ops.colsum(dkv[:, D:], B, D, ld=2 * D, rmap=(1, S + 1, S), out=grad_of(a.bias_v).view(D))
+        dkn = ops.gemm(dkv, a.in_proj_weight.detach()[D:], B * S, D, 2 * D, trans_b=True, amap=kmap)
+        demb = ops.layernorm_bwd(dkn, tape["emb"], self.normk.weight, *tape["sk"], B * S, D,
+                                 dgamma=grad_of(self.normk.weight), dbeta=grad_of(self.normk.bias))
+        dxin = ops.layernorm_bwd(dx, tape["xin"], self.norm1.weight, *tape["s1"], R, D,
+                                 dgamma=grad_of(self.norm1.weight), dbeta=grad_of(self.norm1.bias))
+        ops.colsum(dxin, B, Q * D, out=grad_of(queries).view(Q * D))                                # sum over the batch repeat
+        return demb
+
+    @staticmethod
+    def _kv_wgrad(dkv, kn, gW_kv, B, S, D):
+        # dW_kv[2D, D] = sum over real tokens dkv[b,s,:]^T kn[b,s,:]; dkv rows carry the per-batch extra row
+        # (map S -> S+1), kn rows are dense, so the two reduction maps differ: compact dkv first (B*S*2D bf16).
+        dkv_c = torch.empty((B * S, 2 * D), dtype=torch.bfloat16, device=dkv.device)
+        ops.copy_rows(dkv, dkv_c, B * S, 2 * D, smap=(S, S + 1, 0))
+        ops.gemm(dkv_c, kn, 2 * D, D, B * S, trans_a=True, trans_b=True, out=gW_kv)
