@@ -1,0 +1,266 @@
+"""bench.py -- whole-job throughput of the mPLUG-Video pre-train step on N MI355X GPUs.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1]: mPLUG-Video GPT3-1.3B pre-train step (freezeGPT recipe,
+TimeSformer/CLIP-B16 vision tower -- SURVEY.md R4), per-GPU batch 32 x 8 frames x 224^2 + 32-token
+titles, bf16, synthetic data, random-init weights.  A step = forward + backward + DP gradient
+all-reduce (overlapped) + global-norm clip + AdamW, dropout live (train mode).  One JSON line is
+printed by rank 0 (contract in the task statement) with `roofline` (bf16 MFMA GEMM family, timed
+live with HIP events on the launch stream) and `cpu_baseline` (the oracle restatement of the
+reference path timed on the host cores; reported, not the target).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0     # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+
+
+class Shapes:
+    """1.3B recipe dims (configs/models/config_gpt3_1.3B.json, clip-b16.json with num_frames 8)."""
+    img_size, patch_size, vit_dim, vit_depth, vit_heads, vit_mlp_ratio, num_frames = 224, 16, 768, 12, 8, 4, 8
+    vit_ln_eps, num_queries = 1e-6, 128
+    hidden, layers, heads, ffn, vocab, max_pos, gpt_ln_eps = 2048, 24, 32, 8192, 51200, 2048, 1e-5
+
+
+def algorithmic_train_flops(B, T, L, s=Shapes):
+    """forward FLOPs (mul-add = 2), x3 for trainable parts, x2 for the frozen GPT."""
+    D, N, Q, H, V, Lyr = s.vit_dim, (s.img_size // s.patch_size) ** 2, s.num_queries, s.hidden, s.vocab, s.layers
+    M = B * T * N
+    S = Q + L
+    vit = 2 * M * D * D + s.vit_depth * (M * 2 * D * (2304 + 768 + 768 + 2304 + 768) * (D / 768) ** 0 + (M + B) * 4 * D * 4 * D
+                                         + B * T * 2 * D * 4 * D + B * T * 8 * 4 * (N + 1) ** 2 * (D // s.vit_heads) * s.vit_heads / 8
+                                         + B * N * 8 * 4 * T * T * (D // s.vit_heads) * s.vit_heads / 8)
+    Sk = 1 + T * N
+    pool = 2 * B * Q * D * D + 2 * B * Sk * D * 2 * D + 4 * B * Q * (Sk + 1) * D + 2 * B * Q * D * D + 4 * B * Q * D * 4 * D
+    fc = 2 * B * Q * D * H
+    gpt = Lyr * 2 * B * S * H * (3 * H + H + 2 * s.ffn) + Lyr * 4 * B * S * S * H + 2 * B * S * H * V
+    return 3.0 * (vit + pool + fc) + 2.0 * gpt
+
+
+class GemmTimer:
+    """Times every mpv_gemm_bf16 launch with HIP events on the launch stream (torch's current stream)."""
+
+    def __init__(self):
+        self.records = []
+        self.orig = None
+
+    def __enter__(self):
+        from youku_mplug_amd import ops
+        self.ops, self.orig = ops, ops.gemm
+
+        def timed(a, b, M, N, K, **kw):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = self.orig(a, b, M, N, K, **kw)
+            e.record()
+            kind = "wgrad" if kw.get("trans_a") else ("dgrad" if kw.get("trans_b") else "fwd")
+            self.records.append((kind, 2.0 * M * N * K, s, e))
+            return r
+        ops.gemm = timed
+        import youku_mplug_amd.vision as v, youku_mplug_amd.gpt3 as g, youku_mplug_amd.pretrain as p
+        return self
+
+    def __exit__(self, *exc):
+        self.ops.gemm = self.orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        tot = {}
+        for kind, fl, s, e in self.records:
+            t = tot.setdefault(kind, [0.0, 0.0, 0])
+            t[0] += fl
+            t[1] += s.elapsed_time(e) * 1e-3
+            t[2] += 1
+        return tot
+
+
+def host_cores():
+    """Cores this process may actually use: min(affinity, cgroup cpu quota)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(math.ceil(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(threads):
+    """Oracle restatement (a port of the reference path, oracle/restate.py) on the host cores:
+    ONE full config-A step (B=2, T=4, L=16, 1.3B dims, bf16): forward + backward + AdamW."""
+    from oracle import restate
+    from oracle.weights import CONFIG_A, state_dict_spec
+    torch.set_num_threads(threads)
+    cfg = CONFIG_A
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+    for k, shape, kind in state_dict_spec(cfg):
+        t = torch.empty(shape, dtype=torch.bfloat16)
+        if kind == "ln_w":
+            t.fill_(1.0)
+        else:
+            t.normal_(0.0, 0.02, generator=g)
+        sd[k] = t
+    trainable = [k for k in sd if not k.startswith("text_decoder.")]
+    for k in trainable:
+        sd[k].requires_grad_(True)
+    video = torch.randn(2, 3, cfg.num_frames, 224, 224, generator=g).bfloat16()
+    ids = torch.randint(0, cfg.vocab, (2, 16), generator=g)
+    mask = torch.ones(2, 16, dtype=torch.long)
+    state = {k: (sd[k].detach().float(), torch.zeros_like(sd[k], dtype=torch.float32), torch.zeros_like(sd[k], dtype=torch.float32))
+             for k in trainable}
+    t0 = time.time()
+    out = restate.pretrain_forward(video, ids, mask, sd, cfg)
+    out["loss"].backward()
+    with torch.no_grad():
+        for k in trainable:
+            p, m, v = state[k]
+            restate.adamw_step(p, sd[k].grad.float(), m, v, 1, 1e-4, 0.9, 0.999, 1e-6, 0.05)
+            sd[k].copy_(p)
+    dt = time.time() - t0
+    return {"value": round(2.0 / dt, 5), "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"1 full step of config A (B=2,T=4,L=16, 1.3B dims, bf16) = {dt:.1f} s on {threads} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--text-len", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    t_start = time.perf_counter()
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+
+    import youku_mplug_amd  # noqa: F401  raises if libmpv_hip.so is missing
+    from youku_mplug_amd import _lib, engine as eng
+    from youku_mplug_amd.pretrain import synthetic_model
+    _lib.check(_lib.lib().mpv_check_device(), "mpv_check_device")
+
+    Shapes.num_frames = args.frames
+    torch.manual_seed(1234 + rank)                                   # run_pretrain_distributed_gpt3.py:210
+    model = synthetic_model(Shapes, device=dev, num_frames=args.frames)
+    with torch.no_grad():                                            # module-default init zeroes the temporal branch
+        for blk in model.visual_encoder.blocks:
+            blk.temporal_fc.weight.normal_(0, 0.015)
+        model.visual_encoder.temporal_embed.normal_(0, 0.015)
+    if world > 1:                                                    # identical replicas
+        for p in model.parameters():
+            dist.broadcast(p.data, 0)
+    model.train()
+    groups = eng.get_parameter_groups(model, 0.05, model.no_weight_decay(), visual_backbone_scale=True)
+    engine, opt, _, _ = eng.initialize(model=model, model_parameters=groups,
+                                       config=dict(lr=1e-4, opt_betas=(0.9, 0.999), opt_eps=1e-6, clip_grad=3.0))
+    B, T, L = args.batch, args.frames, args.text_len
+    video = torch.randn(B, 3, T, 224, 224, device=dev).to(torch.bfloat16)
+    ids = torch.randint(0, Shapes.vocab, (B, L), device=dev)
+    text = types.SimpleNamespace(input_ids=ids, attention_mask=torch.ones(B, L, dtype=torch.long, device=dev))
+    total = args.warmup + args.steps
+    lr_sched = [1e-4 * min(1.0, (i + 1) / 2000.0) for i in range(2 * total + 8)]     # linear warm-up (utils.py:350-372)
+
+    def step(i):
+        for g in opt.param_groups:                                   # run_pretrain_distributed_gpt3.py:88-96
+            g["lr"] = lr_sched[i] * g["lr_scale"]
+        loss, _ = engine(video, text)
+        engine.backward(loss)
+        engine.step()
+        return loss
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:7.1f}s] {msg}", file=sys.stderr, flush=True)
+    log("model + engine built")
+    for i in range(args.warmup):
+        loss = step(i)
+    torch.cuda.synchronize()
+    log("warmup done")
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    fence()
+    dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = dt.item()
+    final_loss = loss.item()
+    log(f"timed region done: {dt / args.steps * 1e3:.1f} ms/step")
+    assert math.isfinite(final_loss), "non-finite loss in the timed region"
+
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        nroof = min(args.steps, 3)
+        with GemmTimer() as gt:
+            for i in range(nroof):
+                step(total + i)
+        tot = gt.summary()
+        fl = sum(v[0] for v in tot.values())
+        tt = sum(v[1] for v in tot.values())
+        n = sum(v[2] for v in tot.values())
+        roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel<TA,TB> (fwd/dgrad/wgrad)", "achieved": round(fl / tt / 1e12, 1),
+                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / tt / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "launches_per_step": n // nroof, "avg_launch_us": round(tt / n * 1e6, 1), "avg_launch_gflop": round(fl / n / 1e9, 2),
+                "gemm_ms_per_step": round(tt / nroof * 1e3, 2),
+                "by_pass": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / nroof * 1e3, 2), "launches": v[2] // nroof}
+                            for k, v in tot.items()},
+                "step_algorithmic_tflop": round(algorithmic_train_flops(B, T, L) / 1e12, 2),
+                "step_frac": round(algorithmic_train_flops(B, T, L) / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4)}
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            ncores = host_cores()
+            log(f"cpu baseline on {ncores} cores ...")
+            cpu = cpu_baseline(ncores)
+            log("cpu baseline done")
+        rec = {"metric": "video-text samples/sec/node, mPLUG-Video 1.3B pretrain step", "value": round(world * B * args.steps / dt, 2),
+               "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": f"mPLUG-Video GPT3-1.3B pretrain step (freezeGPT, TimeSformer CLIP-B/16), per-GPU bs={B} x {T} frames x 224^2 + {L}-token titles",
+                          "global_batch": world * B, "frames": T, "text_len": L, "queries": Shapes.num_queries, "parallelism": f"dp{world}",
+                          "trainable_params_m": round(engine.flat.numel / 1e6, 1), "final_loss": round(final_loss, 4)},
+               "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
