@@ -147,23 +147,51 @@ __global__ void add_kernel(const bf16* __restrict__ a, const bf16* __restrict__ 
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
     *(bf16x4*)(o + i * 4) = cvt4(cvt4(*(const bf16x4*)(a + i * 4)) + cvt4(*(const bf16x4*)(b + i * 4)));
 }
-constexpr int COLSUM_ROWS_SPLIT = 256;
-// grid (ceil(cols/256), nsplit): thread owns 1 column... 4 columns per thread, loops rows of its split
-__global__ void colsum_partial_kernel(const bf16* __restrict__ in, float* __restrict__ part, long long rows, int cols,
-                                      long long ld, RowMap m) {
-  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (c >= cols) return;
-  f32x4 a = {0.f, 0.f, 0.f, 0.f};
-  for (long long r = blockIdx.y; r < rows; r += gridDim.y) a += cvt4(*(const bf16x4*)(in + map_row(m, r) * ld + c));
-  *(f32x4*)(part + (long long)blockIdx.y * cols + c) = a;
+constexpr int COLSUM_ROWS_SPLIT = 128;
+// partial sums: grid (ceil(cols/256), nsplit); a workgroup = 64 column-quads x 4 row lanes, each
+// thread keeps 4 independent row loads in flight; the 4 row lanes are reduced through LDS.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16* __restrict__ in, float* __restrict__ part, long long rows,
+                                                             int cols, long long ld, RowMap m) {
+  __shared__ f32x4 red[4][64];
+  const int cq = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + cq) * 4;
+  const bool ok = c < cols;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+  const long long step = (long long)gridDim.y * 4;
+  long long r = (long long)blockIdx.y * 4 + rl;
+  if (ok) {
+    for (; r + 3 * step < rows; r += 4 * step) {
+      const bf16x4 v0 = *(const bf16x4*)(in + map_row(m, r) * ld + c);
+      const bf16x4 v1 = *(const bf16x4*)(in + map_row(m, r + step) * ld + c);
+      const bf16x4 v2 = *(const bf16x4*)(in + map_row(m, r + 2 * step) * ld + c);
+      const bf16x4 v3 = *(const bf16x4*)(in + map_row(m, r + 3 * step) * ld + c);
+      a0 += cvt4(v0);
+      a1 += cvt4(v1);
+      a2 += cvt4(v2);
+      a3 += cvt4(v3);
+    }
+    for (; r < rows; r += step) a0 += cvt4(*(const bf16x4*)(in + map_row(m, r) * ld + c));
+  }
+  red[rl][cq] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (rl == 0 && ok) *(f32x4*)(part + (long long)blockIdx.y * cols + c) = (red[0][cq] + red[1][cq]) + (red[2][cq] + red[3][cq]);
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, bf16* __restrict__ out, int nsplit, int cols, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+// final: workgroup = 64 columns x 4 partial lanes
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, bf16* __restrict__ out, int nsplit, int cols,
+                                                           int accumulate) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   float a = 0.f;
-  for (int i = 0; i < nsplit; ++i) a += part[(long long)i * cols + c];
-  if (accumulate) a += bf2f(out[c]);
-  out[c] = f2bf(a);
+  if (c < cols)
+    for (int i = pl; i < nsplit; i += 4) a += part[(long long)i * cols + c];
+  red[pl][cl] = a;
+  __syncthreads();
+  if (pl == 0 && c < cols) {
+    a = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    if (accumulate) a += bf2f(out[c]);
+    out[c] = f2bf(a);
+  }
 }
 
 // ---------------------------------------------------------------- GPT embedding front
@@ -343,11 +371,11 @@ extern "C" int mpv_colsum(const void* in, void* out, int64_t rows, int64_t cols,
   MPV_REQUIRE(cols > 0 && cols % 4 == 0 && ld % 4 == 0 && rows > 0, MPV_E_SHAPE, "mpv_colsum: bad shape");
   int nsplit = (int)(rows < COLSUM_ROWS_SPLIT ? rows : COLSUM_ROWS_SPLIT);
   MPV_REQUIRE(workspace_bytes >= (size_t)nsplit * cols * sizeof(float), MPV_E_ARG, "mpv_colsum: workspace too small");
-  const int threads = 64;
-  dim3 grid((unsigned)((cols / 4 + threads - 1) / threads), nsplit);
-  hipLaunchKernelGGL(colsum_partial_kernel, grid, dim3(threads), 0, stream, (const bf16*)in, (float*)workspace, (long long)rows,
+  nsplit = (int)((rows + 3) / 4 < COLSUM_ROWS_SPLIT ? (rows + 3) / 4 : COLSUM_ROWS_SPLIT);
+  dim3 grid((unsigned)((cols / 4 + 63) / 64), nsplit);
+  hipLaunchKernelGGL(colsum_partial_kernel, grid, dim3(256), 0, stream, (const bf16*)in, (float*)workspace, (long long)rows,
                      (int)cols, (long long)ld, RowMap{group, stride, offset});
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, stream, (const float*)workspace,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, stream, (const float*)workspace,
                      (bf16*)out, nsplit, (int)cols, accumulate);
   return mpv_check_launch("mpv_colsum");
 }

@@ -67,32 +67,53 @@ __device__ __forceinline__ int lds_addr_tr(int krow, int cb) {
   return krow * 256 + ((((cb >> 6) ^ (krow & 3))) << 6) + (cb & 63);
 }
 
+typedef __attribute__((address_space(3))) void lds_void;
+
+// Per-thread addressing of the LDS-DMA staging (buffer_load_dwordx4 ... lds): one wave instruction
+// fills 1 KiB of LDS lane-linearly (lane l -> +16*l), so the LDS image is fixed and the XOR
+// swizzles are applied to the per-lane GLOBAL source address instead (and again on the read side).
+// Wave w issues instructions j=0..3 of each operand tile; instruction (w,j) covers LDS bytes
+// [(4w+j)*1024, +1024) = 8 rows of a k-contiguous tile or 4 k-rows of a reduction-slow tile.
 template <bool T>
 struct Loader {
-  // per-thread constant part of the 4 chunk offsets
-  uint32_t off[4];
-  bool rowok[4];
-  int ldsw[4];
+  uint32_t off[4];   // byte offset of this lane's 16-byte chunk, minus the k0-dependent part
+  bool ok[4];
 
-  // k-contiguous: rows = output index (M or N side), tile origin row0, total rows R.
-  __device__ __forceinline__ void init_kc(int tid, int row0, int R, long long ld, RowMap map) {
+  __device__ __forceinline__ void init_kc(int lane, int wave, int row0, int R, long long ld, RowMap map) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = (wave * 4 + j) * 8 + (lane >> 3);
+      const int kc = (lane & 7) ^ ((row >> 1) & 7);
+      const long long gr = row0 + row;
+      ok[j] = gr < R;
+      off[j] = (uint32_t)((map_row(map, ok[j] ? gr : 0) * ld + kc * 8) * 2);
+    }
+  }
+  // register-staged k-contiguous operand (used beside a reduction-slow operand): thread t owns
+  // rows (t>>3)+32i, 16-byte chunk t&7
+  __device__ __forceinline__ void init_kc_reg(int tid, int row0, int R, long long ld, RowMap map) {
     const int kc = tid & 7;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = (tid >> 3) + 32 * i;
       const long long gr = row0 + row;
-      rowok[i] = gr < R;
-      off[i] = (uint32_t)((map_row(map, rowok[i] ? gr : 0) * ld + kc * 8) * 2);
+      ok[i] = gr < R;
+      off[i] = (uint32_t)((map_row(map, ok[i] ? gr : 0) * ld + kc * 8) * 2);
       ldsw[i] = lds_addr_kc(row, kc);
     }
   }
-  // reduction-slow: tile is [64 k][128 cols]; col0 origin along the output index, Cn total cols.
+  __device__ __forceinline__ int kc_of(int lane, int wave, int j) const {
+    const int row = (wave * 4 + j) * 8 + (lane >> 3);
+    return (lane & 7) ^ ((row >> 1) & 7);
+  }
+  // reduction-slow operands are staged through registers (thread t: k-rows (t>>4)+16i, chunk t&15)
+  int ldsw[4];
   __device__ __forceinline__ void init_tr(int tid, int col0, int Cn) {
     const int cc = tid & 15;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int krow = (tid >> 4) + 16 * i;
-      rowok[i] = (col0 + cc * 8) < Cn;
+      ok[i] = (col0 + cc * 8) < Cn;
       off[i] = (uint32_t)((col0 + cc * 8) * 2);
       ldsw[i] = lds_addr_tr(krow, cc * 16);
     }
@@ -101,10 +122,10 @@ struct Loader {
 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+  __shared__ __attribute__((aligned(1024))) char smem[4 * TILE_BYTES];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wrow = wave >> 1, wcol = wave & 1;
 
   // XCD-aware bijective remap: workgroup b runs on XCD b%8; give each XCD a contiguous tile range.
@@ -125,42 +146,51 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
 
   Loader<TA> la;
   Loader<TB> lb;
-  if constexpr (TA) la.init_tr(tid, m0, p.M); else la.init_kc(tid, m0, p.M, p.lda, p.amap);
-  if constexpr (TB) lb.init_tr(tid, n0, p.N); else lb.init_kc(tid, n0, p.N, p.ldb, RowMap{0, 0, 0});
+  constexpr bool DMA = !TA && !TB;   // forward pass: both operands by LDS-DMA; dgrad/wgrad: register staging
+  if constexpr (TA) la.init_tr(tid, m0, p.M);
+  else if constexpr (DMA) la.init_kc(lane, wave, m0, p.M, p.lda, p.amap);
+  else la.init_kc_reg(tid, m0, p.M, p.lda, p.amap);
+  if constexpr (TB) lb.init_tr(tid, n0, p.N);
+  else lb.init_kc(lane, wave, n0, p.N, p.ldb, RowMap{0, 0, 0});
+  i32x4 sa[DMA ? 1 : 4], sb[DMA ? 1 : 4];
 
-  i32x4 sa[4], sb[4];
-
-  auto issue = [&](int k0) {
+  // k-contiguous operands: LDS-DMA of K-tile k0 into LDS buffer `buf` (4 x 1 KiB per wave per operand);
+  // reduction-slow operands: buffer loads into registers (committed to LDS after the MFMAs)
+  auto issue = [&](int k0, int buf) {
+    char* pa = smem + buf * 2 * TILE_BYTES + wave * 4096;
+    char* pb = pa + TILE_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      uint32_t va, vb;
+    for (int j = 0; j < 4; ++j) {
       if constexpr (TA) {
-        const int kr = k0 + (tid >> 4) + 16 * i;
-        const bool ok = la.rowok[i] && kr < kend;
-        va = ok ? (uint32_t)(map_row(p.kmap, kr) * p.lda * 2) + la.off[i] : 0x80000000u;
+        const int kr = k0 + (tid >> 4) + 16 * j;
+        const uint32_t va = (la.ok[j] && kr < kend) ? (uint32_t)(map_row(p.kmap, kr) * p.lda * 2) + la.off[j] : 0x80000000u;
+        sa[j] = __builtin_amdgcn_raw_buffer_load_b128(ra_src, va, 0, 0);
+      } else if constexpr (DMA) {
+        const uint32_t va = (la.ok[j] && (k0 + la.kc_of(lane, wave, j) * 8) < kend) ? la.off[j] + (uint32_t)(k0 * 2) : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_src, (lds_void*)(pa + j * 1024), 16, va, 0, 0, 0);
       } else {
-        const bool ok = la.rowok[i] && (k0 + (tid & 7) * 8) < kend;
-        va = ok ? la.off[i] + (uint32_t)(k0 * 2) : 0x80000000u;
+        const uint32_t va = (la.ok[j] && (k0 + (tid & 7) * 8) < kend) ? la.off[j] + (uint32_t)(k0 * 2) : 0x80000000u;
+        sa[j] = __builtin_amdgcn_raw_buffer_load_b128(ra_src, va, 0, 0);
       }
       if constexpr (TB) {
-        const int kr = k0 + (tid >> 4) + 16 * i;
-        const bool ok = lb.rowok[i] && kr < kend;
-        vb = ok ? (uint32_t)(map_row(p.kmap, kr) * p.ldb * 2) + lb.off[i] : 0x80000000u;
+        const int kr = k0 + (tid >> 4) + 16 * j;
+        const uint32_t vb = (lb.ok[j] && kr < kend) ? (uint32_t)(map_row(p.kmap, kr) * p.ldb * 2) + lb.off[j] : 0x80000000u;
+        sb[j] = __builtin_amdgcn_raw_buffer_load_b128(rb_src, vb, 0, 0);
       } else {
-        const bool ok = lb.rowok[i] && (k0 + (tid & 7) * 8) < kend;
-        vb = ok ? lb.off[i] + (uint32_t)(k0 * 2) : 0x80000000u;
+        const uint32_t vb = (lb.ok[j] && (k0 + lb.kc_of(lane, wave, j) * 8) < kend) ? lb.off[j] + (uint32_t)(k0 * 2) : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_src, (lds_void*)(pb + j * 1024), 16, vb, 0, 0, 0);
       }
-      sa[i] = __builtin_amdgcn_raw_buffer_load_b128(ra_src, va, 0, 0);
-      sb[i] = __builtin_amdgcn_raw_buffer_load_b128(rb_src, vb, 0, 0);
     }
   };
   auto commit = [&](int buf) {
     char* pa = smem + buf * 2 * TILE_BYTES;
     char* pb = pa + TILE_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *(i32x4*)(pa + la.ldsw[i]) = sa[i];
-      *(i32x4*)(pb + lb.ldsw[i]) = sb[i];
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (!DMA) {
+        *(i32x4*)(pa + la.ldsw[j]) = sa[j];
+        *(i32x4*)(pb + lb.ldsw[j]) = sb[j];
+      }
     }
   };
 
@@ -195,14 +225,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
   };
 
   if (nk > 0) {
-    issue(kbeg);
+    issue(kbeg, 0);
     commit(0);
   }
-  __syncthreads();
-
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) issue(kbeg + (kt + 1) * BK);
+    // tile kt has landed (every wave drains its own DMA, then the barrier), and every wave is done
+    // reading the other buffer (its reads belong to iteration kt-1)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    __syncthreads();
+    if (kt + 1 < nk) issue(kbeg + (kt + 1) * BK, cur ^ 1);
     const char* pa = smem + cur * 2 * TILE_BYTES;
     const char* pb = pa + TILE_BYTES;
 #pragma unroll
@@ -219,8 +251,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) commit(cur ^ 1);
-    __syncthreads();
+    if constexpr (TA || TB) {
+      if (kt + 1 < nk) commit(cur ^ 1);
+    }
   }
 
   // ------------------------------------------------------------------ epilogue

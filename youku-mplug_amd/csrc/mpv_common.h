@@ -44,7 +44,9 @@ struct RowMap {
 };
 __host__ __device__ __forceinline__ long long map_row(RowMap m, long long r) {
   if (m.group == 0) return r;
-  return (r / m.group) * (long long)m.stride + (r % m.group) + m.offset;
+  const unsigned ru = (unsigned)r, g = (unsigned)m.group;   // rows < 2^31: 32-bit divide (the 64-bit one is a long routine)
+  const unsigned q = ru / g;
+  return (long long)q * (long long)m.stride + (long long)(ru - q * g) + m.offset;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -193,23 +193,34 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p) {
   }
 }
 
-__global__ void ln_dparam_finalize(const float* part, int nblk, int cols, bf16* dgamma, bf16* dbeta, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+// workgroup = 64 columns x 4 partial lanes (coalesced 256-byte rows of the partial table)
+__global__ __launch_bounds__(256) void ln_dparam_finalize(const float* __restrict__ part, int nblk, int cols, bf16* dgamma,
+                                                          bf16* dbeta, int accumulate) {
+  __shared__ float red[2][4][64];
+  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   float a = 0.f, b = 0.f;
-  for (int i = 0; i < nblk; ++i) {
-    a += part[(long long)i * 2 * cols + c];
-    b += part[(long long)i * 2 * cols + cols + c];
+  if (c < cols)
+    for (int i = pl; i < nblk; i += 4) {
+      a += part[(long long)i * 2 * cols + c];
+      b += part[(long long)i * 2 * cols + cols + c];
+    }
+  red[0][pl][cl] = a;
+  red[1][pl][cl] = b;
+  __syncthreads();
+  if (pl == 0 && c < cols) {
+    a = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+    b = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+    if (accumulate) {
+      a += bf2f(dgamma[c]);
+      b += bf2f(dbeta[c]);
+    }
+    dgamma[c] = f2bf(a);
+    dbeta[c] = f2bf(b);
   }
-  if (accumulate) {
-    a += bf2f(dgamma[c]);
-    b += bf2f(dbeta[c]);
-  }
-  dgamma[c] = f2bf(a);
-  dbeta[c] = f2bf(b);
 }
 
-constexpr int LN_BWD_MAX_BLOCKS = 1024;
+constexpr int LN_BWD_MAX_BLOCKS = 512;
 
 template <int MAXC>
 void launch_fwd(const LnFwdArgs& a, int grid, hipStream_t s) {
@@ -294,7 +305,7 @@ extern "C" int mpv_layernorm_bwd(const void* dy, const void* x, const void* gamm
   else if (nc <= 10) launch_bwd<10>(a, dparam, grid, stream);
   else launch_bwd<16>(a, dparam, grid, stream);
   if (dparam)
-    hipLaunchKernelGGL(ln_dparam_finalize, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(ln_dparam_finalize, dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, stream,
                        (const float*)workspace, grid, (int)cols, (bf16*)dgamma, (bf16*)dbeta, accumulate_dparams);
   return mpv_check_launch("mpv_layernorm_bwd");
 }
