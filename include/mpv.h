@@ -175,7 +175,8 @@ int mpv_gpt_embed_bwd(const void* dh, void* dquery, int B, int Q, int L, int H, 
 /* Masked cross-entropy over bf16 logits in fp32 (models/modeling_distributed_gpt3.py:1352-1359,
  * 1615-1617): losses[r] = lse(logits[r]) - logits[r][labels[r]];  if dlogits != NULL it is
  * filled with (softmax - onehot) * weight[r] (weight = loss_mask / sum(loss_mask)), may alias
- * logits.  loss_sum (fp32 scalar, pre-zeroed) accumulates sum_r losses[r]*weight[r]. */
+ * logits.  loss_sum (fp32 scalar) receives sum_r losses[r]*weight[r], reduced in a fixed order
+ * (deterministic; needs `losses`). */
 int mpv_cross_entropy(const void* logits, const int64_t* labels, const float* weight, float* losses, float* loss_sum,
                       void* dlogits, int64_t rows, int64_t vocab, int64_t ld, mpv_stream_t stream);
 

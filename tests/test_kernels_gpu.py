@@ -53,6 +53,19 @@ def test_gemm_wgrad_tn(dev, M, N, K):
     close(out, dy.float().t() @ x.float(), 1e-2, "dW = dY^T X")
 
 
+def test_gemm_bitwise_deterministic(dev):
+    """No races in the LDS-DMA / register pipelines: repeated launches are bit-identical."""
+    from youku_mplug_amd import ops
+    for (M, N, K, ta, tb) in [(1576, 768, 768, 0, 0), (1000, 2304, 768, 0, 0), (520, 8192, 2048, 0, 0), (1576, 768, 2304, 0, 1),
+                              (768, 2304, 1576, 1, 1)]:
+        a = rn(K, M, dev=dev, seed=90) if ta else rn(M, K, dev=dev, seed=90)
+        b = rn(K, N, dev=dev, seed=91) if tb else rn(N, K, dev=dev, seed=91)
+        ref = ops.gemm(a, b, M, N, K, trans_a=bool(ta), trans_b=bool(tb)).clone()
+        for _ in range(25):
+            out = ops.gemm(a, b, M, N, K, trans_a=bool(ta), trans_b=bool(tb))
+            assert torch.equal(out, ref), (M, N, K, ta, tb)
+
+
 def test_gemm_epilogues(dev):
     from youku_mplug_amd import ops
     M, N, K = 300, 256, 192

@@ -274,7 +274,6 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const bf16* __restri
   if (tid == 0) {
     const float loss = lse - bf2f(row[tgt]);
     if (losses) losses[r] = loss;
-    if (loss_sum && w != 0.f) atomicAdd(loss_sum, loss * w);
   }
   if (dlogits) {
     bf16* drow = dlogits + r * ld;
@@ -290,6 +289,18 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const bf16* __restri
       *(bf16x8*)(drow + c * 8) = cvt8(g);
     }
   }
+}
+
+// deterministic sum_r losses[r] * weight[r] (fixed reduction order: no float atomics)
+__global__ __launch_bounds__(256) void weighted_sum_kernel(const float* __restrict__ losses, const float* __restrict__ weight,
+                                                           float* __restrict__ out, long long rows) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long long r = threadIdx.x; r < rows; r += 256) s += losses[r] * (weight ? weight[r] : 1.0f);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 inline int ew_grid(long long work_items, int threads = 256) {
@@ -417,7 +428,10 @@ extern "C" int mpv_cross_entropy(const void* logits, const int64_t* labels, cons
                                  hipStream_t stream) {
   MPV_REQUIRE(logits && labels, MPV_E_ARG, "mpv_cross_entropy: null pointer");
   MPV_REQUIRE(rows > 0 && vocab > 0 && vocab % 8 == 0 && ld % 8 == 0, MPV_E_SHAPE, "mpv_cross_entropy: vocab/ld must be multiples of 8");
+  MPV_REQUIRE(!loss_sum || losses, MPV_E_ARG, "mpv_cross_entropy: loss_sum needs the per-row losses buffer");
   hipLaunchKernelGGL(cross_entropy_kernel, dim3((unsigned)rows), dim3(256), 0, stream, (const bf16*)logits, labels, weight, losses,
                      loss_sum, (bf16*)dlogits, (int)vocab, (long long)ld);
+  if (loss_sum)
+    hipLaunchKernelGGL(weighted_sum_kernel, dim3(1), dim3(256), 0, stream, (const float*)losses, weight, loss_sum, (long long)rows);
   return mpv_check_launch("mpv_cross_entropy");
 }
