@@ -1,0 +1,42 @@
+"""Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate passes because
+the TCC block has 4 counter slots).  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 128-B
+requests of wide coalesced streams at 64 B -> doubled.  Usage: rocpd_pmc.py FETCH.db WRITE.db [out.md]"""
+import re
+import sqlite3
+import sys
+
+
+def short(n):
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    return re.sub(r"^void ", "", n)[:70]
+
+
+def load(db, counter):
+    c = sqlite3.connect(db)
+    agg = {}
+    for name, val in c.execute("select kernel_name, value from counters_collection where counter_name=?", (counter,)):
+        a = agg.setdefault(short(name), [0, 0.0])
+        a[0] += 1
+        a[1] += val
+    return agg
+
+
+def main():
+    f, w = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    rows = []
+    for k in f:
+        n, fk = f[k]
+        wk = w.get(k, [n, 0.0])[1]
+        rows.append((2 * fk + wk, k, n, fk, wk))
+    rows.sort(reverse=True)
+    lines = ["| kernel | launches | FETCH_SIZE KB (raw) | WRITE_SIZE KB | HBM MB/launch (2*FETCH+WRITE) |", "|---|---|---|---|---|"]
+    for tot, k, n, fk, wk in rows[:25]:
+        lines.append(f"| `{k}` | {n} | {fk:.0f} | {wk:.0f} | {tot / n / 1024:.2f} |")
+    out = "\n".join(lines) + "\n"
+    if len(sys.argv) > 3:
+        open(sys.argv[3], "w").write(out)
+    print(out)
+
+
+if __name__ == "__main__":
+    main()

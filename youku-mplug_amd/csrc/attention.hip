@@ -63,10 +63,12 @@ struct ChunkStage {
   static constexpr int NLOAD = (CH * CPR + 255) / 256;
   i32x4 r[NLOAD];
 
+  // nthr = blockDim.x (256..512): with more threads the later iterations are simply predicated off
   __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t src, int tid, int row0, int nrows, long long rs) {
+    const int nthr = blockDim.x;
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
-      const int c = tid + 256 * i;
+      const int c = tid + nthr * i;
       const int row = c / CPR, cc = c - row * CPR;
       const bool ok = (c < CH * CPR) && (row0 + row < nrows) && (cc * 8 < HD);
       const uint32_t off = ok ? (uint32_t)(((long long)(row0 + row) * rs + cc * 8) * 2) : 0x80000000u;
@@ -87,9 +89,10 @@ struct ChunkStage {
     }
   }
   __device__ __forceinline__ void commit(char* lds, int tid) {
+    const int nthr = blockDim.x;
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
-      const int c = tid + 256 * i;
+      const int c = tid + nthr * i;
       const int row = c / CPR, cc = c - row * CPR;
       if (c < CH * CPR) *(i32x4*)(lds + row * ROWB + cc * 16) = r[i];
     }
@@ -151,13 +154,14 @@ __device__ __forceinline__ int last_visible_key(const AttnArgs& p, int qrow) {
 
 // =========================================================================== forward
 template <int HD>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs p) {
   constexpr int NS = HD / 16;
   constexpr int NDT = (HD + 31) / 32;
   __shared__ __attribute__((aligned(16))) char smem[4 * CHUNK_BYTES];  // [buf][K|V]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int rows_per_blk = (blockDim.x >> 6) * 32;
+  const int q0 = blockIdx.x * rows_per_blk + wave * 32;
   const int qrow = q0 + (lane & 31);
   const bf16* qb = p.q + b * p.q_bs + h * p.q_hs;
   const bf16* kb = p.k + b * p.k_bs + h * p.k_hs;
@@ -172,11 +176,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
     scale_frags_bf16(qf, p.scale);
     sc = 1.0f;
   }
-  // keys needed by this workgroup
-  const int blk_last_q = min(p.sq - 1, blockIdx.x * 128 + 127);
+  // keys needed by this workgroup / by this wave (wave-uniform: tiles beyond it are skipped)
+  const int blk_last_q = min(p.sq - 1, blockIdx.x * rows_per_blk + rows_per_blk - 1);
   const int kmax = last_visible_key(p, blk_last_q);
   const int nchunk = kmax / CH + 1;
   const int my_last = last_visible_key(p, qrow);
+  const int wave_last = q0 < p.sq ? last_visible_key(p, min(p.sq - 1, q0 + 31)) : -1;
 
   ChunkStage<HD> sk_, sv_;
   float m = -INFINITY, l = 0.f;
@@ -198,6 +203,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
     const char* kl = smem + cur * 2 * CHUNK_BYTES;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
+      if (c * CH + kt * 32 > wave_last) continue;
       f32x16 s;
       scores(kl, kt, s);
       float mx = -INFINITY;
@@ -245,6 +251,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
     const char* vl = kl + CHUNK_BYTES;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
+      if (c * CH + kt * 32 > wave_last) continue;
       f32x16 s;
       scores(kl, kt, s);
 #pragma unroll
@@ -304,13 +311,14 @@ __global__ void attn_delta_kernel(const AttnArgs p, int hd) {
 
 // =========================================================================== backward: dQ
 template <int HD>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttnArgs p) {
   constexpr int NS = HD / 16;
   constexpr int NDT = (HD + 31) / 32;
   __shared__ __attribute__((aligned(16))) char smem[4 * CHUNK_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int rows_per_blk = (blockDim.x >> 6) * 32;
+  const int q0 = blockIdx.x * rows_per_blk + wave * 32;
   const int qrow = q0 + (lane & 31);
   const bf16* qb = p.q + b * p.q_bs + h * p.q_hs;
   const bf16* kb = p.k + b * p.k_bs + h * p.k_hs;
@@ -330,9 +338,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
   const bool qok = qrow < p.sq;
   const float lse = qok ? p.lse[(long long)bh * p.sq + qrow] : INFINITY;
   const float dl = qok ? p.delta[(long long)bh * p.sq + qrow] : 0.f;
-  const int blk_last_q = min(p.sq - 1, blockIdx.x * 128 + 127);
+  const int blk_last_q = min(p.sq - 1, blockIdx.x * rows_per_blk + rows_per_blk - 1);
   const int nchunk = last_visible_key(p, blk_last_q) / CH + 1;
   const int my_last = last_visible_key(p, qrow);
+  const int wave_last = q0 < p.sq ? last_visible_key(p, min(p.sq - 1, q0 + 31)) : -1;
 
   f32x16 dqacc[NDT];
 #pragma unroll
@@ -356,6 +365,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
     const char* vl = kl + CHUNK_BYTES;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
+      if (c * CH + kt * 32 > wave_last) continue;
       f32x16 s, dp;
 #pragma unroll
       for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
@@ -408,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
 
 // =========================================================================== backward: dK, dV
 template <int HD>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
   constexpr int NS = HD / 16;
   constexpr int NDT = (HD + 31) / 32;
   // [buf][Q|dO] chunks + [buf][lse|delta] rows
@@ -416,7 +426,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnArgs p) 
   float* stat = (float*)(smem + 4 * CHUNK_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
-  const int k0 = blockIdx.x * 128 + wave * 32;
+  const int rows_per_blk = (blockDim.x >> 6) * 32;
+  const int k0 = blockIdx.x * rows_per_blk + wave * 32;
   const int krow = k0 + (lane & 31);
   const bf16* qb = p.q + b * p.q_bs + h * p.q_hs;
   const bf16* kb = p.k + b * p.k_bs + h * p.k_hs;
@@ -432,7 +443,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnArgs p) 
   const bool kok = krow < p.sk;
 
   // query rows that can see any key of this workgroup: q >= first_key - (sk - sq) when causal
-  const int first_q = p.causal ? max(0, blockIdx.x * 128 - (p.sk - p.sq)) : 0;
+  const int first_q = p.causal ? max(0, blockIdx.x * rows_per_blk - (p.sk - p.sq)) : 0;
+  // first query row that can see any key of THIS wave (wave-uniform); whole q-tiles before it are skipped
+  const int wave_first_q = k0 >= p.sk ? p.sq : (p.causal ? max(0, k0 - (p.sk - p.sq)) : 0);
   const int c_begin = first_q / CH;
   const int nchunk = (p.sq + CH - 1) / CH;
 
@@ -479,6 +492,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const AttnArgs p) 
     const float* sl = stat + cur * 2 * CH;
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
+      if (c * CH + qt * 32 + 31 < wave_first_q) continue;
       f32x16 s, dp;
 #pragma unroll
       for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
@@ -655,6 +669,13 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TempArgs p) {
   }
 }
 
+// waves per workgroup: cover a whole sequence with one workgroup when it has <= 256 rows (no idle
+// waves: 160 rows -> 5 waves, 197 -> 7), otherwise 8 waves = 256 rows per workgroup
+int waves_for(int rows) {
+  const int w = (rows + 31) / 32;
+  return w < 4 ? 4 : (w > 8 ? 8 : w);
+}
+
 int fill_args(AttnArgs& a, const mpv_attn_desc* d) {
   a.q = (const bf16*)d->q;
   a.k = (const bf16*)d->k;
@@ -701,7 +722,8 @@ extern "C" int mpv_attn_fwd(const mpv_attn_desc* d, hipStream_t stream) {
   if (rc) return rc;
   AttnArgs a = {};
   fill_args(a, d);
-  dim3 grid((d->sq + 127) / 128, d->batch * d->heads), block(256);
+  const int nw = waves_for(d->sq);
+  dim3 grid((d->sq + 32 * nw - 1) / (32 * nw), d->batch * d->heads), block(64 * nw);
   switch (d->head_dim) {
     case 64: hipLaunchKernelGGL((attn_fwd_kernel<64>), grid, block, 0, stream, a); break;
     case 80: hipLaunchKernelGGL((attn_fwd_kernel<80>), grid, block, 0, stream, a); break;
@@ -724,19 +746,21 @@ extern "C" int mpv_attn_bwd(const mpv_attn_desc* d, const void* dO, void* dq, vo
   a.delta = delta;
   dim3 block(256);
   hipLaunchKernelGGL(attn_delta_kernel, dim3((d->sq + 3) / 4, d->batch * d->heads), block, 0, stream, a, d->head_dim);
-  dim3 gq((d->sq + 127) / 128, d->batch * d->heads), gk((d->sk + 127) / 128, d->batch * d->heads);
+  const int nwq = waves_for(d->sq), nwk = 4;   // dK/dV keeps 4 waves (its accumulators need > 256 VGPRs at 8)
+  dim3 gq((d->sq + 32 * nwq - 1) / (32 * nwq), d->batch * d->heads), gk((d->sk + 32 * nwk - 1) / (32 * nwk), d->batch * d->heads);
+  dim3 bq(64 * nwq), bk(64 * nwk);
   switch (d->head_dim) {
     case 64:
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), gq, block, 0, stream, a);
-      hipLaunchKernelGGL((attn_bwd_dkv_kernel<64>), gk, block, 0, stream, a);
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), gq, bq, 0, stream, a);
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<64>), gk, bk, 0, stream, a);
       break;
     case 80:
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<80>), gq, block, 0, stream, a);
-      hipLaunchKernelGGL((attn_bwd_dkv_kernel<80>), gk, block, 0, stream, a);
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<80>), gq, bq, 0, stream, a);
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<80>), gk, bk, 0, stream, a);
       break;
     default:
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<96>), gq, block, 0, stream, a);
-      hipLaunchKernelGGL((attn_bwd_dkv_kernel<96>), gk, block, 0, stream, a);
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<96>), gq, bq, 0, stream, a);
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<96>), gk, bk, 0, stream, a);
       break;
   }
   return mpv_check_launch("mpv_attn_bwd");

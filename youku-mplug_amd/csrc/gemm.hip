@@ -56,7 +56,7 @@ struct GemmArgs {
   int out_f32;
   int accumulate;
   int k_per_split;
-  int tiles_n;
+  int tiles_n, tiles_m;
   int nwg;
 };
 
@@ -133,7 +133,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
   const int nwg = p.nwg;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
   const int pid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int tile_m = pid / p.tiles_n, tile_n = pid - tile_m * p.tiles_n;
+  // L2 blocking inside an XCD's range: walk GM m-tiles per n-tile, so the ~64 workgroups resident on an
+  // XCD cover an ~8x8 patch of tiles (8 A panels + 8 B panels, each reused 8x from the 4 MiB L2)
+  constexpr int GM = 8;
+  const int gsz = GM * p.tiles_n;
+  const int grp = pid / gsz, rem = pid - grp * gsz;
+  const int gm = min(GM, p.tiles_m - grp * GM);
+  const int tile_n = rem / gm, tile_m = grp * GM + (rem - tile_n * gm);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int split = blockIdx.y;
@@ -358,12 +364,22 @@ extern "C" size_t mpv_gemm_workspace_size(int64_t M, int64_t N, int64_t K, int t
   return (size_t)M * N * sizeof(float) * 32;
 }
 
+// wgrad split: pick the split count whose workgroup count best fills whole rounds of the 512 resident
+// slots (256 CUs x 2 workgroups), keeping at least 4 K-steps per split.
 static int choose_splitk(int64_t M, int64_t N, int64_t K, size_t ws_bytes) {
   const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-  int s = 1;
-  while (tiles * s < 512 && s < 32 && K / (s * 2) >= 4 * BK) s *= 2;
-  while (s > 1 && (size_t)M * N * sizeof(float) * s > ws_bytes) s /= 2;
-  return s;
+  int best = 1;
+  double best_eff = 0.0;
+  for (int s = 1; s <= 32; ++s) {
+    if (s > 1 && (K / s < 4 * BK || (size_t)M * N * sizeof(float) * s > ws_bytes)) break;
+    const int64_t blocks = tiles * s;
+    const double eff = (double)blocks / (double)(((blocks + 511) / 512) * 512);
+    if (eff > best_eff + 0.02) {
+      best_eff = eff;
+      best = s;
+    }
+  }
+  return best;
 }
 
 extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
@@ -428,6 +444,7 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
 
   const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
   g.tiles_n = tiles_n;
+  g.tiles_m = tiles_m;
   g.nwg = tiles_m * tiles_n;
   int splitk = 1;
   if (transA && transB && !g.out_f32) splitk = choose_splitk(M, N, K, workspace ? workspace_bytes : 0);
