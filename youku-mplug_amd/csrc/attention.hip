@@ -42,7 +42,7 @@ struct AttnArgs {
   bf16* o;
   float* lse;
   long long q_bs, q_hs, q_rs, k_bs, k_hs, k_rs, v_bs, v_hs, v_rs, o_bs, o_hs, o_rs;
-  int heads, sq, sk;
+  int batch, heads, sq, sk;
   int causal;
   float scale;
   int scale_q_bf16;
@@ -100,16 +100,36 @@ struct ChunkStage {
 };
 
 // fragment with 8 consecutive d for row (lane&31) of 32-row tile `t`, d-step s (ds_read_b128)
+template <int PITCH = ROWB>
 __device__ __forceinline__ bf16x8 frag_rows(const char* lds, int t, int s, int lane) {
-  return *(const bf16x8*)(lds + (t * 32 + (lane & 31)) * ROWB + (s * 16 + (lane >> 5) * 8) * 2);
+  return *(const bf16x8*)(lds + (t * 32 + (lane & 31)) * PITCH + (s * 16 + (lane >> 5) * 8) * 2);
 }
 // transposed fragment: column d = dt*32 + (lane&31); 8 rows (t*32 + ks*16 + {0..3}+4h, +8) (tr read)
+template <int PITCH = ROWB>
 __device__ __forceinline__ bf16x8 frag_cols(const char* lds, int t, int ks, int dt, int lane) {
   const int h = lane >> 5;
   const int rbase = t * 32 + ks * 16 + 4 * h + ((lane & 15) >> 2);
   const int col = dt * 32 + ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + rbase * ROWB + col * 2));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + (rbase + 8) * ROWB + col * 2));
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + rbase * PITCH + col * 2));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + (rbase + 8) * PITCH + col * 2));
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo;
+  u.s.b = hi;
+  return u.v;
+}
+// clamped variants (resident kernels): rows past `last` re-read row `last` (finite data; the results of
+// such rows are always masked), so unpadded LDS regions are never over-read
+template <int PITCH>
+__device__ __forceinline__ bf16x8 frag_rows_c(const char* lds, int t, int s, int lane, int last) {
+  return *(const bf16x8*)(lds + min(t * 32 + (lane & 31), last) * PITCH + (s * 16 + (lane >> 5) * 8) * 2);
+}
+template <int PITCH>
+__device__ __forceinline__ bf16x8 frag_cols_c(const char* lds, int t, int ks, int dt, int lane, int last) {
+  const int h = lane >> 5;
+  const int rbase = t * 32 + ks * 16 + 4 * h + ((lane & 15) >> 2);
+  const int col = dt * 32 + ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + min(rbase, last) * PITCH + col * 2));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + min(rbase + 8, last) * PITCH + col * 2));
   union { struct { s16x4 a, b; } s; bf16x8 v; } u;
   u.s.a = lo;
   u.s.b = hi;
@@ -559,6 +579,389 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
   }
 }
 
+// =========================================================================== resident variants
+// Short sequences (<= 256 rows on the streamed side: GPT S<=208, ViT spatial 197): the whole K,V
+// (forward, dQ) or Q,dO (dK/dV) of one (batch, head) is brought into LDS ONCE by LDS-DMA
+// (buffer_load_dwordx4 ... lds; the [rows][208 B] image is lane-linear, 13 16-byte chunks per row, the
+// pad chunk and out-of-range rows read as zero), every wave keeps its own 32-row tile in registers and
+// then runs all tiles without further barriers.  The chunked kernels above pay one exposed HBM latency
+// per 64-row chunk, which dominated at these sizes.
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+// Workgroup y -> (batch, head) so that all heads of one sequence run on the SAME XCD (workgroup i lands on
+// XCD i % 8): the 8 x 192-byte head slices of a qkv row share 128-byte lines, which are then fetched
+// into one L2 once instead of once per XCD.  Falls back to the plain order when the grid has an x extent.
+__device__ __forceinline__ bool decode_bh(const AttnArgs& p, int& b, int& h) {
+  const int i = blockIdx.y;
+  if (gridDim.x != 1) {
+    b = i / p.heads;
+    h = i - b * p.heads;
+    return b < p.batch;
+  }
+  const int xcd = i & 7, j = i >> 3;
+  h = j % p.heads;
+  b = (j / p.heads) * 8 + xcd;
+  return b < p.batch;
+}
+
+// PITCH = 208: conflict-free ds_read_b128 of row fragments; PITCH = 192: 16 bytes/row tighter (enough for
+// ds_read_b64_tr_b16 column fragments), which is what lets two workgroups share a CU's 160 KiB at S=197.
+// Only `nrows` rows are written (no padding to whole 32-row tiles): tile reads past them hit whatever
+// follows in LDS -- the caller orders its regions so that data is finite where finiteness matters.
+template <int HD, int PITCH>
+__device__ __forceinline__ void dma_rows(const __amdgpu_buffer_rsrc_t src, char* lds, int nrows, long long rs, int wave, int nwaves,
+                                         int lane) {
+  constexpr int CPR = PITCH / 16;
+  const int ninstr = (nrows * CPR + 63) / 64;
+  for (int i = wave; i < ninstr; i += nwaves) {
+    const int g = i * 64 + lane;
+    const int row = g / CPR, cc = g - row * CPR;
+    const bool ok = row < nrows && cc * 8 < HD;
+    const uint32_t off = ok ? (uint32_t)(((long long)row * rs + cc * 8) * 2) : 0x80000000u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (lds_void_t*)(lds + i * 1024), 16, off, 0, 0, 0);
+  }
+}
+
+template <int HD>
+__global__ __launch_bounds__(512) void attn_fwd_res_kernel(const AttnArgs p) {
+  constexpr int NS = HD / 16;
+  constexpr int NDT = (HD + 31) / 32;
+  extern __shared__ __attribute__((aligned(1024))) char rsm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
+  int b, h;
+  if (!decode_bh(p, b, h)) return;
+  const int bh = b * p.heads + h;
+  char* vl = rsm;                                                         // [sk][192 B]
+  char* kl = rsm + (((long long)p.sk * 192 + 1023) / 1024) * 1024;        // [sk][208 B]; tile over-reads of V land in K (finite)
+  const bf16* qb = p.q + b * p.q_bs + h * p.q_hs;
+  const __amdgpu_buffer_rsrc_t ksrc = make_rsrc(p.k + b * p.k_bs + h * p.k_hs, (uint32_t)(((long long)(p.sk - 1) * p.k_rs + HD) * 2));
+  const __amdgpu_buffer_rsrc_t vsrc = make_rsrc(p.v + b * p.v_bs + h * p.v_hs, (uint32_t)(((long long)(p.sk - 1) * p.v_rs + HD) * 2));
+  dma_rows<HD, ROWB>(ksrc, kl, p.sk, p.k_rs, wave, nwaves, lane);
+  dma_rows<HD, 192>(vsrc, vl, p.sk, p.v_rs, wave, nwaves, lane);
+  const int q0 = (blockIdx.x * nwaves + wave) * 32;
+  const int qrow = q0 + (lane & 31);
+  bf16x8 qf[NS];
+  load_row_frags<HD>(qf, qb, p.q_rs, qrow, p.sq, lane);
+  float sc = p.scale;
+  if (p.scale_q_bf16) {
+    scale_frags_bf16(qf, p.scale);
+    sc = 1.0f;
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  if (q0 >= p.sq) return;
+  const int my_last = last_visible_key(p, qrow);
+  const int wave_last = last_visible_key(p, min(p.sq - 1, q0 + 31));
+  const int wave_first_last = last_visible_key(p, q0);      // tiles entirely <= this need no masking
+  const int nt = wave_last / 32 + 1;
+  const float c2 = sc * 1.4426950408889634f;               // work in the exp2 domain: p = 2^(s*c2 - m)
+  float m = -INFINITY, l = 0.f;
+  for (int kt = 0; kt < nt; ++kt) {
+    f32x16 s;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+    for (int st = 0; st < NS; ++st) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_c<ROWB>(kl, kt, st, lane, p.sk - 1), qf[st], s, 0, 0, 0);
+    float mx = -INFINITY;
+    if (kt * 32 + 31 <= wave_first_last) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        s[e] *= c2;
+        mx = fmaxf(mx, s[e]);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = kt * 32 + acc_row(e, lane);
+        s[e] = key <= my_last ? s[e] * c2 : -INFINITY;
+        mx = fmaxf(mx, s[e]);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);
+    if (mn > -INFINITY) {
+      float sum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sum += exp2f(s[e] - mn);
+      sum += __shfl_xor(sum, 32, 64);
+      l = l * exp2f(m - mn) + sum;
+      m = mn;
+    }
+  }
+  const float inv_l = l > 0.f ? 1.0f / l : 0.f;
+  if (qrow < p.sq && lane < 32 && p.lse) p.lse[(long long)bh * p.sq + qrow] = (m + log2f(l)) * 0.6931471805599453f;
+  f32x16 oacc[NDT];
+#pragma unroll
+  for (int d = 0; d < NDT; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+  for (int kt = 0; kt < nt; ++kt) {
+    f32x16 s;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+    for (int st = 0; st < NS; ++st) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_c<ROWB>(kl, kt, st, lane, p.sk - 1), qf[st], s, 0, 0, 0);
+    if (kt * 32 + 31 <= wave_first_last && !p.drop_thr) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[e] = exp2f(s[e] * c2 - m) * inv_l;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = kt * 32 + acc_row(e, lane);
+        float pr = key <= my_last ? exp2f(s[e] * c2 - m) * inv_l : 0.f;
+        if (p.drop_thr) {
+          const uint64_t idx = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qrow) * (uint64_t)p.sk + (uint64_t)key;
+          pr = mpv_keep(p.seed, idx, p.drop_thr) ? pr * p.drop_scale : 0.f;
+        }
+        s[e] = pr;
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 pf = acc_to_frag(s, ks);
+#pragma unroll
+      for (int d = 0; d < NDT; ++d)
+        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_c<192>(vl, kt, ks, d, lane, p.sk - 1), pf, oacc[d], 0, 0, 0);
+    }
+  }
+  if (qrow < p.sq) {
+    bf16* orow = p.o + b * p.o_bs + h * p.o_hs + (long long)qrow * p.o_rs;
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int col = d * 32 + 8 * q4 + 4 * (lane >> 5);
+        if (col < HD) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = oacc[d][4 * q4 + e];
+          *(bf16x4*)(orow + col) = cvt4(v);
+        }
+      }
+  }
+}
+
+template <int HD>
+__global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const AttnArgs p) {
+  constexpr int NS = HD / 16;
+  constexpr int NDT = (HD + 31) / 32;
+  extern __shared__ __attribute__((aligned(1024))) char rsm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
+  int b, h;
+  if (!decode_bh(p, b, h)) return;
+  const int bh = b * p.heads + h;
+  char* vl = rsm;                                                         // [sk][192 B]
+  char* kl = rsm + (((long long)p.sk * 192 + 1023) / 1024) * 1024;        // [sk][208 B]; tile over-reads of V land in K (finite)
+  const __amdgpu_buffer_rsrc_t ksrc = make_rsrc(p.k + b * p.k_bs + h * p.k_hs, (uint32_t)(((long long)(p.sk - 1) * p.k_rs + HD) * 2));
+  const __amdgpu_buffer_rsrc_t vsrc = make_rsrc(p.v + b * p.v_bs + h * p.v_hs, (uint32_t)(((long long)(p.sk - 1) * p.v_rs + HD) * 2));
+  dma_rows<HD, ROWB>(ksrc, kl, p.sk, p.k_rs, wave, nwaves, lane);
+  dma_rows<HD, 192>(vsrc, vl, p.sk, p.v_rs, wave, nwaves, lane);
+  const int q0 = (blockIdx.x * nwaves + wave) * 32;
+  const int qrow = q0 + (lane & 31);
+  bf16x8 qf[NS], dof[NS];
+  load_row_frags<HD>(qf, p.q + b * p.q_bs + h * p.q_hs, p.q_rs, qrow, p.sq, lane);
+  load_row_frags<HD>(dof, p.dO + b * p.o_bs + h * p.o_hs, p.o_rs, qrow, p.sq, lane);
+  float sc = p.scale;
+  if (p.scale_q_bf16) {
+    scale_frags_bf16(qf, p.scale);
+    sc = 1.0f;
+  }
+  const bool qok = qrow < p.sq;
+  const float lse = qok ? p.lse[(long long)bh * p.sq + qrow] : INFINITY;
+  const float dl = qok ? p.delta[(long long)bh * p.sq + qrow] : 0.f;
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  if (q0 >= p.sq) return;
+  const int my_last = last_visible_key(p, qrow);
+  const int nt = last_visible_key(p, min(p.sq - 1, q0 + 31)) / 32 + 1;
+  const int wave_first_last = last_visible_key(p, q0);
+  const float c2 = sc * 1.4426950408889634f, lse2 = lse * 1.4426950408889634f;
+  f32x16 dqacc[NDT];
+#pragma unroll
+  for (int d = 0; d < NDT; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dqacc[d][e] = 0.f;
+  for (int kt = 0; kt < nt; ++kt) {
+    f32x16 s, dp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_c<ROWB>(kl, kt, st, lane, p.sk - 1), qf[st], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_c<192>(vl, kt, st, lane, p.sk - 1), dof[st], dp, 0, 0, 0);
+    }
+    if (kt * 32 + 31 <= wave_first_last && !p.drop_thr) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[e] = exp2f(s[e] * c2 - lse2) * (dp[e] - dl);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = kt * 32 + acc_row(e, lane);
+        const float pr = key <= my_last ? exp2f(s[e] * c2 - lse2) : 0.f;
+        float dpe = dp[e];
+        if (p.drop_thr) {
+          const uint64_t idx = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qrow) * (uint64_t)p.sk + (uint64_t)key;
+          dpe = mpv_keep(p.seed, idx, p.drop_thr) ? dpe * p.drop_scale : 0.f;
+        }
+        s[e] = key <= my_last ? pr * (dpe - dl) : 0.f;
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 dsf = acc_to_frag(s, ks);
+#pragma unroll
+      for (int d = 0; d < NDT; ++d)
+        dqacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_c<ROWB>(kl, kt, ks, d, lane, p.sk - 1), dsf, dqacc[d], 0, 0, 0);
+    }
+  }
+  if (qok) {
+    bf16* row = p.dq + b * p.q_bs + h * p.q_hs + (long long)qrow * p.q_rs;
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int col = d * 32 + 8 * q4 + 4 * (lane >> 5);
+        if (col < HD) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = dqacc[d][4 * q4 + e] * p.scale;
+          *(bf16x4*)(row + col) = cvt4(v);
+        }
+      }
+  }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_res_kernel(const AttnArgs p) {
+  constexpr int NS = HD / 16;
+  constexpr int NDT = (HD + 31) / 32;
+  extern __shared__ __attribute__((aligned(1024))) char rsm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
+  int b, h;
+  if (!decode_bh(p, b, h)) return;
+  const int bh = b * p.heads + h;
+  const int qtiles = (p.sq + 31) / 32, qrows = qtiles * 32;
+  // LDS order matters: tile over-reads of dO land in Q (finite), over-reads of Q run past the allocation
+  // (hardware returns 0 for out-of-range LDS reads); the fp32 stats sit in front so no bf16 fragment read
+  // can ever interpret them as (possibly Inf/NaN) bf16.
+  float* sl = (float*)rsm;                                                  // [lse*log2e | delta] x qrows
+  char* dl = rsm + ((2 * qrows * 4 + 1023) / 1024) * 1024;                  // dO [sq][192 B] (its b128 reads are 4-way conflicted: accepted)
+  char* ql = dl + (((long long)p.sq * 192 + 1023) / 1024) * 1024;           // Q  [sq][208 B]
+  const __amdgpu_buffer_rsrc_t qsrc = make_rsrc(p.q + b * p.q_bs + h * p.q_hs, (uint32_t)(((long long)(p.sq - 1) * p.q_rs + HD) * 2));
+  const __amdgpu_buffer_rsrc_t dosrc = make_rsrc(p.dO + b * p.o_bs + h * p.o_hs, (uint32_t)(((long long)(p.sq - 1) * p.o_rs + HD) * 2));
+  dma_rows<HD, ROWB>(qsrc, ql, p.sq, p.q_rs, wave, nwaves, lane);
+  dma_rows<HD, 192>(dosrc, dl, p.sq, p.o_rs, wave, nwaves, lane);
+  for (int r = tid; r < qrows; r += blockDim.x) {   // lse pre-multiplied by log2(e): probabilities are 2^(s*c2 - lse2)
+    sl[r] = r < p.sq ? p.lse[(long long)bh * p.sq + r] * 1.4426950408889634f : 1e30f;
+    sl[qrows + r] = r < p.sq ? p.delta[(long long)bh * p.sq + r] : 0.f;
+  }
+  const int k0 = (blockIdx.x * nwaves + wave) * 32;
+  const int krow = k0 + (lane & 31);
+  bf16x8 kf[NS], vf[NS];
+  load_row_frags<HD>(kf, p.k + b * p.k_bs + h * p.k_hs, p.k_rs, krow, p.sk, lane);
+  load_row_frags<HD>(vf, p.v + b * p.v_bs + h * p.v_hs, p.v_rs, krow, p.sk, lane);
+  const float sc = p.scale_q_bf16 ? 1.0f : p.scale;
+  const float c2 = sc * 1.4426950408889634f;
+  const bool kok = krow < p.sk;
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  if (p.scale_q_bf16) {   // q' = bf16(q * scale) in place, once
+    for (int g = tid; g < p.sq * (HD / 8); g += blockDim.x) {
+      const int row = g / (HD / 8), cc = g - row * (HD / 8);
+      bf16x8* ptr = (bf16x8*)(ql + row * ROWB + cc * 16);
+      f32x8 f = cvt8(*ptr);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] *= p.scale;
+      *ptr = cvt8(f);
+    }
+    __syncthreads();
+  }
+  if (k0 >= p.sk) return;
+  const int first_q = p.causal ? max(0, k0 - (p.sk - p.sq)) : 0;
+  f32x16 dkacc[NDT], dvacc[NDT];
+#pragma unroll
+  for (int d = 0; d < NDT; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dkacc[d][e] = dvacc[d][e] = 0.f;
+  for (int qt = first_q / 32; qt < qtiles; ++qt) {
+    f32x16 s, dp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_c<ROWB>(ql, qt, st, lane, p.sq - 1), kf[st], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_c<192>(dl, qt, st, lane, p.sq - 1), vf[st], dp, 0, 0, 0);
+    }
+    f32x16 pd;
+    // a q-tile is "interior" for this wave when every (q,key) pair is visible and in range
+    const bool interior = !p.drop_thr && (k0 + 31 < p.sk) && (qt * 32 + 31 < p.sq) &&
+                          (!p.causal || (k0 + 31 <= qt * 32 + (p.sk - p.sq)));
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int qb4 = qt * 32 + 8 * q4 + 4 * (lane >> 5);
+      const f32x4 l4 = *(const f32x4*)(sl + qb4), d4 = *(const f32x4*)(sl + qrows + qb4);
+      if (interior) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int e = 4 * q4 + j;
+          const float pr = exp2f(s[e] * c2 - l4[j]);
+          pd[e] = pr;
+          s[e] = pr * (dp[e] - d4[j]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int e = 4 * q4 + j;
+          const int qr = qb4 + j;
+          const int lastk = p.causal ? qr + (p.sk - p.sq) : p.sk - 1;
+          const bool vis = kok && krow <= lastk && qr < p.sq;
+          const float pr = vis ? exp2f(s[e] * c2 - l4[j]) : 0.f;
+          float keep = 1.0f;
+          if (p.drop_thr) {
+            const uint64_t idx = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qr) * (uint64_t)p.sk + (uint64_t)krow;
+            keep = mpv_keep(p.seed, idx, p.drop_thr) ? p.drop_scale : 0.f;
+          }
+          pd[e] = vis ? pr * keep : 0.f;
+          s[e] = vis ? pr * (dp[e] * keep - d4[j]) : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 pf = acc_to_frag(pd, ks);
+      const bf16x8 dsf = acc_to_frag(s, ks);
+#pragma unroll
+      for (int d = 0; d < NDT; ++d) {
+        dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_c<192>(dl, qt, ks, d, lane, p.sq - 1), pf, dvacc[d], 0, 0, 0);
+        dkacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_c<ROWB>(ql, qt, ks, d, lane, p.sq - 1), dsf, dkacc[d], 0, 0, 0);
+      }
+    }
+  }
+  if (kok) {
+    bf16* dkrow = p.dk + b * p.k_bs + h * p.k_hs + (long long)krow * p.k_rs;
+    bf16* dvrow = p.dv + b * p.v_bs + h * p.v_hs + (long long)krow * p.v_rs;
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int col = d * 32 + 8 * q4 + 4 * (lane >> 5);
+        if (col < HD) {
+          f32x4 a, c2;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            a[e] = dkacc[d][4 * q4 + e] * sc;
+            c2[e] = dvacc[d][4 * q4 + e];
+          }
+          *(bf16x4*)(dkrow + col) = cvt4(a);
+          *(bf16x4*)(dvrow + col) = cvt4(c2);
+        }
+      }
+  }
+}
+
 // =========================================================================== temporal attention (VALU)
 struct TempArgs {
   const bf16* qkv;
@@ -686,6 +1089,7 @@ int fill_args(AttnArgs& a, const mpv_attn_desc* d) {
   a.k_bs = d->k_bs; a.k_hs = d->k_hs; a.k_rs = d->k_rs;
   a.v_bs = d->v_bs; a.v_hs = d->v_hs; a.v_rs = d->v_rs;
   a.o_bs = d->o_bs; a.o_hs = d->o_hs; a.o_rs = d->o_rs;
+  a.batch = d->batch;
   a.heads = d->heads;
   a.sq = d->sq;
   a.sk = d->sk;
@@ -717,11 +1121,43 @@ int check_desc(const mpv_attn_desc* d, const char* who) {
 
 }  // namespace
 
+constexpr int RES_MAX_ROWS = 256;
+static size_t res_region(int rows, int pitch) { return ((size_t)rows * pitch + 1023) / 1024 * 1024; }
+static size_t res_lds_bytes(int rows, bool stats) {
+  const int padded = (rows + 31) / 32 * 32;
+  return res_region(rows, 192) + res_region(rows, ROWB) + (stats ? (2 * (size_t)padded * sizeof(float) + 1023) / 1024 * 1024 : 0);
+}
+template <typename K>
+static void allow_lds(K kernel) {
+  (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+}
+static void res_attr_once() {
+  static bool done = false;
+  if (done) return;
+  allow_lds(attn_fwd_res_kernel<64>); allow_lds(attn_fwd_res_kernel<80>); allow_lds(attn_fwd_res_kernel<96>);
+  allow_lds(attn_bwd_dq_res_kernel<64>); allow_lds(attn_bwd_dq_res_kernel<80>); allow_lds(attn_bwd_dq_res_kernel<96>);
+  allow_lds(attn_bwd_dkv_res_kernel<64>); allow_lds(attn_bwd_dkv_res_kernel<80>); allow_lds(attn_bwd_dkv_res_kernel<96>);
+  done = true;
+}
+
 extern "C" int mpv_attn_fwd(const mpv_attn_desc* d, hipStream_t stream) {
   int rc = check_desc(d, "mpv_attn_fwd");
   if (rc) return rc;
   AttnArgs a = {};
   fill_args(a, d);
+  if (d->sk <= RES_MAX_ROWS) {
+    res_attr_once();
+    const int nw = waves_for(d->sq);
+    const int gy = (d->batch + 7) / 8 * 8 * d->heads;   // decode_bh() needs whole groups of 8 sequences
+    dim3 grid((d->sq + 32 * nw - 1) / (32 * nw), gy), block(64 * nw);
+    const size_t lds = res_lds_bytes(d->sk, false);
+    switch (d->head_dim) {
+      case 64: hipLaunchKernelGGL((attn_fwd_res_kernel<64>), grid, block, lds, stream, a); break;
+      case 80: hipLaunchKernelGGL((attn_fwd_res_kernel<80>), grid, block, lds, stream, a); break;
+      default: hipLaunchKernelGGL((attn_fwd_res_kernel<96>), grid, block, lds, stream, a); break;
+    }
+    return mpv_check_launch("mpv_attn_fwd");
+  }
   const int nw = waves_for(d->sq);
   dim3 grid((d->sq + 32 * nw - 1) / (32 * nw), d->batch * d->heads), block(64 * nw);
   switch (d->head_dim) {
@@ -746,6 +1182,28 @@ extern "C" int mpv_attn_bwd(const mpv_attn_desc* d, const void* dO, void* dq, vo
   a.delta = delta;
   dim3 block(256);
   hipLaunchKernelGGL(attn_delta_kernel, dim3((d->sq + 3) / 4, d->batch * d->heads), block, 0, stream, a, d->head_dim);
+  if (d->sk <= RES_MAX_ROWS && d->sq <= RES_MAX_ROWS) {
+    res_attr_once();
+    const int nw = waves_for(d->sq);
+    const int gy = (d->batch + 7) / 8 * 8 * d->heads;
+    dim3 gq((d->sq + 32 * nw - 1) / (32 * nw), gy), gk((d->sk + 127) / 128, gy);
+    const size_t lq = res_lds_bytes(d->sk, false), lk = res_lds_bytes(d->sq, true);
+    switch (d->head_dim) {
+      case 64:
+        hipLaunchKernelGGL((attn_bwd_dq_res_kernel<64>), gq, dim3(64 * nw), lq, stream, a);
+        hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<64>), gk, dim3(256), lk, stream, a);
+        break;
+      case 80:
+        hipLaunchKernelGGL((attn_bwd_dq_res_kernel<80>), gq, dim3(64 * nw), lq, stream, a);
+        hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<80>), gk, dim3(256), lk, stream, a);
+        break;
+      default:
+        hipLaunchKernelGGL((attn_bwd_dq_res_kernel<96>), gq, dim3(64 * nw), lq, stream, a);
+        hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<96>), gk, dim3(256), lk, stream, a);
+        break;
+    }
+    return mpv_check_launch("mpv_attn_bwd");
+  }
   const int nwq = waves_for(d->sq), nwk = 4;   // dK/dV keeps 4 waves (its accumulators need > 256 VGPRs at 8)
   dim3 gq((d->sq + 32 * nwq - 1) / (32 * nwq), d->batch * d->heads), gk((d->sk + 32 * nwk - 1) / (32 * nwk), d->batch * d->heads);
   dim3 bq(64 * nwq), bk(64 * nwk);
