@@ -181,6 +181,21 @@ int mpv_cross_entropy(const void* logits, const int64_t* labels, const float* we
                       void* dlogits, int64_t rows, int64_t vocab, int64_t ld, mpv_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * ITC retrieval head (models/distributed_gpt3.py:938-980).
+ * F.normalize(dim=-1) forward/backward (:947,960); norm is fp32 [rows] (saved for backward). */
+int mpv_l2norm_fwd(const void* x, void* y, float* norm, int64_t rows, int64_t cols, float eps, mpv_stream_t stream);
+int mpv_l2norm_bwd(const void* dy, const void* x, const float* norm, void* dx, int64_t rows, int64_t cols,
+                   mpv_stream_t stream);
+/* dst[r] = src[idx[r]] (last-valid-token pooling of the text hidden state, :958-959) */
+int mpv_gather_rows(const void* src, const int64_t* idx, void* dst, int64_t rows, int64_t cols, int64_t ld,
+                    mpv_stream_t stream);
+/* Soft-target contrastive cross-entropy over fp32 similarities sim[rows][cols] (:966-978):
+ * targets[i][j] = [row_ids[i]==col_ids[j]] / count_i; losses[i] = -sum_j log_softmax(sim_i)[j] targets[i][j];
+ * dsim (bf16, optional) = (softmax - targets) * scale; dts[i] (optional) = sum_j dsim[i][j] * sim[i][j]. */
+int mpv_soft_target_ce(const float* sim, const int64_t* row_ids, const int64_t* col_ids, float scale, float* losses,
+                       void* dsim, float* dts, int64_t rows, int64_t cols, mpv_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Optimizer (DeepSpeed FusedAdam + global-norm clip, run_pretrain_distributed_gpt3.py:137;
  * math of optim/adamw.py:66-115; torch.nn.utils.clip_grad_norm_ semantics, utils.py:308).
  * sumsq (fp32 scalar, pre-zeroed) += sum g^2 over n bf16 gradients. */

@@ -70,6 +70,36 @@ def run_case(name: str):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def run_retrieval(name: str = "retrieval_tiny"):
+    """DistributedGPT3_Retrieval (ITC, BASELINE.json configs[4] shape-reduced): B=8, L=10 ragged, duplicate ids."""
+    import types
+    from .ref_loader import build_reference_retrieval, single_rank_collectives
+    cfg = CONFIG_TINY
+    rec = {"meta": dict(case=name, batch=8, text_len=10, weight_seed=2, input_seed=5, ragged=True, idx=[3, 1, 4, 1, 5, 9, 2, 6],
+                        torch=str(torch.__version__))}
+    for tag, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        model, sd = build_reference_retrieval(cfg, 2, dtype=dtype)
+        video, ids, mask = make_inputs(cfg, 8, 10, seed=5, ragged=True)
+        idx = torch.tensor(rec["meta"]["idx"])
+        model.eval()
+        with single_rank_collectives():
+            loss = model(video.to(dtype), types.SimpleNamespace(input_ids=ids, attention_mask=mask), idx)
+            loss.backward()
+        r = {"loss": loss.detach().float().clone(), "grad_norm": {}, "grad_sample": {}}
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                r["grad_norm"][n] = float(p.grad.float().norm())
+                r["grad_sample"][n] = grad_sample(p.grad)
+        rec[tag] = r
+        print(f"[{name}/{tag}] loss={float(loss):.6f}", flush=True)
+    path = os.path.join(GOLDEN_DIR, f"{name}.pt")
+    torch.save(rec, path)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     for c in (sys.argv[1:] or ["tiny"]):
-        run_case(c)
+        if c.startswith("retrieval"):
+            run_retrieval(c)
+        else:
+            run_case(c)

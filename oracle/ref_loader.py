@@ -135,3 +135,47 @@ def reference_forward(model, video, ids, mask, train: bool = False):
     finally:
         td.forward = orig_forward
     return loss, captured["out"], captured["input_embeds"]
+
+
+def build_reference_retrieval(cfg: PathConfig, seed: int = 0, dtype=torch.float32, embed_dim: int = 256):
+    """DistributedGPT3_Retrieval (models/distributed_gpt3.py:817-985) on CPU with seeded weights."""
+    from .weights import retrieval_spec
+    vt, mg, dg = import_reference()
+    sd = make_state_dict(cfg, seed, spec_fn=lambda c: retrieval_spec(c, embed_dim))
+    tmp = tempfile.mkdtemp(prefix="mpv_oracle_")
+    for name, d in (("config.json", _gpt_config_dict(cfg)), ("visual.json", _visual_config_dict(cfg)), ("text.json", _gpt_config_dict(cfg))):
+        with open(os.path.join(tmp, name), "w") as f:
+            json.dump(d, f)
+    config = {"visual_cfg": os.path.join(tmp, "visual.json"), "text_cfg": os.path.join(tmp, "text.json"), "text_decoder": tmp,
+              "megatron_cfg": {"world_size": 1, "model_parallel_size": 1, "tensor_model_parallel_size": 1}, "freeze_vit": False,
+              "freeze_text_decoder": True, "num_learnable_token": cfg.num_queries, "num_frames": cfg.num_frames,
+              "contrastive_embed_dim": embed_dim, "temp": 0.07}
+    prefix = "text_decoder.dist_model."
+    gpt_sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    old = mg.pre_load
+    mg.pre_load = lambda *a, **k: gpt_sd
+    try:
+        with _cpu_patches():
+            model = dg.DistributedGPT3_Retrieval(config=config, tokenizer=None)
+    finally:
+        mg.pre_load = old
+    model.load_state_dict(sd, strict=True)
+    return model.to(dtype), sd
+
+
+@contextlib.contextmanager
+def single_rank_collectives():
+    """models/distributed_gpt3.py:962-964 call torch.distributed collectives unconditionally: run them on a
+    1-rank gloo group so the reference forward works in a plain process."""
+    import torch.distributed as dist
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        created = True
+    try:
+        yield
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -209,6 +209,28 @@ def pretrain_forward(video, ids, attn_mask, sd, cfg: PathConfig):
     return out
 
 
+def retrieval_forward(video, ids, attn_mask, idx, sd, cfg: PathConfig):
+    """models/distributed_gpt3.py:938-980 at world size 1 (all_gather of one rank is the identity)."""
+    B = video.shape[0]
+    image_embeds = timesformer(video, sd, cfg)
+    image_query = image_embeds[:, 0]                                                              # :939 pooled cls
+    vision_feats = F.normalize(F.linear(image_query, sd["vision_proj.weight"], sd["vision_proj.bias"]), dim=-1)   # :947
+    emb = F.embedding(ids, sd["text_decoder.dist_model.language_model.embedding.word_embeddings.weight"])
+    targets = torch.cat([ids[:, 1:], ids[:, 1:2]], dim=1)                                        # :949-950
+    out = gpt_forward(emb, targets, attn_mask[:, 1:], sd, cfg)                                    # :952-956
+    hid = out["last_hidden_state"]
+    pooled = hid[torch.arange(B), attn_mask.sum(dim=-1) - 1]                                      # :958-959
+    text_feat = F.normalize(F.linear(pooled, sd["text_proj.weight"], sd["text_proj.bias"]), dim=-1)        # :960
+    sim_i2t = vision_feats @ text_feat.t() / sd["temp"]                                           # :966
+    sim_t2i = text_feat @ vision_feats.t() / sd["temp"]                                           # :967
+    idx = idx.view(-1, 1)
+    pos = torch.eq(idx, idx.t()).float()
+    tg = pos / pos.sum(1, keepdim=True)                                                           # :970-972
+    loss_i2t = -torch.sum(F.log_softmax(sim_i2t.float(), dim=1) * tg, dim=1).mean()
+    loss_t2i = -torch.sum(F.log_softmax(sim_t2i.float(), dim=1) * tg, dim=1).mean()
+    return dict(loss=(loss_i2t + loss_t2i) / 2, vision_feats=vision_feats, text_feat=text_feat)
+
+
 # --------------------------------------------------------------------------- optimizer
 def adamw_step(p, g, m, v, step, lr, beta1, beta2, eps, wd):
     """optim/adamw.py:66-115 (decoupled decay first, then bias-corrected Adam); in place, fp32."""

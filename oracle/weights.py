@@ -122,11 +122,22 @@ def state_dict_spec(cfg: PathConfig):
     return s
 
 
-def make_state_dict(cfg: PathConfig, seed: int = 0, dtype=torch.float32) -> "OrderedDict[str, torch.Tensor]":
+def retrieval_spec(cfg: PathConfig, embed_dim: int = 256):
+    """DistributedGPT3_Retrieval.state_dict() = pre-train keys + ITC head (models/distributed_gpt3.py:904-907)."""
+    s = state_dict_spec(cfg)
+    s.append(("vision_proj.weight", (embed_dim, cfg.vit_dim), "w_vit"))
+    s.append(("vision_proj.bias", (embed_dim,), "bias"))
+    s.append(("text_proj.weight", (embed_dim, cfg.hidden), "w_proj"))
+    s.append(("text_proj.bias", (embed_dim,), "bias"))
+    s.append(("temp", (), "temp"))
+    return s
+
+
+def make_state_dict(cfg: PathConfig, seed: int = 0, dtype=torch.float32, spec_fn=state_dict_spec) -> "OrderedDict[str, torch.Tensor]":
     g = torch.Generator(device="cpu")
     g.manual_seed(seed)
     out = OrderedDict()
-    spec = sorted(state_dict_spec(cfg), key=lambda t: t[0])
+    spec = sorted(spec_fn(cfg), key=lambda t: t[0])
     for key, shape, kind in spec:
         r = torch.randn(shape, generator=g, dtype=torch.float32)
         if kind == "ln_w":
@@ -141,13 +152,17 @@ def make_state_dict(cfg: PathConfig, seed: int = 0, dtype=torch.float32) -> "Ord
             t = 0.02 * r
         elif kind == "w_gpt":
             t = 0.02 * r
+        elif kind == "w_proj":
+            t = 0.05 * r
+        elif kind == "temp":
+            t = torch.tensor(0.07)
         elif kind == "w_gpt_out":
             t = (0.02 / math.sqrt(2.0 * cfg.layers)) * r
         else:  # pragma: no cover
             raise KeyError(kind)
         out[key] = t.to(dtype)
     # keep original (reference) ordering for load_state_dict friendliness
-    ordered = OrderedDict((k, out[k]) for k, _, _ in state_dict_spec(cfg))
+    ordered = OrderedDict((k, out[k]) for k, _, _ in spec_fn(cfg))
     return ordered
 
 

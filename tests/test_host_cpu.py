@@ -189,3 +189,74 @@ def test_dp_gloo_world2_matches_single_process():
     ref = torch.cat([torch.nn.functional.pad(p.grad.reshape(-1), (0, (-p.numel()) % 256)) for p in
                      list(model[2].parameters()) + list(model[0].parameters())])
     assert torch.allclose(res[0], ref, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------ retrieval (ITC, config 5)
+def test_retrieval_restatement_matches_golden():
+    from oracle import restate
+    from oracle.weights import CONFIG_TINY, make_inputs, make_state_dict, retrieval_spec
+    g = torch.load(os.path.join(GOLD, "retrieval_tiny.pt"))
+    m = g["meta"]
+    sd = {k: v.requires_grad_(True) for k, v in make_state_dict(CONFIG_TINY, m["weight_seed"], spec_fn=retrieval_spec).items()}
+    video, ids, mask = make_inputs(CONFIG_TINY, m["batch"], m["text_len"], seed=m["input_seed"], ragged=m["ragged"])
+    r = restate.retrieval_forward(video, ids, mask, torch.tensor(m["idx"]), sd, CONFIG_TINY)
+    assert abs(r["loss"].item() - g["fp32"]["loss"].item()) < 1e-5
+    r["loss"].backward()
+    for n, gn in g["fp32"]["grad_norm"].items():
+        assert abs(sd[n].grad.norm().item() - gn) <= 1e-4 * gn + 1e-9, n
+
+
+def test_retrieval_state_dict_layout():
+    from oracle.weights import CONFIG_TINY, retrieval_spec
+    from youku_mplug_amd.retrieval import synthetic_retrieval_model
+    model = synthetic_retrieval_model(CONFIG_TINY, device="cpu")
+    spec = {k: tuple(s) for k, s, _ in retrieval_spec(CONFIG_TINY)}
+    sd = model.state_dict()
+    assert set(sd) == set(spec)
+    for k, s in spec.items():
+        assert tuple(sd[k].shape) == s, k
+    unused = {id(p) for p in model.unused_parameters()}
+    assert id(model.learnable_queries) in unused and id(model.vision_proj.weight) not in unused
+
+
+def _itc_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    import youku_mplug_amd  # noqa: F401
+    from youku_mplug_amd.retrieval import gather_cat, reduce_scatter_sum
+    g = torch.Generator().manual_seed(7)
+    feats = torch.randn(world * 4, 8, generator=g)
+    mine = feats[rank * 4:(rank + 1) * 4].clone()
+    allf = gather_cat(mine)
+    ids = gather_cat(torch.arange(4) + 4 * rank)
+    # every rank forms d(all) = W_r * all ; the true d(mine) is the sum over ranks of their slice for `rank`
+    w_r = torch.randn(world * 4, 8, generator=torch.Generator().manual_seed(100 + rank))
+    d_mine = reduce_scatter_sum(w_r * allf)
+    q.put((rank, allf.clone(), ids.clone(), d_mine.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_itc_collectives_gloo_world2():
+    """all-gather forward / reduce-scatter backward of the ITC features (models/distributed_utils.py:285-311)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_itc_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r: (a, i, d) for r, a, i, d in (q.get(timeout=120) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(7)
+    feats = torch.randn(8, 8, generator=g)
+    for r in (0, 1):
+        assert torch.equal(res[r][0], feats) and torch.equal(res[r][1], torch.arange(8))
+    w = [torch.randn(8, 8, generator=torch.Generator().manual_seed(100 + r)) for r in (0, 1)]
+    total = (w[0] + w[1]) * feats
+    for r in (0, 1):
+        assert torch.allclose(res[r][2], total[r * 4:(r + 1) * 4], atol=1e-6)

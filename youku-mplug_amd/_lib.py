@@ -70,6 +70,10 @@ _SIGS = {
     "mpv_gpt_embed_fwd": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_float, c_uint64, c_uint64, c_void_p]),
     "mpv_gpt_embed_bwd": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_float, c_uint64, c_uint64, c_void_p]),
     "mpv_cross_entropy": (c_int, [c_void_p] * 6 + [c_int64] * 3 + [c_void_p]),
+    "mpv_l2norm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p]),
+    "mpv_l2norm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "mpv_gather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "mpv_soft_target_ce": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "mpv_grad_sumsq": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "mpv_adamw_step": (c_int, [c_void_p] * 5 + [c_int64] + [c_float] * 5 + [c_int, c_float, c_void_p, c_float, c_void_p]),
     "mpv_adamw_step_grouped": (c_int, [c_void_p] * 5 + [c_int64, c_void_p, C.POINTER(c_float), C.POINTER(c_float), c_int,

@@ -303,6 +303,89 @@ __global__ __launch_bounds__(256) void weighted_sum_kernel(const float* __restri
   if (threadIdx.x == 0) *out = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// ---------------------------------------------------------------- ITC head (retrieval)
+// F.normalize(x, dim=-1): y = x / max(||x||_2, eps); one wave per row, cols <= 2048
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, float* __restrict__ nrm,
+                                                         long long rows, int cols, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float ss = 0.f;
+  for (int c = lane * 4; c < cols; c += 256) {
+    const f32x4 v = cvt4(*(const bf16x4*)(x + r * cols + c));
+    ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  const float n = fmaxf(sqrtf(wave_sum(ss)), eps);
+  const float inv = 1.0f / n;
+  for (int c = lane * 4; c < cols; c += 256) *(bf16x4*)(y + r * cols + c) = cvt4(cvt4(*(const bf16x4*)(x + r * cols + c)) * inv);
+  if (lane == 0) nrm[r] = n;
+}
+// dx = (dy - y * <y, dy>) / n   (y = x / n recomputed in fp32)
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+                                                         const float* __restrict__ nrm, bf16* __restrict__ dx, long long rows,
+                                                         int cols) {
+  const int lane = threadIdx.x & 63;
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float inv = 1.0f / nrm[r];
+  float dot = 0.f;
+  for (int c = lane * 4; c < cols; c += 256) {
+    const f32x4 xv = cvt4(*(const bf16x4*)(x + r * cols + c)) * inv, dv = cvt4(*(const bf16x4*)(dy + r * cols + c));
+    dot += xv[0] * dv[0] + xv[1] * dv[1] + xv[2] * dv[2] + xv[3] * dv[3];
+  }
+  dot = wave_sum(dot);
+  for (int c = lane * 4; c < cols; c += 256) {
+    const f32x4 xv = cvt4(*(const bf16x4*)(x + r * cols + c)) * inv, dv = cvt4(*(const bf16x4*)(dy + r * cols + c));
+    *(bf16x4*)(dx + r * cols + c) = cvt4((dv - xv * dot) * inv);
+  }
+}
+__global__ void gather_rows_kernel(const bf16* __restrict__ src, const int64_t* __restrict__ idx, bf16* __restrict__ dst,
+                                   long long rows, int cols, long long ld) {
+  const int C4 = cols / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < rows * C4; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / C4;
+    const int c4 = (int)(i - r * C4);
+    *(bf16x4*)(dst + r * cols + c4 * 4) = *(const bf16x4*)(src + idx[r] * ld + c4 * 4);
+  }
+}
+// Soft-target contrastive CE (models/distributed_gpt3.py:966-978): targets[i][j] = [ids_r[i]==ids_c[j]] / count_i;
+// loss_i = -sum_j log_softmax(sim_i)[j] * targets[i][j];  dsim = (softmax - targets) * scale (bf16);
+// dts[i] = sum_j dsim[i][j] * sim[i][j] (for the temperature gradient).  One wave per row.
+__global__ __launch_bounds__(256) void soft_ce_kernel(const float* __restrict__ sim, const int64_t* __restrict__ ids_r,
+                                                      const int64_t* __restrict__ ids_c, float scale, float* __restrict__ losses,
+                                                      bf16* __restrict__ dsim, float* __restrict__ dts, int rows, int cols) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* row = sim + (long long)r * cols;
+  const int64_t me = ids_r[r];
+  float mx = -INFINITY, cnt = 0.f;
+  for (int c = lane; c < cols; c += 64) {
+    mx = fmaxf(mx, row[c]);
+    cnt += ids_c[c] == me ? 1.f : 0.f;
+  }
+  mx = wave_max(mx);
+  cnt = wave_sum(cnt);
+  float se = 0.f;
+  for (int c = lane; c < cols; c += 64) se += __expf(row[c] - mx);
+  se = wave_sum(se);
+  const float lse = mx + __logf(se), invc = 1.0f / cnt;
+  float loss = 0.f, dt = 0.f;
+  for (int c = lane; c < cols; c += 64) {
+    const float t = ids_c[c] == me ? invc : 0.f;
+    const float g = (__expf(row[c] - lse) - t) * scale;
+    loss -= (row[c] - lse) * t;
+    dt += g * row[c];
+    if (dsim) dsim[(long long)r * cols + c] = f2bf(g);
+  }
+  loss = wave_sum(loss);
+  dt = wave_sum(dt);
+  if (lane == 0) {
+    losses[r] = loss;
+    if (dts) dts[r] = dt;
+  }
+}
+
 inline int ew_grid(long long work_items, int threads = 256) {
   long long b = (work_items + threads - 1) / threads;
   return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
@@ -434,4 +517,39 @@ extern "C" int mpv_cross_entropy(const void* logits, const int64_t* labels, cons
   if (loss_sum)
     hipLaunchKernelGGL(weighted_sum_kernel, dim3(1), dim3(256), 0, stream, (const float*)losses, weight, loss_sum, (long long)rows);
   return mpv_check_launch("mpv_cross_entropy");
+}
+
+extern "C" int mpv_l2norm_fwd(const void* x, void* y, float* norm, int64_t rows, int64_t cols, float eps, hipStream_t stream) {
+  MPV_REQUIRE(x && y && norm, MPV_E_ARG, "mpv_l2norm_fwd: null pointer");
+  MPV_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0, MPV_E_SHAPE, "mpv_l2norm_fwd: cols must be a multiple of 4");
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, norm,
+                     (long long)rows, (int)cols, eps);
+  return mpv_check_launch("mpv_l2norm_fwd");
+}
+
+extern "C" int mpv_l2norm_bwd(const void* dy, const void* x, const float* norm, void* dx, int64_t rows, int64_t cols,
+                              hipStream_t stream) {
+  MPV_REQUIRE(dy && x && norm && dx, MPV_E_ARG, "mpv_l2norm_bwd: null pointer");
+  MPV_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0, MPV_E_SHAPE, "mpv_l2norm_bwd: cols must be a multiple of 4");
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)x, norm,
+                     (bf16*)dx, (long long)rows, (int)cols);
+  return mpv_check_launch("mpv_l2norm_bwd");
+}
+
+extern "C" int mpv_gather_rows(const void* src, const int64_t* idx, void* dst, int64_t rows, int64_t cols, int64_t ld,
+                               hipStream_t stream) {
+  MPV_REQUIRE(src && idx && dst, MPV_E_ARG, "mpv_gather_rows: null pointer");
+  MPV_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && ld % 4 == 0, MPV_E_SHAPE, "mpv_gather_rows: bad shape");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(ew_grid(rows * (cols / 4))), dim3(256), 0, stream, (const bf16*)src, idx, (bf16*)dst,
+                     (long long)rows, (int)cols, (long long)ld);
+  return mpv_check_launch("mpv_gather_rows");
+}
+
+extern "C" int mpv_soft_target_ce(const float* sim, const int64_t* row_ids, const int64_t* col_ids, float scale, float* losses,
+                                  void* dsim, float* dts, int64_t rows, int64_t cols, hipStream_t stream) {
+  MPV_REQUIRE(sim && row_ids && col_ids && losses, MPV_E_ARG, "mpv_soft_target_ce: null pointer");
+  MPV_REQUIRE(rows > 0 && cols > 0, MPV_E_SHAPE, "mpv_soft_target_ce: empty problem");
+  hipLaunchKernelGGL(soft_ce_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, sim, row_ids, col_ids, scale, losses,
+                     (bf16*)dsim, dts, (int)rows, (int)cols);
+  return mpv_check_launch("mpv_soft_target_ce");
 }

@@ -189,6 +189,9 @@ class MplugEngine(nn.Module):
         super().__init__()
         self.module = model
         group_of = {id(p): gi for gi, g in enumerate(param_groups) for p in g["params"]}
+        if hasattr(model, "unused_parameters"):          # never receive gradients: skip them (tile group 255), as an
+            for p in model.unused_parameters():          # optimizer over .grad=None parameters would
+                group_of[id(p)] = 255
         stages = default_stages(model)
         stages = [(n, [p for p in ps if id(p) in group_of]) for n, ps in stages]
         stages = [s for s in stages if s[1]]

@@ -169,8 +169,8 @@ class DistributedGPT3(nn.Module):
         self.step_seed = 0        # bumped by the engine every step -> fresh dropout masks
 
     # -------------------------------------------------------------- explicit forward / backward
-    def forward_lm(self, query_features: Optional[torch.Tensor], ids: torch.Tensor, labels: torch.Tensor,
-                   loss_mask: torch.Tensor, tape: dict, want_logits: bool = False):
+    def forward_lm(self, query_features: Optional[torch.Tensor], ids: torch.Tensor, labels: Optional[torch.Tensor],
+                   loss_mask: Optional[torch.Tensor], tape: dict, want_logits: bool = False, hidden_only: bool = False):
         """query_features [B*Q, H] (or None), ids [B,L] int64, labels [B,S] int64, loss_mask [B,S-1].
         Returns dict(loss fp32 scalar, losses [B,S-1] fp32, logits?, last_hidden_state [B,S,H])."""
         cfg = self.config
@@ -211,6 +211,8 @@ class DistributedGPT3(nn.Module):
             h = h2
         fl = lm.encoder.final_layernorm
         xf, mf, rf = ops.layernorm_fwd(h, fl.weight, fl.bias, fl.eps, R, H)
+        if hidden_only:     # retrieval text tower: only last_hidden_state is consumed (models/distributed_gpt3.py:958)
+            return dict(last_hidden_state=xf.view(B, S, H))
         logits = ops.gemm(xf, lm.embedding.word_embeddings.weight, R, V, H)          # tied LM head (:1348-1350)
         # masked mean of per-token CE over positions 0..S-2 (:1615-1617)
         lmf = loss_mask.to(torch.float32)

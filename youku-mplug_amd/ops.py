@@ -271,3 +271,31 @@ def adamw_step_grouped(p16, master, m, v, g16, tile_group, lrs, wds, beta1, beta
     check(_lib.lib().mpv_adamw_step_grouped(p16.data_ptr(), master.data_ptr(), m.data_ptr(), v.data_ptr(), g16.data_ptr(),
                                             p16.numel(), tile_group.data_ptr(), arr(*lrs), arr(*wds), n, beta1, beta2, eps, step,
                                             grad_scale, _p(sumsq), max_norm, _stream()), "mpv_adamw_step_grouped")
+
+
+def l2norm_fwd(x, rows, cols, eps=1e-12):
+    y = torch.empty((rows, cols), dtype=torch.bfloat16, device=x.device)
+    nrm = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(_lib.lib().mpv_l2norm_fwd(x.data_ptr(), y.data_ptr(), nrm.data_ptr(), rows, cols, eps, _stream()), "mpv_l2norm_fwd")
+    return y, nrm
+
+
+def l2norm_bwd(dy, x, nrm, rows, cols):
+    dx = torch.empty((rows, cols), dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().mpv_l2norm_bwd(dy.data_ptr(), x.data_ptr(), nrm.data_ptr(), dx.data_ptr(), rows, cols, _stream()), "mpv_l2norm_bwd")
+    return dx
+
+
+def gather_rows(src, idx, rows, cols, ld=None):
+    dst = torch.empty((rows, cols), dtype=torch.bfloat16, device=src.device)
+    check(_lib.lib().mpv_gather_rows(src.data_ptr(), idx.data_ptr(), dst.data_ptr(), rows, cols, ld or cols, _stream()), "mpv_gather_rows")
+    return dst
+
+
+def soft_target_ce(sim, row_ids, col_ids, scale, rows, cols, want_grad=True):
+    losses = torch.empty(rows, dtype=torch.float32, device=sim.device)
+    dsim = torch.empty((rows, cols), dtype=torch.bfloat16, device=sim.device) if want_grad else None
+    dts = torch.empty(rows, dtype=torch.float32, device=sim.device) if want_grad else None
+    check(_lib.lib().mpv_soft_target_ce(sim.data_ptr(), row_ids.data_ptr(), col_ids.data_ptr(), scale, losses.data_ptr(), _p(dsim),
+                                        _p(dts), rows, cols, _stream()), "mpv_soft_target_ce")
+    return losses, dsim, dts
