@@ -976,7 +976,7 @@ struct TempArgs {
 
 // one wave per (sequence, head); T <= 16, hd <= 96.  LDS floats per wave: 3*T*(hd+1) + T*(T+1) (+ bwd extras)
 template <bool BWD>
-__global__ __launch_bounds__(256) void temporal_attn_kernel(const TempArgs p) {
+__global__ __launch_bounds__(512) void temporal_attn_kernel(const TempArgs p) {
   extern __shared__ __attribute__((aligned(16))) float tsm[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int T = p.T, hd = p.hd, ld = hd + 1, D = p.heads * hd;
@@ -988,7 +988,8 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TempArgs p) {
   float* dos = ps + T * (T + 1);        // BWD: dO [T][ld]
   float* dss = dos + T * ld;            // BWD: dS [T][T+1]
   const long long nprob = (long long)p.n_outer * p.n_inner * p.heads;
-  for (long long pr = (long long)blockIdx.x * 4 + wave; pr < nprob; pr += (long long)gridDim.x * 4) {
+  const int nwv = blockDim.x >> 6;   // = heads when heads <= 8: one workgroup reads whole qkv rows of a sequence
+  for (long long pr = (long long)blockIdx.x * nwv + wave; pr < nprob; pr += (long long)gridDim.x * nwv) {
     const int h = (int)(pr % p.heads);
     const long long seq = pr / p.heads;
     const long long o = seq / p.n_inner, i = seq % p.n_inner;
@@ -1251,10 +1252,17 @@ extern "C" int mpv_temporal_attn_fwd(const void* qkv, void* out, int n_outer, in
   if (rc) return rc;
   t.qkv = (const bf16*)qkv;
   t.out = (bf16*)out;
-  const size_t lds = 4 * sizeof(float) * (size_t)(3 * T * (head_dim + 1) + T * (T + 1));
+  const int nwv = 4;
+  const size_t lds = nwv * sizeof(float) * (size_t)(3 * T * (head_dim + 1) + T * (T + 1));
   const long long nprob = (long long)n_outer * n_inner * heads;
-  const int grid = (int)((nprob + 3) / 4 < 8192 ? (nprob + 3) / 4 : 8192);
-  hipLaunchKernelGGL((temporal_attn_kernel<false>), dim3(grid), dim3(256), lds, stream, t);
+  const int grid = (int)((nprob + nwv - 1) / nwv < 16384 ? (nprob + nwv - 1) / nwv : 16384);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)temporal_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)temporal_attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL((temporal_attn_kernel<false>), dim3(grid), dim3(64 * nwv), lds, stream, t);
   return mpv_check_launch("mpv_temporal_attn_fwd");
 }
 
@@ -1269,9 +1277,16 @@ extern "C" int mpv_temporal_attn_bwd(const void* qkv, const void* dout, void* dq
   t.qkv = (const bf16*)qkv;
   t.dout = (const bf16*)dout;
   t.dqkv = (bf16*)dqkv;
-  const size_t lds = 4 * sizeof(float) * (size_t)(4 * T * (head_dim + 1) + 2 * T * (T + 1));
+  const int nwv = 4;
+  const size_t lds = nwv * sizeof(float) * (size_t)(4 * T * (head_dim + 1) + 2 * T * (T + 1));
   const long long nprob = (long long)n_outer * n_inner * heads;
-  const int grid = (int)((nprob + 3) / 4 < 8192 ? (nprob + 3) / 4 : 8192);
-  hipLaunchKernelGGL((temporal_attn_kernel<true>), dim3(grid), dim3(256), lds, stream, t);
+  const int grid = (int)((nprob + nwv - 1) / nwv < 16384 ? (nprob + nwv - 1) / nwv : 16384);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)temporal_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)temporal_attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL((temporal_attn_kernel<true>), dim3(grid), dim3(64 * nwv), lds, stream, t);
   return mpv_check_launch("mpv_temporal_attn_bwd");
 }

@@ -243,19 +243,29 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
     if (kt + 1 < nk) issue(kbeg + (kt + 1) * BK, cur ^ 1);
     const char* pa = smem + cur * 2 * TILE_BYTES;
     const char* pb = pa + TILE_BYTES;
+    // software-pipelined fragment fetch: the ds_reads of k-sub s+1 are in flight under the MFMAs of k-sub s
+    bf16x8 fa[2][2], fb[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      fa[0][t] = frag(pa, TA, wrow * 64 + t * 32, 0);
+      fb[0][t] = frag(pb, TB, wcol * 64 + t * 32, 0);
+    }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      bf16x8 fa[2], fb[2];
+      if (s < 3) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        fa[t] = frag(pa, TA, wrow * 64 + t * 32, s);
-        fb[t] = frag(pb, TB, wcol * 64 + t * 32, s);
+        for (int t = 0; t < 2; ++t) {
+          fa[(s + 1) & 1][t] = frag(pa, TA, wrow * 64 + t * 32, s + 1);
+          fb[(s + 1) & 1][t] = frag(pb, TB, wcol * 64 + t * 32, s + 1);
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);   // keep the next k-sub's reads ahead of this k-sub's MFMAs
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[s & 1][j], fa[s & 1][i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (TA || TB) {
       if (kt + 1 < nk) commit(cur ^ 1);

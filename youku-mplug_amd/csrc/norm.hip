@@ -193,15 +193,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p) {
   }
 }
 
-// workgroup = 64 columns x 4 partial lanes (coalesced 256-byte rows of the partial table)
-__global__ __launch_bounds__(256) void ln_dparam_finalize(const float* __restrict__ part, int nblk, int cols, bf16* dgamma,
-                                                          bf16* dbeta, int accumulate) {
+// Two-level deterministic reduction of the per-workgroup partials [nblk][2][cols]:
+// level 1: grid (cols/64, nblk/64): each workgroup (64 columns x 4 lanes) folds 64 partial rows;
+// level 2 (final): grid (cols/64): folds the <= 32 level-1 rows and writes bf16 (optionally accumulating).
+__global__ __launch_bounds__(256) void ln_dparam_reduce(const float* __restrict__ part, int nblk, int cols, float* __restrict__ out1,
+                                                        bf16* dgamma, bf16* dbeta, int accumulate, int final_level) {
   __shared__ float red[2][4][64];
   const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
+  const int i0 = final_level ? 0 : blockIdx.y * 64, i1 = final_level ? nblk : min(nblk, i0 + 64);
   float a = 0.f, b = 0.f;
   if (c < cols)
-    for (int i = pl; i < nblk; i += 4) {
+    for (int i = i0 + pl; i < i1; i += 4) {
       a += part[(long long)i * 2 * cols + c];
       b += part[(long long)i * 2 * cols + cols + c];
     }
@@ -211,16 +214,22 @@ __global__ __launch_bounds__(256) void ln_dparam_finalize(const float* __restric
   if (pl == 0 && c < cols) {
     a = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
     b = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
-    if (accumulate) {
-      a += bf2f(dgamma[c]);
-      b += bf2f(dbeta[c]);
+    if (!final_level) {
+      out1[(long long)blockIdx.y * 2 * cols + c] = a;
+      out1[(long long)blockIdx.y * 2 * cols + cols + c] = b;
+    } else {
+      if (accumulate) {
+        a += bf2f(dgamma[c]);
+        b += bf2f(dbeta[c]);
+      }
+      dgamma[c] = f2bf(a);
+      dbeta[c] = f2bf(b);
     }
-    dgamma[c] = f2bf(a);
-    dbeta[c] = f2bf(b);
   }
 }
 
-constexpr int LN_BWD_MAX_BLOCKS = 512;
+constexpr int LN_BWD_MAX_BLOCKS = 2048;
+constexpr int LN_L1_ROWS = (LN_BWD_MAX_BLOCKS + 63) / 64;
 
 template <int MAXC>
 void launch_fwd(const LnFwdArgs& a, int grid, hipStream_t s) {
@@ -258,7 +267,7 @@ extern "C" int mpv_layernorm_fwd(const void* x, const void* gamma, const void* b
 }
 
 extern "C" size_t mpv_layernorm_bwd_workspace_size(int64_t cols) {
-  return (size_t)LN_BWD_MAX_BLOCKS * 2 * (size_t)cols * sizeof(float);
+  return (size_t)(LN_BWD_MAX_BLOCKS + LN_L1_ROWS) * 2 * (size_t)cols * sizeof(float);
 }
 
 extern "C" int mpv_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
@@ -276,8 +285,8 @@ extern "C" int mpv_layernorm_bwd(const void* dy, const void* x, const void* gamm
   const bool dparam = dgamma != nullptr;
   int grid = (int)((rows + 3) / 4 < LN_BWD_MAX_BLOCKS ? (rows + 3) / 4 : LN_BWD_MAX_BLOCKS);
   if (dparam)
-    MPV_REQUIRE(workspace && workspace_bytes >= (size_t)grid * 2 * cols * sizeof(float), MPV_E_ARG,
-                "mpv_layernorm_bwd: workspace too small (need %zu bytes)", (size_t)grid * 2 * cols * sizeof(float));
+    MPV_REQUIRE(workspace && workspace_bytes >= (size_t)(grid + LN_L1_ROWS) * 2 * cols * sizeof(float), MPV_E_ARG,
+                "mpv_layernorm_bwd: workspace too small (need %zu bytes)", (size_t)(grid + LN_L1_ROWS) * 2 * cols * sizeof(float));
   LnBwdArgs a = {};
   a.dy = (const bf16*)dy;
   a.x = (const bf16*)x;
@@ -304,8 +313,20 @@ extern "C" int mpv_layernorm_bwd(const void* dy, const void* x, const void* gamm
   else if (nc <= 8) launch_bwd<8>(a, dparam, grid, stream);
   else if (nc <= 10) launch_bwd<10>(a, dparam, grid, stream);
   else launch_bwd<16>(a, dparam, grid, stream);
-  if (dparam)
-    hipLaunchKernelGGL(ln_dparam_finalize, dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, stream,
-                       (const float*)workspace, grid, (int)cols, (bf16*)dgamma, (bf16*)dbeta, accumulate_dparams);
+  if (dparam) {
+    float* l0 = (float*)workspace;
+    float* l1 = l0 + (size_t)grid * 2 * cols;
+    const unsigned gx = (unsigned)((cols + 63) / 64);
+    const int n1 = (grid + 63) / 64;
+    if (grid > 64) {
+      hipLaunchKernelGGL(ln_dparam_reduce, dim3(gx, n1), dim3(256), 0, stream, (const float*)l0, grid, (int)cols, l1, (bf16*)nullptr,
+                         (bf16*)nullptr, 0, 0);
+      hipLaunchKernelGGL(ln_dparam_reduce, dim3(gx), dim3(256), 0, stream, (const float*)l1, n1, (int)cols, (float*)nullptr,
+                         (bf16*)dgamma, (bf16*)dbeta, accumulate_dparams, 1);
+    } else {
+      hipLaunchKernelGGL(ln_dparam_reduce, dim3(gx), dim3(256), 0, stream, (const float*)l0, grid, (int)cols, (float*)nullptr,
+                         (bf16*)dgamma, (bf16*)dbeta, accumulate_dparams, 1);
+    }
+  }
   return mpv_check_launch("mpv_layernorm_bwd");
 }
