@@ -74,6 +74,8 @@ typedef struct mpv_gemm_epilogue {
   float alpha;            /* host scalar multiplier (0 -> 1)                                  */
   int out_f32;            /* C is fp32 (no epilogue besides alpha / accumulate)               */
   int accumulate;         /* C += result                                                      */
+  void* colsum_out;       /* wgrad only: bf16 [M] = column sums of A over the (mapped) reduction rows,
+                             i.e. the bias gradient that goes with dW = dY^T X, fused into the same pass */
 } mpv_gemm_epilogue;
 
 size_t mpv_gemm_workspace_size(int64_t M, int64_t N, int64_t K, int transA, int transB);

@@ -394,3 +394,21 @@ def test_adamw_and_gradnorm(dev):
     close(m, ref_m, 1e-4, "AdamW m")
     close(v, ref_v, 1e-4, "AdamW v")
     assert torch.equal(p16, master.bfloat16())
+
+
+def test_gemm_wgrad_fused_bias_grad(dev):
+    """colsum_out: the bias gradient (column sums of dY over the mapped reduction rows) fused into the wgrad pass."""
+    from youku_mplug_amd import ops
+    for (M, N, K, kmap) in [(768, 256, 1576, (0, 0, 0)), (2304, 768, 1568, (196, 197, 1)), (136, 72, 200, (0, 0, 0))]:
+        rows = K if kmap[0] == 0 else (K // kmap[0]) * kmap[1] + 4
+        dy, x = rn(rows, M, dev=dev, seed=95), rn(rows, N, dev=dev, seed=96)
+        bsum = torch.empty(M, dtype=torch.bfloat16, device=dev)
+        dw = ops.gemm(dy, x, M, N, K, trans_a=True, trans_b=True, lda=M, ldb=N, kmap=kmap, colsum_out=bsum)
+        if kmap[0]:
+            idx = torch.arange(K, device=dev)
+            idx = (idx // kmap[0]) * kmap[1] + idx % kmap[0] + kmap[2]
+            dyr, xr = dy[idx].float(), x[idx].float()
+        else:
+            dyr, xr = dy.float(), x.float()
+        close(dw, dyr.t() @ xr, 1e-2, "dW")
+        close(bsum, dyr.sum(0), 1e-2, "fused bias grad")

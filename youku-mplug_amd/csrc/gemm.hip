@@ -58,6 +58,7 @@ struct GemmArgs {
   int k_per_split;
   int tiles_n, tiles_m;
   int nwg;
+  float* colsum_part;   // wgrad only: [splits][M] fp32 partial column sums of the A operand (bias gradient)
 };
 
 // LDS byte address of 16-byte chunk `kc` (0..7) of `row` in a k-contiguous [128][64] tile.
@@ -188,6 +189,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
       }
     }
   };
+  // fused bias gradient (wgrad, first n-tile only): column sums of the A operand (dY) ride along with its
+  // staging registers -- each thread owns 8 columns x 4 k-rows per K step
+  f32x8 csum = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool do_colsum = TA && p.colsum_part != nullptr && n0 == 0;
   auto commit = [&](int buf) {
     char* pa = smem + buf * 2 * TILE_BYTES;
     char* pb = pa + TILE_BYTES;
@@ -196,6 +201,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
       if constexpr (!DMA) {
         *(i32x4*)(pa + la.ldsw[j]) = sa[j];
         *(i32x4*)(pb + lb.ldsw[j]) = sb[j];
+      }
+      if constexpr (TA) {
+        if (do_colsum) {
+          union { i32x4 i; bf16x8 b; } u;
+          u.i = sa[j];
+          csum += cvt8(u.b);
+        }
       }
     }
   };
@@ -272,6 +284,22 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
     }
   }
 
+  if constexpr (TA) {
+    if (do_colsum) {     // 16 threads (tid>>4) share a column chunk (tid&15): reduce through LDS, 128 columns per tile
+      __syncthreads();
+      float* red = (float*)smem;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[(tid >> 4) * 128 + (tid & 15) * 8 + e] = csum[e];
+      __syncthreads();
+      if (tid < 128 && m0 + tid < p.M) {
+        float a = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a += red[r * 128 + tid];
+        p.colsum_part[(long long)split * p.M + m0 + tid] = a;
+      }
+      // the epilogue starts with its own __syncthreads() before reusing smem
+    }
+  }
   // ------------------------------------------------------------------ epilogue
   // The MFMA layout gives each lane 4 columns of 32 different rows: stored directly that is 32
   // partial cache lines per store instruction (measured: ~6.7 us fixed cost per tile, independent of
@@ -366,6 +394,14 @@ __global__ void splitk_reduce_kernel(const float* part, bf16* out, long long MN,
   *(bf16x4*)(out + i) = cvt4(s);
 }
 
+__global__ void colsum_finish_kernel(const float* part, bf16* out, int M, int splits) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  float a = 0.f;
+  for (int z = 0; z < splits; ++z) a += part[(long long)z * M + m];
+  out[m] = f2bf(a);
+}
+
 }  // namespace
 
 extern "C" size_t mpv_gemm_workspace_size(int64_t M, int64_t N, int64_t K, int transA, int transB) {
@@ -442,6 +478,8 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
     g.out_f32 = ep->out_f32;
     g.accumulate = ep->accumulate;
   }
+  void* colsum_out = ep ? ep->colsum_out : nullptr;
+  MPV_REQUIRE(!colsum_out || (transA && transB && !g.out_f32), MPV_E_ARG, "mpv_gemm_bf16: colsum_out is a wgrad (transA=transB=1) option");
   // byte extents for the buffer descriptors (rows may be gathered through amap/kmap)
   const long long a_rows = transA ? map_row(g.kmap, K - 1) + 1 : map_row(g.amap, M - 1) + 1;
   const long long b_rows = transB ? map_row(g.kmap, K - 1) + 1 : N;
@@ -468,6 +506,11 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
   dim3 grid(g.nwg, splitk), block(256);
   void* user_c = C;
   const int user_acc = g.accumulate;
+  if (colsum_out) {
+    const size_t need = (size_t)(splitk > 1 ? splitk : 0) * M * N * sizeof(float) + (size_t)splitk * M * sizeof(float);
+    MPV_REQUIRE(workspace && workspace_bytes >= need, MPV_E_ARG, "mpv_gemm_bf16: workspace too small for colsum_out");
+    g.colsum_part = (float*)((char*)workspace + (size_t)(splitk > 1 ? splitk : 0) * M * N * sizeof(float));
+  }
   if (splitk > 1) {
     MPV_REQUIRE(!g.bias && !g.act && !g.residual && !g.act_bwd && !g.drop_thr && g.cmap.group == 0 && ldc == N, MPV_E_ARG,
                 "mpv_gemm_bf16: split-K (wgrad) pass takes no fused epilogue");
@@ -488,5 +531,8 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(thr), 0, stream, (const float*)workspace,
                        (bf16*)user_c, MN, splitk, user_acc);
   }
+  if (colsum_out)
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, (const float*)g.colsum_part,
+                       (bf16*)colsum_out, (int)M, splitk);
   return mpv_check_launch("mpv_gemm_bf16");
 }

@@ -228,42 +228,39 @@ class TimeSformer(nn.Module):
             hid = blk.mlp.fc1.out_features
             dout = dx
             # ---- MLP
-            ops.colsum(dout, R, D, out=grad_of(blk.mlp.fc2.bias))
-            ops.gemm(dout, s["h1"], D, hid, R, trans_a=True, trans_b=True, out=grad_of(blk.mlp.fc2.weight))
+            ops.gemm(dout, s["h1"], D, hid, R, trans_a=True, trans_b=True, out=grad_of(blk.mlp.fc2.weight), colsum_out=grad_of(blk.mlp.fc2.bias))
             dz = ops.gemm(dout, blk.mlp.fc2.weight, R, hid, D, trans_b=True, act_bwd_z=s["z"], act_bwd=ACT_GELU_ERF)
-            ops.colsum(dz, R, hid, out=grad_of(blk.mlp.fc1.bias))
-            ops.gemm(dz, s["l2"], hid, D, R, trans_a=True, trans_b=True, out=grad_of(blk.mlp.fc1.weight))
+            ops.gemm(dz, s["l2"], hid, D, R, trans_a=True, trans_b=True, out=grad_of(blk.mlp.fc1.weight), colsum_out=grad_of(blk.mlp.fc1.bias))
             dl2 = ops.gemm(dz, blk.mlp.fc1.weight, R, D, hid, trans_b=True)
             dy = ops.layernorm_bwd(dl2, s["y"], blk.norm2.weight, s["m2"], s["r2"], R, D, dres=dout,
                                    dgamma=grad_of(blk.norm2.weight), dbeta=grad_of(blk.norm2.bias))
             # ---- cls merge + spatial attention
             dps = ops.vit_cls_merge_bwd(dy, B, T, N1, D)
-            ops.colsum(dps, R, D, out=grad_of(blk.attn.proj.bias))
-            ops.gemm(dps, s["a_s"], D, D, R, trans_a=True, trans_b=True, out=grad_of(blk.attn.proj.weight))
+            ops.gemm(dps, s["a_s"], D, D, R, trans_a=True, trans_b=True, out=grad_of(blk.attn.proj.weight), colsum_out=grad_of(blk.attn.proj.bias))
             das = ops.gemm(dps, blk.attn.proj.weight, R, D, D, trans_b=True)
             qkv_s = s["qkv_s"]
             dqkv = torch.empty_like(qkv_s)
             ops.attn_bwd(qkv_s, qkv_s[:, D:], qkv_s[:, 2 * D:], s["a_s"], s["lse"], das, dqkv, dqkv[:, D:], dqkv[:, 2 * D:],
                          s["lay"], B * T, heads, N1, N1, hd, scale=blk.attn.scale, scale_q_bf16=True)
-            ops.colsum(dqkv, R, D, ld=3 * D, out=grad_of(blk.attn.q_bias))
-            ops.colsum(dqkv[:, 2 * D:], R, D, ld=3 * D, out=grad_of(blk.attn.v_bias))
-            ops.gemm(dqkv, s["l1"], 3 * D, D, R, trans_a=True, trans_b=True, out=grad_of(blk.attn.qkv.weight))
+            bsum = torch.empty(3 * D, dtype=torch.bfloat16, device=dqkv.device)
+            ops.gemm(dqkv, s["l1"], 3 * D, D, R, trans_a=True, trans_b=True, out=grad_of(blk.attn.qkv.weight), colsum_out=bsum)
+            grad_of(blk.attn.q_bias).copy_(bsum[:D])
+            grad_of(blk.attn.v_bias).copy_(bsum[2 * D:])
             dl1 = ops.gemm(dqkv, blk.attn.qkv.weight, R, D, 3 * D, trans_b=True)
             dxt = ops.layernorm_bwd(dl1, s["xt"], blk.norm1.weight, s["m1"], s["r1"], R, D, dres=dy,
                                     dgamma=grad_of(blk.norm1.weight), dbeta=grad_of(blk.norm1.bias))
             # ---- temporal branch (token rows)
-            ops.colsum(dxt, Rt, D, rmap=tok, out=grad_of(blk.temporal_fc.bias))
-            ops.gemm(dxt, s["pt"], D, D, Rt, trans_a=True, trans_b=True, kmap=tok, out=grad_of(blk.temporal_fc.weight))
+            ops.gemm(dxt, s["pt"], D, D, Rt, trans_a=True, trans_b=True, kmap=tok, out=grad_of(blk.temporal_fc.weight), colsum_out=grad_of(blk.temporal_fc.bias))
             dpt = ops.gemm(dxt, blk.temporal_fc.weight, Rt, D, D, trans_b=True, amap=tok, cmap=tok, out_rows=R)
-            ops.colsum(dpt, Rt, D, rmap=tok, out=grad_of(blk.temporal_attn.proj.bias))
-            ops.gemm(dpt, s["at"], D, D, Rt, trans_a=True, trans_b=True, kmap=tok, out=grad_of(blk.temporal_attn.proj.weight))
+            ops.gemm(dpt, s["at"], D, D, Rt, trans_a=True, trans_b=True, kmap=tok, out=grad_of(blk.temporal_attn.proj.weight), colsum_out=grad_of(blk.temporal_attn.proj.bias))
             dat = ops.gemm(dpt, blk.temporal_attn.proj.weight, Rt, D, D, trans_b=True, amap=tok, cmap=tok, out_rows=R)
             dqkv_t = torch.empty_like(s["qkv_t"])
             ops.temporal_attn_bwd(s["qkv_t"], dat, dqkv_t, B, T * N1, N, 1, N1, T, heads, hd, blk.temporal_attn.scale)
-            ops.colsum(dqkv_t, Rt, D, ld=3 * D, rmap=tok, out=grad_of(blk.temporal_attn.q_bias))
-            ops.colsum(dqkv_t[:, 2 * D:], Rt, D, ld=3 * D, rmap=tok, out=grad_of(blk.temporal_attn.v_bias))
+            bsum_t = torch.empty(3 * D, dtype=torch.bfloat16, device=dqkv_t.device)
             ops.gemm(dqkv_t, s["lt"], 3 * D, D, Rt, trans_a=True, trans_b=True, kmap=tok,
-                     out=grad_of(blk.temporal_attn.qkv.weight))
+                     out=grad_of(blk.temporal_attn.qkv.weight), colsum_out=bsum_t)
+            grad_of(blk.temporal_attn.q_bias).copy_(bsum_t[:D])
+            grad_of(blk.temporal_attn.v_bias).copy_(bsum_t[2 * D:])
             dlt = ops.gemm(dqkv_t, blk.temporal_attn.qkv.weight, Rt, D, 3 * D, trans_b=True, amap=tok, cmap=tok, out_rows=R)
             # dx = dxt (all rows) + LN_t-backward on token rows, accumulated in place
             ops.layernorm_bwd(dlt, s["x"], blk.temporal_ln.weight, s["mt"], s["rt"], Rt, D, dres=dxt, dx=dxt,
@@ -353,16 +350,13 @@ class AttentionPool(nn.Module):
         hd, hid = D // heads, self.mlp.fc1.out_features
         a = self.attn
         R = B * Q
-        ops.colsum(dout, R, D, out=grad_of(self.mlp.fc2.bias))
-        ops.gemm(dout, tape["h1"], D, hid, R, trans_a=True, trans_b=True, out=grad_of(self.mlp.fc2.weight))
+        ops.gemm(dout, tape["h1"], D, hid, R, trans_a=True, trans_b=True, out=grad_of(self.mlp.fc2.weight), colsum_out=grad_of(self.mlp.fc2.bias))
         dz = ops.gemm(dout, self.mlp.fc2.weight, R, hid, D, trans_b=True, act_bwd_z=tape["z"], act_bwd=ACT_GELU_ERF)
-        ops.colsum(dz, R, hid, out=grad_of(self.mlp.fc1.bias))
-        ops.gemm(dz, tape["l2"], hid, D, R, trans_a=True, trans_b=True, out=grad_of(self.mlp.fc1.weight))
+        ops.gemm(dz, tape["l2"], hid, D, R, trans_a=True, trans_b=True, out=grad_of(self.mlp.fc1.weight), colsum_out=grad_of(self.mlp.fc1.bias))
         dl2 = ops.gemm(dz, self.mlp.fc1.weight, R, D, hid, trans_b=True)
         dx2 = ops.layernorm_bwd(dl2, tape["x2"], self.norm2.weight, *tape["s2"], R, D, dres=dout,
                                 dgamma=grad_of(self.norm2.weight), dbeta=grad_of(self.norm2.bias))
-        ops.colsum(dx2, R, D, out=grad_of(a.out_proj.bias))
-        ops.gemm(dx2, tape["o"], D, D, R, trans_a=True, trans_b=True, out=grad_of(a.out_proj.weight))
+        ops.gemm(dx2, tape["o"], D, D, R, trans_a=True, trans_b=True, out=grad_of(a.out_proj.weight), colsum_out=grad_of(a.out_proj.bias))
         do = ops.gemm(dx2, a.out_proj.weight, R, D, D, trans_b=True)
         kv = tape["kv"]
         dq = torch.empty_like(tape["q"])
