@@ -974,51 +974,49 @@ struct TempArgs {
   float scale;
 };
 
-// one wave per (sequence, head); T <= 16, hd <= 96.  LDS floats per wave: 3*T*(hd+1) + T*(T+1) (+ bwd extras)
+// one wave per (sequence, head); T <= 16, hd <= 96 (multiple of 4).  Rows live in LDS as fp32 with a pitch of
+// hd+4 floats so every inner product runs on 16-byte ds_read_b128 operands (conflict-free across rows).
+// LDS floats per wave: (3|4)*T*(hd+4) + (1|2)*T*(T+1).
 template <bool BWD>
-__global__ __launch_bounds__(512) void temporal_attn_kernel(const TempArgs p) {
+__global__ __launch_bounds__(256) void temporal_attn_kernel(const TempArgs p) {
   extern __shared__ __attribute__((aligned(16))) float tsm[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int T = p.T, hd = p.hd, ld = hd + 1, D = p.heads * hd;
+  const int T = p.T, hd = p.hd, ld = hd + 4, D = p.heads * hd, H4 = hd / 4;
   const int per_wave = (BWD ? 4 : 3) * T * ld + (BWD ? 2 : 1) * T * (T + 1);
-  float* qs = tsm + wave * per_wave;
+  float* qs = tsm + wave * ((per_wave + 3) & ~3);
   float* ks = qs + T * ld;
   float* vs = ks + T * ld;
-  float* ps = vs + T * ld;              // [T][T+1] probabilities
-  float* dos = ps + T * (T + 1);        // BWD: dO [T][ld]
-  float* dss = dos + T * ld;            // BWD: dS [T][T+1]
+  float* dos = vs + T * ld;                         // BWD only: dO [T][ld]
+  float* ps = (BWD ? dos + T * ld : dos);           // [T][T+1] probabilities
+  float* dss = ps + T * (T + 1);                    // BWD only: dS [T][T+1]
   const long long nprob = (long long)p.n_outer * p.n_inner * p.heads;
-  const int nwv = blockDim.x >> 6;   // = heads when heads <= 8: one workgroup reads whole qkv rows of a sequence
-  for (long long pr = (long long)blockIdx.x * nwv + wave; pr < nprob; pr += (long long)gridDim.x * nwv) {
+  for (long long pr = (long long)blockIdx.x * 4 + wave; pr < nprob; pr += (long long)gridDim.x * 4) {
     const int h = (int)(pr % p.heads);
     const long long seq = pr / p.heads;
     const long long o = seq / p.n_inner, i = seq % p.n_inner;
     const long long row0 = o * p.outer_stride + p.inner_offset + i;
-    const int nvec = T * (hd / 4);
-    for (int x = lane; x < nvec; x += 64) {
-      const int t = x / (hd / 4), c4 = x % (hd / 4);
+    for (int x = lane; x < T * H4; x += 64) {
+      const int t = x / H4, c4 = x - t * H4;
       const bf16* src = p.qkv + (row0 + t * p.t_stride) * (3LL * D) + h * hd + c4 * 4;
-      f32x4 qv = cvt4(*(const bf16x4*)src);
-      const f32x4 kv = cvt4(*(const bf16x4*)(src + D));
-      const f32x4 vv = cvt4(*(const bf16x4*)(src + 2 * D));
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        qs[t * ld + c4 * 4 + e] = bf2f(f2bf(qv[e] * p.scale));   // q*scale rounds to bf16 (reference :179)
-        ks[t * ld + c4 * 4 + e] = kv[e];
-        vs[t * ld + c4 * 4 + e] = vv[e];
-      }
-      if constexpr (BWD) {
-        const f32x4 dv = cvt4(*(const bf16x4*)(p.dout + (row0 + t * p.t_stride) * (long long)D + h * hd + c4 * 4));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dos[t * ld + c4 * 4 + e] = dv[e];
-      }
+      f32x4 qv = cvt4(*(const bf16x4*)src) * p.scale;
+      qv = cvt4(cvt4(qv));                                        // q*scale rounds to bf16 (reference :179)
+      *(f32x4*)(qs + t * ld + c4 * 4) = qv;
+      *(f32x4*)(ks + t * ld + c4 * 4) = cvt4(*(const bf16x4*)(src + D));
+      *(f32x4*)(vs + t * ld + c4 * 4) = cvt4(*(const bf16x4*)(src + 2 * D));
+      if constexpr (BWD)
+        *(f32x4*)(dos + t * ld + c4 * 4) = cvt4(*(const bf16x4*)(p.dout + (row0 + t * p.t_stride) * (long long)D + h * hd + c4 * 4));
     }
     WAVE_SYNC();
     for (int x = lane; x < T * T; x += 64) {
-      const int a = x / T, bb = x % T;
-      float s = 0.f;
-      for (int d = 0; d < hd; ++d) s += qs[a * ld + d] * ks[bb * ld + d];
-      ps[a * (T + 1) + bb] = s;
+      const int a = x / T, bb = x - a * T;
+      f32x4 acc4 = {0.f, 0.f, 0.f, 0.f}, dp4 = acc4;
+      for (int c4 = 0; c4 < H4; ++c4) {
+        const f32x4 kv = *(const f32x4*)(ks + bb * ld + c4 * 4);
+        acc4 += *(const f32x4*)(qs + a * ld + c4 * 4) * kv;
+        if constexpr (BWD) dp4 += *(const f32x4*)(dos + a * ld + c4 * 4) * *(const f32x4*)(vs + bb * ld + c4 * 4);
+      }
+      ps[a * (T + 1) + bb] = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+      if constexpr (BWD) dss[a * (T + 1) + bb] = (dp4[0] + dp4[1]) + (dp4[2] + dp4[3]);     // dP = dO V^T
     }
     WAVE_SYNC();
     if (lane < T) {
@@ -1027,46 +1025,33 @@ __global__ __launch_bounds__(512) void temporal_attn_kernel(const TempArgs p) {
       float sum = 0.f;
       for (int j = 0; j < T; ++j) sum += __expf(ps[lane * (T + 1) + j] - mx);
       const float inv = 1.0f / sum;
+      float dl = 0.f;
       for (int j = 0; j < T; ++j) {
         const float pv = __expf(ps[lane * (T + 1) + j] - mx) * inv;
         ps[lane * (T + 1) + j] = BWD ? pv : bf2f(f2bf(pv));      // forward: probs cast to bf16 (:201)
+        if constexpr (BWD) dl += pv * dss[lane * (T + 1) + j];
       }
+      if constexpr (BWD)                                           // dS = P * (dP - rowsum(P*dP))
+        for (int j = 0; j < T; ++j) dss[lane * (T + 1) + j] = ps[lane * (T + 1) + j] * (dss[lane * (T + 1) + j] - dl);
     }
     WAVE_SYNC();
-    if constexpr (!BWD) {
-      for (int x = lane; x < T * hd; x += 64) {
-        const int a = x / hd, d = x % hd;
-        float s = 0.f;
-        for (int j = 0; j < T; ++j) s += ps[a * (T + 1) + j] * vs[j * ld + d];
-        p.out[(row0 + a * p.t_stride) * (long long)D + h * hd + d] = f2bf(s);
-      }
-    } else {
-      // dP = dO V^T ; delta = rowsum(P*dP) ; dS = P*(dP - delta)
-      for (int x = lane; x < T * T; x += 64) {
-        const int a = x / T, bb = x % T;
-        float s = 0.f;
-        for (int d = 0; d < hd; ++d) s += dos[a * ld + d] * vs[bb * ld + d];
-        dss[a * (T + 1) + bb] = s;
-      }
-      WAVE_SYNC();
-      if (lane < T) {
-        float dl = 0.f;
-        for (int j = 0; j < T; ++j) dl += ps[lane * (T + 1) + j] * dss[lane * (T + 1) + j];
-        for (int j = 0; j < T; ++j) dss[lane * (T + 1) + j] = ps[lane * (T + 1) + j] * (dss[lane * (T + 1) + j] - dl);
-      }
-      WAVE_SYNC();
-      for (int x = lane; x < T * hd; x += 64) {
-        const int a = x / hd, d = x % hd;
-        float dq = 0.f, dk = 0.f, dv = 0.f;
+    for (int x = lane; x < T * H4; x += 64) {
+      const int a = x / H4, c4 = x - a * H4;
+      if constexpr (!BWD) {
+        f32x4 o4 = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < T; ++j) o4 += *(const f32x4*)(vs + j * ld + c4 * 4) * ps[a * (T + 1) + j];
+        *(bf16x4*)(p.out + (row0 + a * p.t_stride) * (long long)D + h * hd + c4 * 4) = cvt4(o4);
+      } else {
+        f32x4 dq = {0.f, 0.f, 0.f, 0.f}, dk = dq, dv = dq;
         for (int j = 0; j < T; ++j) {
-          dq += dss[a * (T + 1) + j] * ks[j * ld + d];
-          dk += dss[j * (T + 1) + a] * qs[j * ld + d];
-          dv += ps[j * (T + 1) + a] * dos[j * ld + d];
+          dq += *(const f32x4*)(ks + j * ld + c4 * 4) * dss[a * (T + 1) + j];
+          dk += *(const f32x4*)(qs + j * ld + c4 * 4) * dss[j * (T + 1) + a];
+          dv += *(const f32x4*)(dos + j * ld + c4 * 4) * ps[j * (T + 1) + a];
         }
-        bf16* dst = p.dqkv + (row0 + a * p.t_stride) * (3LL * D) + h * hd + d;
-        dst[0] = f2bf(dq * p.scale);
-        dst[D] = f2bf(dk);
-        dst[2 * D] = f2bf(dv);
+        bf16* dst = p.dqkv + (row0 + a * p.t_stride) * (3LL * D) + h * hd + c4 * 4;
+        *(bf16x4*)dst = cvt4(dq * p.scale);
+        *(bf16x4*)(dst + D) = cvt4(dk);
+        *(bf16x4*)(dst + 2 * D) = cvt4(dv);
       }
     }
     WAVE_SYNC();
@@ -1253,7 +1238,7 @@ extern "C" int mpv_temporal_attn_fwd(const void* qkv, void* out, int n_outer, in
   t.qkv = (const bf16*)qkv;
   t.out = (bf16*)out;
   const int nwv = 4;
-  const size_t lds = nwv * sizeof(float) * (size_t)(3 * T * (head_dim + 1) + T * (T + 1));
+  const size_t lds = nwv * sizeof(float) * (size_t)(((3 * T * (head_dim + 4) + T * (T + 1)) + 3) & ~3);
   const long long nprob = (long long)n_outer * n_inner * heads;
   const int grid = (int)((nprob + nwv - 1) / nwv < 16384 ? (nprob + nwv - 1) / nwv : 16384);
   static bool attr = false;
@@ -1278,7 +1263,7 @@ extern "C" int mpv_temporal_attn_bwd(const void* qkv, const void* dout, void* dq
   t.dout = (const bf16*)dout;
   t.dqkv = (bf16*)dqkv;
   const int nwv = 4;
-  const size_t lds = nwv * sizeof(float) * (size_t)(4 * T * (head_dim + 1) + 2 * T * (T + 1));
+  const size_t lds = nwv * sizeof(float) * (size_t)(((4 * T * (head_dim + 4) + 2 * T * (T + 1)) + 3) & ~3);
   const long long nprob = (long long)n_outer * n_inner * heads;
   const int grid = (int)((nprob + nwv - 1) / nwv < 16384 ? (nprob + nwv - 1) / nwv : 16384);
   static bool attr = false;
