@@ -31,6 +31,7 @@ namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand tile
+constexpr unsigned TAIL_WS_BYTES_DEV = 512u * 128 * 128 * 4;   // partial-tile workspace of the tail split (32 MiB)
 
 struct GemmArgs {
   const bf16* A;
@@ -59,6 +60,11 @@ struct GemmArgs {
   int tiles_n, tiles_m;
   int nwg;
   float* colsum_part;   // wgrad only: [splits][M] fp32 partial column sums of the A operand (bias gradient)
+  // tail split: the last `tiles % 512` tiles (a mostly empty final round of the 512 resident slots) are cut
+  // tail_g ways along K; partial tiles meet in tail_ws and the last workgroup to arrive finishes the tile
+  int tail_start, tail_g, tail_steps;
+  float* tail_ws;
+  unsigned* tail_cnt;
 };
 
 // LDS byte address of 16-byte chunk `kc` (0..7) of `row` in a k-contiguous [128][64] tile.
@@ -130,7 +136,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
   const int wrow = wave >> 1, wcol = wave & 1;
 
   // XCD-aware bijective remap: workgroup b runs on XCD b%8; give each XCD a contiguous tile range.
-  const int bid = blockIdx.x;
+  int bid = blockIdx.x;
+  int part = 0, parts = 1, tail_tile = 0;
+  if (p.tail_g > 1 && bid >= p.tail_start) {
+    const int u = bid - p.tail_start;
+    tail_tile = u / p.tail_g;
+    part = u - tail_tile * p.tail_g;
+    parts = p.tail_g;
+    bid = p.tail_start + tail_tile;
+  }
   const int nwg = p.nwg;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
   const int pid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
@@ -144,9 +158,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int split = blockIdx.y;
-  const int kbeg = split * p.k_per_split;
-  const int kend = min(p.K, kbeg + p.k_per_split);
-  const int nk = (kend - kbeg + BK - 1) / BK;
+  const int kbeg = parts > 1 ? part * p.tail_steps * BK : split * p.k_per_split;
+  const int kend = min(p.K, kbeg + (parts > 1 ? p.tail_steps * BK : p.k_per_split));
+  const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
 
   const __amdgpu_buffer_rsrc_t ra_src = make_rsrc(p.A, p.a_bytes);
   const __amdgpu_buffer_rsrc_t rb_src = make_rsrc(p.B, p.b_bytes);
@@ -310,8 +324,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
   constexpr int CP = 132;
   float* cs = (float*)smem;
   __syncthreads();   // every wave is done with the operand tiles
-#pragma unroll 1
-  for (int half = 0; half < 2; ++half) {
+  auto stage = [&](int half) {
     if (wrow == half) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -325,7 +338,43 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
             *(f32x4*)(cs + (i * 32 + (lane & 31)) * CP + wcol * 64 + j * 32 + 8 * q + 4 * (lane >> 5)) = v;
           }
     }
+  };
+  // tail split: park this K-part's raw fp32 tile in the workspace; the last part to arrive sums all parts in
+  // part order (bitwise reproducible whoever is last) and runs the fused epilogue on the sum
+  bool tail_src = false;
+  constexpr int COHERENT = 0x11;   // sc0 | sc1
+  const __amdgpu_buffer_rsrc_t tail_rsrc = make_rsrc(p.tail_ws, (uint32_t)TAIL_WS_BYTES_DEV);
+  if (parts > 1) {
+    // partials cross XCDs (private L2s): write them through and read them back with sc0|sc1 instead of
+    // fencing (an agent-scope fence writes back / invalidates the whole L2 of the XCD)
+    const uint32_t wbase = (uint32_t)(tail_tile * parts + part) << 16;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      stage(half);
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int c = tid + 256 * it;
+        const int row = c >> 4, col = (c & 15) * 8;
+        const uint32_t d = wbase + (uint32_t)((half * 64 + row) * 128 + col) * 4;
+        __builtin_amdgcn_raw_buffer_store_b128(*(const i32x4*)(cs + row * CP + col), tail_rsrc, d, 0, COHERENT);
+        __builtin_amdgcn_raw_buffer_store_b128(*(const i32x4*)(cs + row * CP + col + 4), tail_rsrc, d + 16, 0, COHERENT);
+      }
+      __syncthreads();
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): my partial stores are acknowledged
     __syncthreads();
+    if (tid == 0) ((int*)smem)[0] = atomicInc(p.tail_cnt + tail_tile, (unsigned)(parts - 1)) == (unsigned)(parts - 1);
+    __syncthreads();
+    if (!((int*)smem)[0]) return;
+    tail_src = true;
+  }
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    if (!tail_src) {
+      stage(half);
+      __syncthreads();
+    }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int c = tid + 256 * it;
@@ -334,7 +383,24 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
       if (m < p.M && n < p.N) {
         f32x8 v;
         {
-          const f32x4 lo = *(const f32x4*)(cs + row * CP + col), hi = *(const f32x4*)(cs + row * CP + col + 4);
+          f32x4 lo, hi;
+          if (tail_src) {
+            const uint32_t sp = ((uint32_t)(tail_tile * parts) << 16) + (uint32_t)((half * 64 + row) * 128 + col) * 4;
+            union { i32x4 i; f32x4 f; } u0, u1;
+            u0.i = __builtin_amdgcn_raw_buffer_load_b128(tail_rsrc, sp, 0, COHERENT);
+            u1.i = __builtin_amdgcn_raw_buffer_load_b128(tail_rsrc, sp + 16, 0, COHERENT);
+            lo = u0.f;
+            hi = u1.f;
+            for (int z = 1; z < parts; ++z) {
+              u0.i = __builtin_amdgcn_raw_buffer_load_b128(tail_rsrc, sp + ((uint32_t)z << 16), 0, COHERENT);
+              u1.i = __builtin_amdgcn_raw_buffer_load_b128(tail_rsrc, sp + ((uint32_t)z << 16) + 16, 0, COHERENT);
+              lo += u0.f;
+              hi += u1.f;
+            }
+          } else {
+            lo = *(const f32x4*)(cs + row * CP + col);
+            hi = *(const f32x4*)(cs + row * CP + col + 4);
+          }
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             v[e] = lo[e] * alpha;
@@ -380,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
         *(bf16x8*)cp = cvt8(v);
       }
     }
-    __syncthreads();
+    if (!tail_src) __syncthreads();
   }
 }
 
@@ -404,10 +470,29 @@ __global__ void colsum_finish_kernel(const float* part, bf16* out, int M, int sp
 
 }  // namespace
 
+constexpr int SLOTS = 512;                                   // resident workgroups: 256 CUs x 2
+constexpr size_t TAIL_WS_BYTES = (size_t)SLOTS * BM * BN * sizeof(float);   // 32 MiB of partial tiles
+
 extern "C" size_t mpv_gemm_workspace_size(int64_t M, int64_t N, int64_t K, int transA, int transB) {
-  if (!(transA && transB)) return 0;
+  if (!(transA && transB)) return TAIL_WS_BYTES;
   // wgrad: split the (long) reduction so that >= ~2 workgroups per CU exist
-  return (size_t)M * N * sizeof(float) * 32;
+  const size_t w = (size_t)M * N * sizeof(float) * 32;
+  return w > TAIL_WS_BYTES ? w : TAIL_WS_BYTES;
+}
+
+// arrival counters of the tail split, one per tail tile; atomicInc wraps them back to zero, so they are
+// zeroed once per device.  (GEMMs of one device are expected on one stream at a time.)
+static unsigned* tail_counters() {
+  static unsigned* cnt[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!cnt[dev]) {
+    unsigned* p = nullptr;
+    if (hipMalloc(&p, SLOTS * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, SLOTS * sizeof(unsigned)) != hipSuccess) return nullptr;
+    cnt[dev] = p;
+  }
+  return cnt[dev];
 }
 
 // wgrad split: pick the split count whose workgroup count best fills whole rounds of the 512 resident
@@ -503,7 +588,28 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
   }
   g.k_per_split = kps;
 
-  dim3 grid(g.nwg, splitk), block(256);
+  // tail split of a mostly empty last round (see GemmArgs); needs the partial-tile workspace
+  int grid_x = g.nwg;
+  if (splitk == 1 && !g.out_f32 && !colsum_out && workspace && workspace_bytes >= TAIL_WS_BYTES) {
+    const int R = g.nwg % SLOTS, nk = (int)((K + BK - 1) / BK);
+    int tg = R > 0 ? SLOTS / R : 1;
+    if (tg > 8) tg = 8;
+    while (tg > 1 && nk / tg < 16) --tg;   // short parts do not pay for the partial-tile round trip (measured)
+    if (tg > 1) {
+      const int steps = (nk + tg - 1) / tg;
+      tg = (nk + steps - 1) / steps;
+      unsigned* cnt = tg > 1 ? tail_counters() : nullptr;
+      if (cnt) {
+        g.tail_start = g.nwg - R;
+        g.tail_g = tg;
+        g.tail_steps = steps;
+        g.tail_ws = (float*)workspace;
+        g.tail_cnt = cnt;
+        grid_x = g.tail_start + R * tg;
+      }
+    }
+  }
+  dim3 grid(grid_x, splitk), block(256);
   void* user_c = C;
   const int user_acc = g.accumulate;
   if (colsum_out) {

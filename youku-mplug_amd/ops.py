@@ -78,8 +78,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: Optio
     ep.accumulate = int(accumulate)
     ep.colsum_out = _p(colsum_out)
     ws, wsn = None, 0
-    if trans_a and trans_b and not out_f32:
-        wsn = _lib.lib().mpv_gemm_workspace_size(M, N, K, 1, 1)
+    if not out_f32:
+        wsn = _lib.lib().mpv_gemm_workspace_size(M, N, K, int(trans_a), int(trans_b))
         ws = workspace(wsn, a.device)
         wsn = ws.numel()
     check(_lib.lib().mpv_gemm_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, lda, ldb, ldc, int(trans_a),
