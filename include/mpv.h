@@ -42,6 +42,7 @@ typedef struct ihipStream_t* mpv_stream_t; /* == hipStream_t */
 #define MPV_ACT_NONE 0
 #define MPV_ACT_GELU_ERF 1  /* nn.GELU, models/vision_transformer.py:94,99 */
 #define MPV_ACT_GELU_TANH 2 /* megatron bias_gelu_impl, models/modeling_distributed_gpt3.py:586-588 */
+#define MPV_ACT_RELU 3      /* nn.ReLU of cls_head, models/distributed_gpt3.py:526-530, 1081-1085 */
 
 int mpv_version(void);
 const char* mpv_last_error(void);
@@ -191,6 +192,10 @@ int mpv_l2norm_bwd(const void* dy, const void* x, const float* norm, void* dx, i
 /* dst[r] = src[idx[r]] (last-valid-token pooling of the text hidden state, :958-959) */
 int mpv_gather_rows(const void* src, const int64_t* idx, void* dst, int64_t rows, int64_t cols, int64_t ld,
                     mpv_stream_t stream);
+/* dst[idx[r]] = src[r], idx distinct, dst rows of stride ld (backward of that pooling where the decoder input
+ * carries gradient: the prompt pass of cls_head, models/distributed_gpt3.py:583-585, 1149-1151) */
+int mpv_scatter_rows(const void* src, const int64_t* idx, void* dst, int64_t rows, int64_t cols, int64_t ld,
+                     mpv_stream_t stream);
 /* Soft-target contrastive cross-entropy over fp32 similarities sim[rows][cols] (:966-978):
  * targets[i][j] = [row_ids[i]==col_ids[j]] / count_i; losses[i] = -sum_j log_softmax(sim_i)[j] targets[i][j];
  * dsim (bf16, optional) = (softmax - targets) * scale; dts[i] (optional) = sum_j dsim[i][j] * sim[i][j]. */

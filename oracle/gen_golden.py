@@ -97,9 +97,76 @@ def run_retrieval(name: str = "retrieval_tiny"):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def gencls_inputs(cfg, kind: str):
+    """Seeded inputs shared by the golden generator and the tests (tiny shapes)."""
+    g = torch.Generator().manual_seed(77 if kind == "itm" else 78)
+    Bv, L, Lp, C = 3, 10, 8, (2 if kind == "itm" else 3)
+    video = torch.randn(Bv, 3, cfg.num_frames, cfg.img_size, cfg.img_size, generator=g)
+    neg = [1, 2, 0, 2, 0, 1] if kind == "itm" else None                     # two derangements (run_retrieval_..._itm.py:110-111)
+    n = Bv + (len(neg) if neg else 0)
+
+    def text(rows, length):
+        ids = torch.randint(0, cfg.vocab, (rows, length), generator=g)
+        mask = torch.ones(rows, length, dtype=torch.long)
+        lens = torch.randint(3, length + 1, (rows,), generator=g)
+        for b in range(rows):
+            mask[b, lens[b]:] = 0
+        return ids, mask
+    ids, mask = text(n, L)
+    p_ids, p_mask = text(n, Lp)
+    plen = torch.randint(1, 3, (n,), generator=g)
+    labels = torch.randint(0, C, (n,), generator=g)
+    t = 2 if kind == "itm" else C
+    e_ids, e_mask = text(Bv * t, L)
+    e_pids, e_pmask = text(Bv * t if kind == "itm" else Bv, Lp)
+    e_plen = torch.randint(1, 3, (Bv * t,), generator=g)
+    return dict(video=video, neg=neg, ids=ids, mask=mask, p_ids=p_ids, p_mask=p_mask, plen=plen, labels=labels, num_classes=C,
+                e_ids=e_ids, e_mask=e_mask, e_pids=e_pids, e_pmask=e_pmask, e_plen=e_plen)
+
+
+def run_gencls(kind: str):
+    """DistributedGPT3_Retrieval_Cls ("itm") / DistributedGPT3_Cls ("cls"), use_cls on: SURVEY.md section 8(f) rank 1."""
+    import types
+    from .ref_loader import build_reference_gencls
+    cfg = CONFIG_TINY
+    name = f"{kind}_tiny"
+    rec = {"meta": dict(case=name, weight_seed=3, torch=str(torch.__version__))}
+    for tag, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        inp = gencls_inputs(cfg, kind)
+        model, sd = build_reference_gencls(cfg, kind, 3, dtype=dtype, num_classes=inp["num_classes"])
+        model.eval()                                                       # dropout off; forward(train=True) still takes the loss branch
+        text = types.SimpleNamespace(input_ids=inp["ids"], attention_mask=inp["mask"], prompt_lengths=inp["plen"])
+        ptext = types.SimpleNamespace(input_ids=inp["p_ids"], attention_mask=inp["p_mask"])
+        if kind == "itm":
+            lc, lk = model(inp["video"].to(dtype), text, ptext, inp["neg"], inp["labels"])
+        else:
+            lc, lk = model(inp["video"].to(dtype), text, ptext, inp["labels"])
+        (lc + lk).backward()
+        r = {"loss_caption": lc.detach().float().clone(), "loss_cls": lk.detach().float().clone(), "grad_norm": {}, "grad_sample": {}}
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                r["grad_norm"][n] = float(p.grad.float().norm())
+                r["grad_sample"][n] = grad_sample(p.grad)
+        etext = types.SimpleNamespace(input_ids=inp["e_ids"], attention_mask=inp["e_mask"], prompt_lengths=inp["e_plen"])
+        eptext = types.SimpleNamespace(input_ids=inp["e_pids"], attention_mask=inp["e_pmask"])
+        with torch.no_grad():
+            if kind == "itm":
+                gen, cl = model(inp["video"].to(dtype), etext, eptext, train=False)
+            else:
+                gen, cl = model(inp["video"].to(dtype), etext, eptext, train=False)
+        r["generation_logits"], r["cls_logits"] = gen.float().clone(), cl.float().clone()
+        rec[tag] = r
+        print(f"[{name}/{tag}] loss_caption={float(lc):.6f} loss_cls={float(lk):.6f}", flush=True)
+    path = os.path.join(GOLDEN_DIR, f"{name}.pt")
+    torch.save(rec, path)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     for c in (sys.argv[1:] or ["tiny"]):
         if c.startswith("retrieval"):
             run_retrieval(c)
+        elif c in ("itm", "cls"):
+            run_gencls(c)
         else:
             run_case(c)

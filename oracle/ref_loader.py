@@ -163,6 +163,34 @@ def build_reference_retrieval(cfg: PathConfig, seed: int = 0, dtype=torch.float3
     return model.to(dtype), sd
 
 
+def build_reference_gencls(cfg: PathConfig, kind: str, seed: int = 0, dtype=torch.float32, num_classes: int = 2):
+    """DistributedGPT3_Cls (kind="cls", models/distributed_gpt3.py:431-657) or DistributedGPT3_Retrieval_Cls
+    (kind="itm", :988-1218) on CPU with seeded weights and use_cls on."""
+    from .weights import cls_spec
+    vt, mg, dg = import_reference()
+    sd = make_state_dict(cfg, seed, spec_fn=lambda c: cls_spec(c, num_classes))
+    tmp = tempfile.mkdtemp(prefix="mpv_oracle_")
+    for name, d in (("config.json", _gpt_config_dict(cfg)), ("visual.json", _visual_config_dict(cfg)), ("text.json", _gpt_config_dict(cfg))):
+        with open(os.path.join(tmp, name), "w") as f:
+            json.dump(d, f)
+    config = {"visual_cfg": os.path.join(tmp, "visual.json"), "text_cfg": os.path.join(tmp, "text.json"), "text_decoder": tmp,
+              "megatron_cfg": {"world_size": 1, "model_parallel_size": 1, "tensor_model_parallel_size": 1}, "freeze_vit": False,
+              "freeze_text_decoder": True, "num_learnable_token": cfg.num_queries, "num_frames": cfg.num_frames,
+              "use_cls": True, "num_classes": num_classes}
+    prefix = "text_decoder.dist_model."
+    gpt_sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    old = mg.pre_load
+    mg.pre_load = lambda *a, **k: gpt_sd
+    try:
+        with _cpu_patches():
+            klass = dg.DistributedGPT3_Cls if kind == "cls" else dg.DistributedGPT3_Retrieval_Cls
+            model = klass(config=config, tokenizer=None)
+    finally:
+        mg.pre_load = old
+    model.load_state_dict(sd, strict=True)
+    return model.to(dtype), sd
+
+
 @contextlib.contextmanager
 def single_rank_collectives():
     """models/distributed_gpt3.py:962-964 call torch.distributed collectives unconditionally: run them on a

@@ -231,6 +231,61 @@ def retrieval_forward(video, ids, attn_mask, idx, sd, cfg: PathConfig):
     return dict(loss=(loss_i2t + loss_t2i) / 2, vision_feats=vision_feats, text_feat=text_feat)
 
 
+def gencls_forward(video, ids, attn_mask, prompt_lengths, prompt_ids, prompt_mask, labels, sd, cfg: PathConfig,
+                   negative_indices=None, train=True, kind="itm"):
+    """DistributedGPT3_Retrieval_Cls.forward (kind="itm", models/distributed_gpt3.py:1087-1214) and
+    DistributedGPT3_Cls.forward (kind="cls", :532-653) with use_cls on: generation pass with a per-sample
+    prompt-length loss mask + a prompt pass whose last valid hidden state feeds cls_head."""
+    Bv = video.shape[0]
+    image_embeds = timesformer(video, sd, cfg)
+    image_query = attention_pool(sd["learnable_queries"].repeat(Bv, 1, 1), image_embeds, sd, cfg)
+    qf = F.linear(image_query, sd["visual_fc.weight"], sd["visual_fc.bias"])                      # :1093 / :538
+    Q = qf.shape[1]
+    wte = sd["text_decoder.dist_model.language_model.embedding.word_embeddings.weight"]
+    targets = torch.cat([ids[:, 1:], ids[:, 1:2]], dim=1)                                         # :1097-1098
+    tla = attn_mask[:, 1:].clone()
+    for i, pl in enumerate(prompt_lengths):                                                       # :1100-1102
+        tla[i, :pl] = 0
+
+    def head(x):
+        return F.linear(F.relu(F.linear(x, sd["cls_head.0.weight"], sd["cls_head.0.bias"])), sd["cls_head.2.weight"], sd["cls_head.2.bias"])
+
+    def pooled_of(qfeat, p_ids, p_mask):
+        n = p_ids.shape[0]
+        tt = torch.cat([p_ids[:, 1:], p_ids[:, 1:2]], dim=1)
+        tt = torch.cat([torch.full((n, Q), 100, dtype=torch.long), tt], dim=1)
+        emb = torch.cat([qfeat, F.embedding(p_ids, wte)], dim=1)
+        lm_p = torch.cat([torch.zeros(n, Q, dtype=torch.long), p_mask[:, 1:]], dim=1)             # value unused downstream
+        out = gpt_forward(emb, tt, lm_p, sd, cfg)
+        am = torch.cat([torch.ones(n, Q, dtype=torch.long), p_mask], dim=1)
+        return out["last_hidden_state"][torch.arange(n), am.sum(dim=-1) - 1]                     # :1149-1150
+
+    if train:
+        if kind == "itm":
+            qf = torch.cat([qf, qf[negative_indices]], dim=0)                                    # :1105-1108
+        n = qf.shape[0]
+        tg = torch.cat([torch.full((n, Q), 100, dtype=torch.long), targets], dim=1)
+        emb = torch.cat([qf, F.embedding(ids, wte)], dim=1)
+        loss_mask = torch.cat([torch.zeros(n, Q, dtype=torch.long), tla], dim=1)
+        out = gpt_forward(emb, tg, loss_mask, sd, cfg)
+        logits = head(pooled_of(qf, prompt_ids, prompt_mask))
+        return dict(loss_caption=out["loss"], loss_cls=F.cross_entropy(logits.float(), labels), cls_logits=logits)
+    t = ids.shape[0] // Bv
+    qf_rep = qf.unsqueeze(1).repeat(1, t, 1, 1).reshape(Bv * t, Q, -1)                           # :1158-1159 / :599-600
+    n = qf_rep.shape[0]
+    tg = torch.cat([torch.full((n, Q), 100, dtype=torch.long), targets], dim=1)
+    emb = torch.cat([qf_rep, F.embedding(ids, wte)], dim=1)
+    loss_mask = torch.cat([torch.zeros(n, Q, dtype=torch.long), tla], dim=1)
+    out = gpt_forward(emb, tg, loss_mask, sd, cfg)
+    gen = (-torch.sum(out["losses"] * loss_mask, dim=-1)).view(Bv, t)                             # :1180-1181
+    if kind == "cls":
+        gen = torch.softmax(gen, dim=-1)                                                          # :620
+        cls_logits = head(pooled_of(qf, prompt_ids, prompt_mask))                                 # per video (:622-647)
+    else:
+        cls_logits = torch.softmax(head(pooled_of(qf_rep, prompt_ids, prompt_mask)), dim=-1)[:, 1].view(Bv, t)   # :1207-1208
+    return dict(generation_logits=gen, cls_logits=cls_logits)
+
+
 # --------------------------------------------------------------------------- optimizer
 def adamw_step(p, g, m, v, step, lr, beta1, beta2, eps, wd):
     """optim/adamw.py:66-115 (decoupled decay first, then bias-corrected Adam); in place, fp32."""

@@ -133,6 +133,17 @@ def retrieval_spec(cfg: PathConfig, embed_dim: int = 256):
     return s
 
 
+def cls_spec(cfg: PathConfig, num_classes: int = 2):
+    """DistributedGPT3_Cls / DistributedGPT3_Retrieval_Cls .state_dict() = pre-train keys + cls_head
+    (models/distributed_gpt3.py:524-530, 1079-1085)."""
+    s = state_dict_spec(cfg)
+    s.append(("cls_head.0.weight", (cfg.hidden, cfg.hidden), "w_proj"))
+    s.append(("cls_head.0.bias", (cfg.hidden,), "bias"))
+    s.append(("cls_head.2.weight", (num_classes, cfg.hidden), "w_proj"))
+    s.append(("cls_head.2.bias", (num_classes,), "bias"))
+    return s
+
+
 def make_state_dict(cfg: PathConfig, seed: int = 0, dtype=torch.float32, spec_fn=state_dict_spec) -> "OrderedDict[str, torch.Tensor]":
     g = torch.Generator(device="cpu")
     g.manual_seed(seed)

@@ -260,3 +260,28 @@ def test_itc_collectives_gloo_world2():
     total = (w[0] + w[1]) * feats
     for r in (0, 1):
         assert torch.allclose(res[r][2], total[r * 4:(r + 1) * 4], atol=1e-6)
+
+
+@pytest.mark.parametrize("kind", ["itm", "cls"])
+def test_restatement_generation_cls_heads_vs_golden(kind):
+    """oracle/restate.py:gencls_forward reproduces the reference modules' ITM / classification goldens
+    (both losses, every gradient norm, the train=False scores) in fp32."""
+    from oracle import restate
+    from oracle.gen_golden import gencls_inputs
+    from oracle.weights import CONFIG_TINY, cls_spec, make_state_dict
+    g = torch.load(os.path.join(GOLD, f"{kind}_tiny.pt"))["fp32"]
+    inp = gencls_inputs(CONFIG_TINY, kind)
+    sd = make_state_dict(CONFIG_TINY, 3, spec_fn=lambda c: cls_spec(c, inp["num_classes"]))
+    sd = {k: v.clone().requires_grad_(not k.startswith("text_decoder")) for k, v in sd.items()}
+    out = restate.gencls_forward(inp["video"], inp["ids"], inp["mask"], inp["plen"].tolist(), inp["p_ids"], inp["p_mask"], inp["labels"],
+                                 sd, CONFIG_TINY, negative_indices=inp["neg"], train=True, kind=kind)
+    assert abs(out["loss_caption"].item() - g["loss_caption"].item()) < 1e-5
+    assert abs(out["loss_cls"].item() - g["loss_cls"].item()) < 1e-5
+    (out["loss_caption"] + out["loss_cls"]).backward()
+    for n, gn in g["grad_norm"].items():
+        assert abs(sd[n].grad.norm().item() - gn) <= 1e-4 * gn + 1e-9, n
+    with torch.no_grad():
+        ev = restate.gencls_forward(inp["video"], inp["e_ids"], inp["e_mask"], inp["e_plen"].tolist(), inp["e_pids"], inp["e_pmask"], None,
+                                    {k: v.detach() for k, v in sd.items()}, CONFIG_TINY, train=False, kind=kind)
+    assert (ev["generation_logits"] - g["generation_logits"]).abs().max().item() < 1e-4
+    assert (ev["cls_logits"] - g["cls_logits"]).abs().max().item() < 1e-5

@@ -348,6 +348,16 @@ __global__ void gather_rows_kernel(const bf16* __restrict__ src, const int64_t* 
     *(bf16x4*)(dst + r * cols + c4 * 4) = *(const bf16x4*)(src + idx[r] * ld + c4 * 4);
   }
 }
+// dst[idx[r]] = src[r] (rows of idx are distinct): backward of the last-valid-token pooling
+__global__ void scatter_rows_kernel(const bf16* __restrict__ src, const int64_t* __restrict__ idx, bf16* __restrict__ dst,
+                                    long long rows, int cols, long long ld) {
+  const int C4 = cols / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < rows * C4; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / C4;
+    const int c4 = (int)(i - r * C4);
+    *(bf16x4*)(dst + idx[r] * ld + c4 * 4) = *(const bf16x4*)(src + r * cols + c4 * 4);
+  }
+}
 // Soft-target contrastive CE (models/distributed_gpt3.py:966-978): targets[i][j] = [ids_r[i]==ids_c[j]] / count_i;
 // loss_i = -sum_j log_softmax(sim_i)[j] * targets[i][j];  dsim = (softmax - targets) * scale (bf16);
 // dts[i] = sum_j dsim[i][j] * sim[i][j] (for the temperature gradient).  One wave per row.
@@ -543,6 +553,15 @@ extern "C" int mpv_gather_rows(const void* src, const int64_t* idx, void* dst, i
   hipLaunchKernelGGL(gather_rows_kernel, dim3(ew_grid(rows * (cols / 4))), dim3(256), 0, stream, (const bf16*)src, idx, (bf16*)dst,
                      (long long)rows, (int)cols, (long long)ld);
   return mpv_check_launch("mpv_gather_rows");
+}
+
+extern "C" int mpv_scatter_rows(const void* src, const int64_t* idx, void* dst, int64_t rows, int64_t cols, int64_t ld,
+                                hipStream_t stream) {
+  MPV_REQUIRE(src && idx && dst, MPV_E_ARG, "mpv_scatter_rows: null pointer");
+  MPV_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && ld % 4 == 0, MPV_E_SHAPE, "mpv_scatter_rows: bad shape");
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(ew_grid(rows * (cols / 4))), dim3(256), 0, stream, (const bf16*)src, idx, (bf16*)dst,
+                     (long long)rows, (int)cols, (long long)ld);
+  return mpv_check_launch("mpv_scatter_rows");
 }
 
 extern "C" int mpv_soft_target_ce(const float* sim, const int64_t* row_ids, const int64_t* col_ids, float scale, float* losses,

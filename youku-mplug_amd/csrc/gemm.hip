@@ -428,12 +428,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
           if (p.preact) *(bf16x8*)(p.preact + crow * p.ldc + n) = zb;
           const f32x8 z = cvt8(zb);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = p.act == 1 ? gelu_erf_f(z[e]) : gelu_tanh_f(z[e]);
+          for (int e = 0; e < 8; ++e) v[e] = p.act == 1 ? gelu_erf_f(z[e]) : p.act == 2 ? gelu_tanh_f(z[e]) : fmaxf(z[e], 0.f);
         }
         if (p.act_bwd) {
           const f32x8 z = cvt8(*(const bf16x8*)(p.actz + (long long)m * p.ldz + n));
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= p.act_bwd == 1 ? gelu_erf_grad_f(z[e]) : gelu_tanh_grad_f(z[e]);
+          for (int e = 0; e < 8; ++e) v[e] *= p.act_bwd == 1 ? gelu_erf_grad_f(z[e]) : p.act_bwd == 2 ? gelu_tanh_grad_f(z[e]) : (z[e] > 0.f ? 1.f : 0.f);
         }
         if (p.drop_thr) {
           const uint64_t base = p.drop_offset + (uint64_t)m * (uint64_t)p.N + (uint64_t)n;

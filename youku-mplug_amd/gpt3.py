@@ -170,7 +170,8 @@ class DistributedGPT3(nn.Module):
 
     # -------------------------------------------------------------- explicit forward / backward
     def forward_lm(self, query_features: Optional[torch.Tensor], ids: torch.Tensor, labels: Optional[torch.Tensor],
-                   loss_mask: Optional[torch.Tensor], tape: dict, want_logits: bool = False, hidden_only: bool = False):
+                   loss_mask: Optional[torch.Tensor], tape: dict, want_logits: bool = False, hidden_only: bool = False,
+                   pass_index: int = 0):
         """query_features [B*Q, H] (or None), ids [B,L] int64, labels [B,S] int64, loss_mask [B,S-1].
         Returns dict(loss fp32 scalar, losses [B,S-1] fp32, logits?, last_hidden_state [B,S,H])."""
         cfg = self.config
@@ -182,7 +183,7 @@ class DistributedGPT3(nn.Module):
         train = self.training
         p_h = cfg.hidden_dropout if train else 0.0
         p_a = cfg.attention_dropout if train else 0.0
-        seed = self.step_seed
+        seed = self.step_seed + 0x51ED2705 * pass_index     # a second decoder pass of one step draws its own dropout masks
         h = ops.gpt_embed_fwd(query_features, ids.contiguous(), lm.embedding.word_embeddings.weight,
                               lm.embedding.position_embeddings.weight, B, Q, L, H, dropout_p=p_h, seed=seed,
                               offset=_offset(0, _SITE_EMBED))
@@ -211,7 +212,9 @@ class DistributedGPT3(nn.Module):
             h = h2
         fl = lm.encoder.final_layernorm
         xf, mf, rf = ops.layernorm_fwd(h, fl.weight, fl.bias, fl.eps, R, H)
-        if hidden_only:     # retrieval text tower: only last_hidden_state is consumed (models/distributed_gpt3.py:958)
+        if hidden_only:     # only last_hidden_state is consumed (models/distributed_gpt3.py:958, 583-584, 1149-1150)
+            tape.update(B=B, Q=Q, L=L, S=S, layers=layers, h_last=h, sf=(mf, rf), dlogits=None, lay=lay, scale=scale, seed=seed,
+                        p_h=p_h, p_a=p_a)
             return dict(last_hidden_state=xf.view(B, S, H))
         logits = ops.gemm(xf, lm.embedding.word_embeddings.weight, R, V, H)          # tied LM head (:1348-1350)
         # masked mean of per-token CE over positions 0..S-2 (:1615-1617)
@@ -228,8 +231,23 @@ class DistributedGPT3(nn.Module):
             out["logits"] = keep_logits.view(B, S, V)
         return out
 
-    def backward_lm(self, tape: dict, grad_loss: Optional[torch.Tensor] = None):
-        """-> d(query_features) [B*Q, H] (dgrad only: the decoder is frozen)."""
+    def _dgrad(self, dy, weight, R, n_in, n_out, **kw):
+        """dX[R, n_in] = dY[R, n_out] W[n_out, n_in].  A frozen weight (the recipes' freeze_text_decoder: true) is
+        kept in a second, transposed copy so the pass runs as the k-contiguous (forward-type, LDS-DMA) GEMM, which is
+        measurably faster than the reduction-slow operand path; a trainable weight takes the ordinary dgrad kernel."""
+        if weight.requires_grad:
+            return ops.gemm(dy, weight, R, n_in, n_out, trans_b=True, **kw)
+        cache = self.__dict__.setdefault("_wt_cache", {})
+        key = id(weight)
+        ent = cache.get(key)
+        if ent is None or ent[0] != weight._version or ent[1] != weight.data_ptr():
+            ent = (weight._version, weight.data_ptr(), weight.detach().t().contiguous())
+            cache[key] = ent
+        return ops.gemm(dy, ent[2], R, n_in, n_out, **kw)
+
+    def backward_lm(self, tape: dict, grad_loss: Optional[torch.Tensor] = None, d_last_hidden: Optional[torch.Tensor] = None):
+        """-> d(query_features) [B*Q, H] (dgrad only: the decoder is frozen).  The seed is the loss (grad_loss scales the
+        stored dlogits) and/or d_last_hidden [B*S, H], the gradient of the final-layernorm output."""
         cfg = self.config
         lm = self.dist_model.language_model
         B, Q, L, S = tape["B"], tape["Q"], tape["L"], tape["S"]
@@ -238,8 +256,12 @@ class DistributedGPT3(nn.Module):
         p_h, p_a, seed, lay, scale = tape["p_h"], tape["p_a"], tape["seed"], tape["lay"], tape["scale"]
         nl = len(lm.encoder.layers)
         fl = lm.encoder.final_layernorm
-        dxf = ops.gemm(tape["dlogits"], lm.embedding.word_embeddings.weight, R, H, V, trans_b=True, alpha_dev=grad_loss)
-        tape["dlogits"] = None
+        if tape["dlogits"] is not None:
+            dxf = self._dgrad(tape["dlogits"], lm.embedding.word_embeddings.weight, R, H, V, alpha_dev=grad_loss,
+                              residual=d_last_hidden)
+            tape["dlogits"] = None
+        else:
+            dxf = d_last_hidden
         drop = p_h > 0.0
         dh_m = torch.empty((R, H), dtype=torch.bfloat16, device=dxf.device) if drop else None
         dh = ops.layernorm_bwd(dxf, tape["h_last"], fl.weight, *tape["sf"], R, H, dx_drop=dh_m, dropout_p=p_h, seed=seed,
@@ -250,18 +272,18 @@ class DistributedGPT3(nn.Module):
             att, mlp = layer.self_attention, layer.mlp
             F4 = mlp.dense_h_to_4h.out_features
             do = dh_m if drop else dh
-            dz = ops.gemm(do, mlp.dense_4h_to_h.weight, R, F4, H, trans_b=True, act_bwd_z=s["z"], act_bwd=ACT_GELU_TANH)
-            dx2 = ops.gemm(dz, mlp.dense_h_to_4h.weight, R, H, F4, trans_b=True)
+            dz = self._dgrad(do, mlp.dense_4h_to_h.weight, R, F4, H, act_bwd_z=s["z"], act_bwd=ACT_GELU_TANH)
+            dx2 = self._dgrad(dz, mlp.dense_h_to_4h.weight, R, H, F4)
             dh1_m = torch.empty((R, H), dtype=torch.bfloat16, device=dh.device) if drop else None
             dh1 = ops.layernorm_bwd(dx2, s["h1"], layer.post_attention_layernorm.weight, *s["s2"], R, H, dres=dh, dx_drop=dh1_m,
                                     dropout_p=p_h, seed=seed, offset=_offset(ln, _SITE_DROP1))
             da = dh1_m if drop else dh1
-            dctx = ops.gemm(da, att.dense.weight, R, H, H, trans_b=True)
+            dctx = self._dgrad(da, att.dense.weight, R, H, H)
             qkv = s["qkv"]
             dqkv = torch.empty_like(qkv)
             ops.attn_bwd(qkv, qkv[:, hn:], qkv[:, 2 * hn:], s["ctx"], s["lse"], dctx, dqkv, dqkv[:, hn:], dqkv[:, 2 * hn:], lay,
                          B, np_, S, S, hn, causal=True, scale=scale, dropout_p=p_a, seed=seed, offset=_offset(ln, _SITE_ATTN))
-            dx1 = ops.gemm(dqkv, att.query_key_value.weight, R, H, 3 * H, trans_b=True)
+            dx1 = self._dgrad(dqkv, att.query_key_value.weight, R, H, 3 * H)
             prev_off = _offset(li, _SITE_DROP2) if li > 0 else 0
             want_mask = drop and li > 0
             dh_m = torch.empty((R, H), dtype=torch.bfloat16, device=dh.device) if want_mask else None

@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import AttnDesc, GemmEpilogue, check
 
-ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH = 0, 1, 2
+ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_RELU = 0, 1, 2, 3
 RowMap = Tuple[int, int, int]
 IDENT: RowMap = (0, 0, 0)
 
@@ -290,6 +290,11 @@ def l2norm_bwd(dy, x, nrm, rows, cols):
 def gather_rows(src, idx, rows, cols, ld=None):
     dst = torch.empty((rows, cols), dtype=torch.bfloat16, device=src.device)
     check(_lib.lib().mpv_gather_rows(src.data_ptr(), idx.data_ptr(), dst.data_ptr(), rows, cols, ld or cols, _stream()), "mpv_gather_rows")
+    return dst
+
+
+def scatter_rows(src, idx, dst, rows, cols, ld=None):
+    check(_lib.lib().mpv_scatter_rows(src.data_ptr(), idx.data_ptr(), dst.data_ptr(), rows, cols, ld or cols, _stream()), "mpv_scatter_rows")
     return dst
 
 
