@@ -66,8 +66,10 @@ class GemmTimer:
             s.record()
             r = self.orig(a, b, M, N, K, **kw)
             e.record()
-            kind = "wgrad" if kw.get("trans_a") else ("dgrad" if kw.get("trans_b") else "fwd")
-            self.records.append((kind, 2.0 * M * N * K, s, e))
+            # kernel variant: <0,0> k-contiguous operands (forward, and dgrad against the frozen decoder's transposed weight
+            # copies), <0,1> dgrad against trainable weights, <1,1> wgrad
+            kind = "gemm<1,1> wgrad" if kw.get("trans_a") else ("gemm<0,1> dgrad" if kw.get("trans_b") else "gemm<0,0> fwd + frozen-weight dgrad")
+            self.records.append((kind, 2.0 * M * N * K, s, e, 2.0 * (M * K + N * K + M * N)))
             return r
         ops.gemm = timed
         import youku_mplug_amd.vision as v, youku_mplug_amd.gpt3 as g, youku_mplug_amd.pretrain as p
@@ -79,12 +81,24 @@ class GemmTimer:
     def summary(self):
         torch.cuda.synchronize()
         tot = {}
-        for kind, fl, s, e in self.records:
-            t = tot.setdefault(kind, [0.0, 0.0, 0])
+        for kind, fl, s, e, by in self.records:
+            t = tot.setdefault(kind, [0.0, 0.0, 0, 0.0])
             t[0] += fl
             t[1] += s.elapsed_time(e) * 1e-3
             t[2] += 1
+            t[3] += by
         return tot
+
+
+def pmc_traffic():
+    """HBM bytes per GEMM launch from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE doubled per the
+    gfx950 note in MI355X_MICROARCH.md, + WRITE_SIZE; tools/rocpd_pmc.py writes the file).  None when no profile is committed."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_gemm_latest.json")
+    try:
+        rec = json.load(open(path))
+        return {"hbm_mb_per_launch": rec["hbm_mb_per_launch"], "source": rec.get("source", "profiles/pmc_gemm_latest.json")}
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def host_cores():
@@ -232,11 +246,13 @@ def main():
         fl = sum(v[0] for v in tot.values())
         tt = sum(v[1] for v in tot.values())
         n = sum(v[2] for v in tot.values())
+        by = sum(v[3] for v in tot.values())
         roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel<TA,TB> (fwd/dgrad/wgrad)", "achieved": round(fl / tt / 1e12, 1),
-                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / tt / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / tt / 1e12 / PEAK_BF16_TFLOPS, 4),
+                "traffic": pmc_traffic(), "algorithmic_mb_per_launch": round(by / n / 1e6, 1),
                 "launches_per_step": n // nroof, "avg_launch_us": round(tt / n * 1e6, 1), "avg_launch_gflop": round(fl / n / 1e9, 2),
                 "gemm_ms_per_step": round(tt / nroof * 1e3, 2),
-                "by_pass": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / nroof * 1e3, 2), "launches": v[2] // nroof}
+                "by_kernel": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / nroof * 1e3, 2), "launches": v[2] // nroof}
                             for k, v in tot.items()},
                 "step_algorithmic_tflop": round(algorithmic_train_flops(B, T, L) / 1e12, 2),
                 "step_frac": round(algorithmic_train_flops(B, T, L) / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4)}

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round profile on the MI355X box: kernel trace + two PMC passes (FETCH_SIZE, WRITE_SIZE) of bench.py.
+# Usage (from the repo root, on the GPU box): bash tools/profile_round.sh r01_final
+set -u
+TAG=${1:-r01}
+R=$PWD
+OUT=$R/gpurun_out
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/kt /tmp/pf /tmp/pw
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt -o $TAG -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/${TAG}_trace_bench.log 2>&1
+python $R/tools/rocpd_stats.py $(find /tmp/kt -name "*.db" | head -1) $OUT/${TAG}_kernel_trace.md > /dev/null
+timeout 400 rocprofv3 --pmc FETCH_SIZE -d /tmp/pf -o f -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/${TAG}_pmc_fetch.log 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE -d /tmp/pw -o w -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/${TAG}_pmc_write.log 2>&1
+python $R/tools/rocpd_pmc.py $(find /tmp/pf -name "*.db" | head -1) $(find /tmp/pw -name "*.db" | head -1) $OUT/${TAG}_pmc_hbm_traffic.md $OUT/pmc_gemm_latest.json > /dev/null
+head -12 $OUT/${TAG}_kernel_trace.md; head -6 $OUT/${TAG}_pmc_hbm_traffic.md; cat $OUT/pmc_gemm_latest.json

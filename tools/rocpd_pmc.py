@@ -36,6 +36,13 @@ def main():
     if len(sys.argv) > 3:
         open(sys.argv[3], "w").write(out)
     print(out)
+    if len(sys.argv) > 4:       # GEMM-family summary consumed by bench.py (roofline.traffic)
+        import json
+        gem = [(tot, n) for tot, k, n, fk, wk in rows if k.startswith("gemm_bf16_kernel")]
+        nl = sum(n for _, n in gem)
+        json.dump({"hbm_mb_per_launch": round(sum(t for t, _ in gem) / nl / 1024, 1), "launches": nl,
+                   "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 1 --warmup 1`, 2*FETCH+WRITE, " + sys.argv[3]},
+                  open(sys.argv[4], "w"))  # note: copy into profiles/ with a repo-relative source
 
 
 if __name__ == "__main__":

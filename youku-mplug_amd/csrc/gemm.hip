@@ -58,7 +58,7 @@ struct GemmArgs {
   int accumulate;
   int k_per_split;
   int tiles_n, tiles_m;
-  int nwg;
+  int nwg, splits;
   float* colsum_part;   // wgrad only: [splits][M] fp32 partial column sums of the A operand (bias gradient)
   // tail split: the last `tiles % 512` tiles (a mostly empty final round of the 512 resident slots) are cut
   // tail_g ways along K; partial tiles meet in tail_ws and the last workgroup to arrive finishes the tile
@@ -145,9 +145,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
     parts = p.tail_g;
     bid = p.tail_start + tail_tile;
   }
-  const int nwg = p.nwg;
+  // Split-K launches are 1-D too, split-major: an XCD's contiguous range then lies inside one or two K-splits, so
+  // the workgroups sharing its L2 stream the SAME rows of both operands (measured on the wgrad shapes: the
+  // (x = tile, y = split) grid spread every XCD over all splits and re-fetched ~2.6x the algorithmic bytes).
+  const int nwg = p.nwg * p.splits;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-  const int pid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int split = lin / p.nwg;
+  const int pid = lin - split * p.nwg;
   // L2 blocking inside an XCD's range: walk GM m-tiles per n-tile, so the ~64 workgroups resident on an
   // XCD cover an ~8x8 patch of tiles (8 A panels + 8 B panels, each reused 8x from the 4 MiB L2)
   constexpr int GM = 8;
@@ -157,7 +162,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
   const int tile_n = rem / gm, tile_m = grp * GM + (rem - tile_n * gm);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  const int split = blockIdx.y;
   const int kbeg = parts > 1 ? part * p.tail_steps * BK : split * p.k_per_split;
   const int kend = min(p.K, kbeg + (parts > 1 ? p.tail_steps * BK : p.k_per_split));
   const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
@@ -609,7 +613,8 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
       }
     }
   }
-  dim3 grid(grid_x, splitk), block(256);
+  g.splits = splitk;
+  dim3 grid(splitk > 1 ? g.nwg * splitk : grid_x), block(256);
   void* user_c = C;
   const int user_acc = g.accumulate;
   if (colsum_out) {
