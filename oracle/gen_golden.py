@@ -162,11 +162,53 @@ def run_gencls(kind: str):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def run_eva(name: str = "eva_tiny"):
+    """DistributedGPT3_Pretrain_Image with the EVA encoder, shape-reduced
+    (heads of 88, MLP ratio 4.3637, patch 14); B=3, L=9 ragged, prompt_lengths masked."""
+    import types
+    from .ref_loader import build_reference_image
+    from .weights import CONFIG_EVA_TINY
+    cfg = CONFIG_EVA_TINY
+    rec = {"meta": dict(case=name, batch=3, text_len=9, weight_seed=4, input_seed=6, prompt_lengths=[1, 2, 1], torch=str(torch.__version__))}
+    for tag, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        model, sd = build_reference_image(cfg, 4, dtype=dtype)
+        video, ids, mask = make_inputs(cfg, 3, 9, seed=6, ragged=True)
+        image = video[:, :, 0]
+        model.eval()
+        captured = {}
+        td = model.text_decoder
+        orig = td.forward
+
+        def spy(*a, **k):
+            out = orig(*a, **k)
+            captured["out"] = out
+            return out
+        td.forward = spy
+        text = types.SimpleNamespace(input_ids=ids, attention_mask=mask, prompt_lengths=torch.tensor(rec["meta"]["prompt_lengths"]))
+        loss, _ = model(image.to(dtype), text)
+        td.forward = orig
+        loss.backward()
+        out = captured["out"]
+        r = {"loss": loss.detach().float().clone(), "losses": out.losses.detach().float().clone(),
+             "logits": out.logits.detach()[:, :, ::8].float().clone(), "grad_norm": {}, "grad_sample": {}}
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                r["grad_norm"][n] = float(p.grad.float().norm())
+                r["grad_sample"][n] = grad_sample(p.grad)
+        rec[tag] = r
+        print(f"[{name}/{tag}] loss={float(loss):.6f}", flush=True)
+    path = os.path.join(GOLDEN_DIR, f"{name}.pt")
+    torch.save(rec, path)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     for c in (sys.argv[1:] or ["tiny"]):
         if c.startswith("retrieval"):
             run_retrieval(c)
         elif c in ("itm", "cls"):
             run_gencls(c)
+        elif c.startswith("eva"):
+            run_eva(c)
         else:
             run_case(c)

@@ -191,6 +191,42 @@ def build_reference_gencls(cfg: PathConfig, kind: str, seed: int = 0, dtype=torc
     return model.to(dtype), sd
 
 
+def build_reference_image(cfg: PathConfig, seed: int = 0, dtype=torch.float32):
+    """DistributedGPT3_Pretrain_Image (models/distributed_gpt3.py:229-427) with use_eva_g on CPU with seeded weights.
+    create_eva_vit_g hard-codes the ViT-g sizes (models/eva_vit.py:413-427); for a CPU-sized oracle the SAME
+    reference VisionTransformer class is built with cfg's reduced width/depth/heads (everything else as in the factory)."""
+    from .weights import eva_spec
+    vt, mg, dg = import_reference()
+    import models.eva_vit as ev
+    sd = make_state_dict(cfg, seed, spec_fn=eva_spec)
+    tmp = tempfile.mkdtemp(prefix="mpv_oracle_")
+    vis = dict(_visual_config_dict(cfg), drop_path=0)
+    for name, d in (("config.json", _gpt_config_dict(cfg)), ("visual.json", vis), ("text.json", _gpt_config_dict(cfg))):
+        with open(os.path.join(tmp, name), "w") as f:
+            json.dump(d, f)
+    config = {"visual_cfg": os.path.join(tmp, "visual.json"), "text_cfg": os.path.join(tmp, "text.json"), "text_decoder": tmp,
+              "megatron_cfg": {"world_size": 1, "model_parallel_size": 1, "tensor_model_parallel_size": 1}, "freeze_vit": False,
+              "freeze_text_decoder": True, "num_learnable_token": cfg.num_queries, "use_eva_g": True, "use_contrastive": False}
+
+    def reduced_factory(img_size=224, drop_path_rate=0.4, norm_layer=None, use_checkpoint=True, precision="fp16"):
+        return ev.VisionTransformer(img_size=img_size, patch_size=cfg.patch_size, use_mean_pooling=False, embed_dim=cfg.vit_dim,
+                                    depth=cfg.vit_depth, num_heads=cfg.vit_heads, mlp_ratio=cfg.vit_mlp_ratio, qkv_bias=True,
+                                    drop_path_rate=drop_path_rate, norm_layer=norm_layer, use_checkpoint=False)
+
+    prefix = "text_decoder.dist_model."
+    gpt_sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    old, old_f = mg.pre_load, dg.create_eva_vit_g
+    mg.pre_load = lambda *a, **k: gpt_sd
+    dg.create_eva_vit_g = reduced_factory
+    try:
+        with _cpu_patches():
+            model = dg.DistributedGPT3_Pretrain_Image(config=config, tokenizer=None)
+    finally:
+        mg.pre_load, dg.create_eva_vit_g = old, old_f
+    model.load_state_dict(sd, strict=True)
+    return model.to(dtype), sd
+
+
 @contextlib.contextmanager
 def single_rank_collectives():
     """models/distributed_gpt3.py:962-964 call torch.distributed collectives unconditionally: run them on a

@@ -231,6 +231,50 @@ def retrieval_forward(video, ids, attn_mask, idx, sd, cfg: PathConfig):
     return dict(loss=(loss_i2t + loss_t2i) / 2, vision_feats=vision_feats, text_feat=text_feat)
 
 
+def eva_vit(image, sd, cfg: PathConfig, p="visual_encoder."):
+    """models/eva_vit.py:338-350 (forward_features) with Block :169-174 and Attention :123-153, as built by
+    create_eva_vit_g (:413-427): conv patch embed with bias, cls + absolute positions, pre-LN blocks with q/v bias,
+    no relative-position bias, no LayerScale, final LayerNorm (eps 1e-6, models/distributed_gpt3.py:258)."""
+    B = image.shape[0]
+    D, heads = cfg.vit_dim, cfg.vit_heads
+    x = F.conv2d(image, sd[p + "patch_embed.proj.weight"], sd[p + "patch_embed.proj.bias"], stride=cfg.patch_size)
+    x = x.flatten(2).transpose(1, 2)                                                              # :197
+    x = torch.cat([sd[p + "cls_token"].expand(B, -1, -1), x], dim=1) + sd[p + "pos_embed"]       # :341-345
+    scale = (D // heads) ** -0.5
+    for i in range(cfg.vit_depth):
+        b = f"{p}blocks.{i}."
+        h = ln_fp32(x, sd[b + "norm1.weight"], sd[b + "norm1.bias"], 1e-6)
+        bias = torch.cat([sd[b + "attn.q_bias"], torch.zeros_like(sd[b + "attn.v_bias"]), sd[b + "attn.v_bias"]])   # :127
+        qkv = F.linear(h, sd[b + "attn.qkv.weight"], bias).reshape(B, -1, 3, heads, D // heads).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0] * scale, qkv[1], qkv[2]                                                  # :134
+        a = (q @ k.transpose(-2, -1)).softmax(dim=-1)                                            # :135-148
+        a = (a @ v).transpose(1, 2).reshape(B, -1, D)
+        x = x + F.linear(a, sd[b + "attn.proj.weight"], sd[b + "attn.proj.bias"])                 # :172
+        h = ln_fp32(x, sd[b + "norm2.weight"], sd[b + "norm2.bias"], 1e-6)
+        h = F.linear(F.gelu(F.linear(h, sd[b + "mlp.fc1.weight"], sd[b + "mlp.fc1.bias"])), sd[b + "mlp.fc2.weight"], sd[b + "mlp.fc2.bias"])
+        x = x + h                                                                                 # :173
+    return ln_fp32(x, sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-6)                           # :350
+
+
+def pretrain_image_forward(image, ids, attn_mask, sd, cfg: PathConfig, prompt_lengths=None):
+    """DistributedGPT3_Pretrain_Image.forward with use_eva_g, use_contrastive False (models/distributed_gpt3.py:334-372)."""
+    B = image.shape[0]
+    image_embeds = eva_vit(image, sd, cfg)
+    image_query = attention_pool(sd["learnable_queries"].repeat(B, 1, 1), image_embeds, sd, cfg)
+    query_features = F.linear(image_query, sd["visual_fc.weight"], sd["visual_fc.bias"])
+    Q = query_features.shape[1]
+    targets = torch.cat([ids[:, 1:], ids[:, 1:2]], dim=1)
+    tla = attn_mask[:, 1:].clone()
+    if prompt_lengths is not None:                                                                # :348-351
+        for i, pl in enumerate(prompt_lengths):
+            tla[i, :pl] = 0
+    targets = torch.cat([torch.full((B, Q), 100, dtype=torch.long), targets], dim=1)
+    emb = F.embedding(ids, sd["text_decoder.dist_model.language_model.embedding.word_embeddings.weight"])
+    out = gpt_forward(torch.cat([query_features, emb], dim=1), targets, torch.cat([torch.zeros(B, Q, dtype=torch.long), tla], dim=1), sd, cfg)
+    out.update(image_embeds=image_embeds, query_features=query_features)
+    return out
+
+
 def gencls_forward(video, ids, attn_mask, prompt_lengths, prompt_ids, prompt_mask, labels, sd, cfg: PathConfig,
                    negative_indices=None, train=True, kind="itm"):
     """DistributedGPT3_Retrieval_Cls.forward (kind="itm", models/distributed_gpt3.py:1087-1214) and

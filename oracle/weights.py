@@ -144,6 +144,53 @@ def cls_spec(cfg: PathConfig, num_classes: int = 2):
     return s
 
 
+CONFIG_EVA_TINY = dataclasses.replace(CONFIG_TINY, img_size=56, patch_size=14, vit_dim=176, vit_depth=2, vit_heads=2,
+                                      vit_mlp_ratio=4.3637, num_frames=1)     # EVA-ViT-g shape-reduced: heads of 88, MLP ratio 4.3637
+
+
+def eva_spec(cfg: PathConfig):
+    """DistributedGPT3_Pretrain_Image(use_eva_g).state_dict(): EVA VisionTransformer keys (models/eva_vit.py:245-305)
+    + abstractor / visual_fc / decoder keys of the pre-train model."""
+    D = cfg.vit_dim
+    hid = int(D * cfg.vit_mlp_ratio)
+    P = cfg.patch_size
+    s = []
+
+    def ln(prefix, n):
+        s.append((prefix + ".weight", (n,), "ln_w"))
+        s.append((prefix + ".bias", (n,), "ln_b"))
+
+    def lin(prefix, out, inp):
+        s.append((prefix + ".weight", (out, inp), "w_vit"))
+        s.append((prefix + ".bias", (out,), "bias"))
+
+    ve = "visual_encoder."
+    s.append((ve + "cls_token", (1, 1, D), "embed"))
+    s.append((ve + "pos_embed", (1, cfg.n_patches + 1, D), "embed"))
+    s.append((ve + "patch_embed.proj.weight", (D, 3, P, P), "w_vit"))
+    s.append((ve + "patch_embed.proj.bias", (D,), "bias"))
+    for i in range(cfg.vit_depth):
+        b = f"{ve}blocks.{i}."
+        ln(b + "norm1", D)
+        s.append((b + "attn.qkv.weight", (3 * D, D), "w_vit"))
+        s.append((b + "attn.q_bias", (D,), "bias"))
+        s.append((b + "attn.v_bias", (D,), "bias"))
+        lin(b + "attn.proj", D, D)
+        ln(b + "norm2", D)
+        lin(b + "mlp.fc1", hid, D)
+        lin(b + "mlp.fc2", D, hid)
+    ln(ve + "norm", D)
+    for key, shape, kind in state_dict_spec(dataclasses.replace(cfg, vit_mlp_ratio=1)):
+        if key.startswith("visual_encoder."):
+            continue
+        if key.startswith("attn_pool.mlp.fc1"):
+            shape = (hid, D) if key.endswith("weight") else (hid,)
+        if key.startswith("attn_pool.mlp.fc2.weight"):
+            shape = (D, hid)
+        s.append((key, shape, kind))
+    return s
+
+
 def make_state_dict(cfg: PathConfig, seed: int = 0, dtype=torch.float32, spec_fn=state_dict_spec) -> "OrderedDict[str, torch.Tensor]":
     g = torch.Generator(device="cpu")
     g.manual_seed(seed)

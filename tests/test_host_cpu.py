@@ -285,3 +285,20 @@ def test_restatement_generation_cls_heads_vs_golden(kind):
                                     {k: v.detach() for k, v in sd.items()}, CONFIG_TINY, train=False, kind=kind)
     assert (ev["generation_logits"] - g["generation_logits"]).abs().max().item() < 1e-4
     assert (ev["cls_logits"] - g["cls_logits"]).abs().max().item() < 1e-5
+
+
+def test_restatement_eva_image_model_vs_golden():
+    """oracle/restate.py:pretrain_image_forward (EVA encoder blocks) reproduces the reference module's golden in fp32."""
+    from oracle import restate
+    from oracle.weights import CONFIG_EVA_TINY, eva_spec, make_inputs, make_state_dict
+    g = torch.load(os.path.join(GOLD, "eva_tiny.pt"))
+    f, m = g["fp32"], g["meta"]
+    sd = make_state_dict(CONFIG_EVA_TINY, m["weight_seed"], spec_fn=eva_spec)
+    sd = {k: v.clone().requires_grad_(not k.startswith("text_decoder")) for k, v in sd.items()}
+    video, ids, mask = make_inputs(CONFIG_EVA_TINY, m["batch"], m["text_len"], seed=m["input_seed"], ragged=True)
+    out = restate.pretrain_image_forward(video[:, :, 0], ids, mask, sd, CONFIG_EVA_TINY, prompt_lengths=m["prompt_lengths"])
+    assert abs(out["loss"].item() - f["loss"].item()) < 1e-5
+    assert (out["logits"][:, :, ::8] - f["logits"]).abs().max().item() < 1e-4
+    out["loss"].backward()
+    for n, gn in f["grad_norm"].items():
+        assert abs(sd[n].grad.norm().item() - gn) <= 1e-4 * gn + 1e-9, n

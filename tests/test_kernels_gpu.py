@@ -197,6 +197,8 @@ ATTN_CASES = [  # B, H, Sq, Sk, hd, causal, scale_q_bf16
     (2, 2, 128, 786, 96, False, False),
     (1, 1, 5, 7, 64, False, False),
     (1, 2, 33, 33, 96, True, False),
+    (2, 3, 257, 257, 88, False, True),      # EVA-ViT-g spatial attention (models/eva_vit.py:413-427: 1408 / 16 heads)
+    (2, 2, 32, 258, 88, False, False),      # its abstractor: 257 keys + bias_kv
 ]
 
 

@@ -43,6 +43,7 @@ struct AttnArgs {
   float* lse;
   long long q_bs, q_hs, q_rs, k_bs, k_hs, k_rs, v_bs, v_hs, v_rs, o_bs, o_hs, o_rs;
   int batch, heads, sq, sk;
+  int hd;       // true head_dim (<= HD, multiple of 8); columns hd..HD-1 are zero-filled on load and never stored
   int causal;
   float scale;
   int scale_q_bf16;
@@ -64,13 +65,13 @@ struct ChunkStage {
   i32x4 r[NLOAD];
 
   // nthr = blockDim.x (256..512): with more threads the later iterations are simply predicated off
-  __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t src, int tid, int row0, int nrows, long long rs) {
+  __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t src, int tid, int row0, int nrows, long long rs, int hd = HD) {
     const int nthr = blockDim.x;
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
       const int c = tid + nthr * i;
       const int row = c / CPR, cc = c - row * CPR;
-      const bool ok = (c < CH * CPR) && (row0 + row < nrows) && (cc * 8 < HD);
+      const bool ok = (c < CH * CPR) && (row0 + row < nrows) && (cc * 8 < hd);
       const uint32_t off = ok ? (uint32_t)(((long long)(row0 + row) * rs + cc * 8) * 2) : 0x80000000u;
       r[i] = __builtin_amdgcn_raw_buffer_load_b128(src, off, 0, 0);
     }
@@ -148,12 +149,12 @@ __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8
 // load this lane's B-operand fragments (row = row0 + lane&31, all d) straight from global
 template <int HD>
 __device__ __forceinline__ void load_row_frags(bf16x8 (&f)[HD / 16], const bf16* base, long long rs, int row, int nrows,
-                                               int lane) {
+                                               int lane, int hd = HD) {
 #pragma unroll
   for (int s = 0; s < HD / 16; ++s) {
     union { i32x4 i; bf16x8 b; } u;
     u.i = i32x4{0, 0, 0, 0};
-    if (row < nrows) u.i = *(const i32x4*)(base + (long long)row * rs + s * 16 + (lane >> 5) * 8);
+    if (row < nrows && s * 16 + (lane >> 5) * 8 < hd) u.i = *(const i32x4*)(base + (long long)row * rs + s * 16 + (lane >> 5) * 8);
     f[s] = u.b;
   }
 }
@@ -186,11 +187,11 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs p) {
   const bf16* qb = p.q + b * p.q_bs + h * p.q_hs;
   const bf16* kb = p.k + b * p.k_bs + h * p.k_hs;
   const bf16* vb = p.v + b * p.v_bs + h * p.v_hs;
-  const __amdgpu_buffer_rsrc_t ksrc = make_rsrc(kb, (uint32_t)(((long long)(p.sk - 1) * p.k_rs + HD) * 2));
-  const __amdgpu_buffer_rsrc_t vsrc = make_rsrc(vb, (uint32_t)(((long long)(p.sk - 1) * p.v_rs + HD) * 2));
+  const __amdgpu_buffer_rsrc_t ksrc = make_rsrc(kb, (uint32_t)(((long long)(p.sk - 1) * p.k_rs + p.hd) * 2));
+  const __amdgpu_buffer_rsrc_t vsrc = make_rsrc(vb, (uint32_t)(((long long)(p.sk - 1) * p.v_rs + p.hd) * 2));
 
   bf16x8 qf[NS];
-  load_row_frags<HD>(qf, qb, p.q_rs, qrow, p.sq, lane);
+  load_row_frags<HD>(qf, qb, p.q_rs, qrow, p.sq, lane, p.hd);
   float sc = p.scale;
   if (p.scale_q_bf16) {
     scale_frags_bf16(qf, p.scale);
@@ -214,12 +215,12 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs p) {
   };
 
   // ---------------- pass 1: row max and sum
-  sk_.issue(ksrc, tid, 0, p.sk, p.k_rs);
+  sk_.issue(ksrc, tid, 0, p.sk, p.k_rs, p.hd);
   sk_.commit(smem, tid);
   __syncthreads();
   for (int c = 0; c < nchunk; ++c) {
     const int cur = c & 1;
-    if (c + 1 < nchunk) sk_.issue(ksrc, tid, (c + 1) * CH, p.sk, p.k_rs);
+    if (c + 1 < nchunk) sk_.issue(ksrc, tid, (c + 1) * CH, p.sk, p.k_rs, p.hd);
     const char* kl = smem + cur * 2 * CHUNK_BYTES;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -256,16 +257,16 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs p) {
   for (int d = 0; d < NDT; ++d)
 #pragma unroll
     for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
-  sk_.issue(ksrc, tid, 0, p.sk, p.k_rs);
-  sv_.issue(vsrc, tid, 0, p.sk, p.v_rs);
+  sk_.issue(ksrc, tid, 0, p.sk, p.k_rs, p.hd);
+  sv_.issue(vsrc, tid, 0, p.sk, p.v_rs, p.hd);
   sk_.commit(smem, tid);
   sv_.commit(smem + CHUNK_BYTES, tid);
   __syncthreads();
   for (int c = 0; c < nchunk; ++c) {
     const int cur = c & 1;
     if (c + 1 < nchunk) {
-      sk_.issue(ksrc, tid, (c + 1) * CH, p.sk, p.k_rs);
-      sv_.issue(vsrc, tid, (c + 1) * CH, p.sk, p.v_rs);
+      sk_.issue(ksrc, tid, (c + 1) * CH, p.sk, p.k_rs, p.hd);
+      sv_.issue(vsrc, tid, (c + 1) * CH, p.sk, p.v_rs, p.hd);
     }
     const char* kl = smem + cur * 2 * CHUNK_BYTES;
     const char* vl = kl + CHUNK_BYTES;
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
         const int col = d * 32 + 8 * q4 + 4 * (lane >> 5);
-        if (col < HD) {
+        if (col < p.hd) {
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = oacc[d][4 * q4 + e];
@@ -344,12 +345,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttnArgs p) {
   const bf16* kb = p.k + b * p.k_bs + h * p.k_hs;
   const bf16* vb = p.v + b * p.v_bs + h * p.v_hs;
   const bf16* dob = p.dO + b * p.o_bs + h * p.o_hs;
-  const __amdgpu_buffer_rsrc_t ksrc = make_rsrc(kb, (uint32_t)(((long long)(p.sk - 1) * p.k_rs + HD) * 2));
-  const __amdgpu_buffer_rsrc_t vsrc = make_rsrc(vb, (uint32_t)(((long long)(p.sk - 1) * p.v_rs + HD) * 2));
+  const __amdgpu_buffer_rsrc_t ksrc = make_rsrc(kb, (uint32_t)(((long long)(p.sk - 1) * p.k_rs + p.hd) * 2));
+  const __amdgpu_buffer_rsrc_t vsrc = make_rsrc(vb, (uint32_t)(((long long)(p.sk - 1) * p.v_rs + p.hd) * 2));
 
   bf16x8 qf[NS], dof[NS];
-  load_row_frags<HD>(qf, qb, p.q_rs, qrow, p.sq, lane);
-  load_row_frags<HD>(dof, dob, p.o_rs, qrow, p.sq, lane);
+  load_row_frags<HD>(qf, qb, p.q_rs, qrow, p.sq, lane, p.hd);
+  load_row_frags<HD>(dof, dob, p.o_rs, qrow, p.sq, lane, p.hd);
   float sc = p.scale;
   if (p.scale_q_bf16) {
     scale_frags_bf16(qf, p.scale);
@@ -370,16 +371,16 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttnArgs p) {
     for (int e = 0; e < 16; ++e) dqacc[d][e] = 0.f;
 
   ChunkStage<HD> sk_, sv_;
-  sk_.issue(ksrc, tid, 0, p.sk, p.k_rs);
-  sv_.issue(vsrc, tid, 0, p.sk, p.v_rs);
+  sk_.issue(ksrc, tid, 0, p.sk, p.k_rs, p.hd);
+  sv_.issue(vsrc, tid, 0, p.sk, p.v_rs, p.hd);
   sk_.commit(smem, tid);
   sv_.commit(smem + CHUNK_BYTES, tid);
   __syncthreads();
   for (int c = 0; c < nchunk; ++c) {
     const int cur = c & 1;
     if (c + 1 < nchunk) {
-      sk_.issue(ksrc, tid, (c + 1) * CH, p.sk, p.k_rs);
-      sv_.issue(vsrc, tid, (c + 1) * CH, p.sk, p.v_rs);
+      sk_.issue(ksrc, tid, (c + 1) * CH, p.sk, p.k_rs, p.hd);
+      sv_.issue(vsrc, tid, (c + 1) * CH, p.sk, p.v_rs, p.hd);
     }
     const char* kl = smem + cur * 2 * CHUNK_BYTES;
     const char* vl = kl + CHUNK_BYTES;
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttnArgs p) {
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
         const int col = d * 32 + 8 * q4 + 4 * (lane >> 5);
-        if (col < HD) {
+        if (col < p.hd) {
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = dqacc[d][4 * q4 + e] * p.scale;
@@ -453,12 +454,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
   const bf16* kb = p.k + b * p.k_bs + h * p.k_hs;
   const bf16* vb = p.v + b * p.v_bs + h * p.v_hs;
   const bf16* dob = p.dO + b * p.o_bs + h * p.o_hs;
-  const __amdgpu_buffer_rsrc_t qsrc = make_rsrc(qb, (uint32_t)(((long long)(p.sq - 1) * p.q_rs + HD) * 2));
-  const __amdgpu_buffer_rsrc_t dosrc = make_rsrc(dob, (uint32_t)(((long long)(p.sq - 1) * p.o_rs + HD) * 2));
+  const __amdgpu_buffer_rsrc_t qsrc = make_rsrc(qb, (uint32_t)(((long long)(p.sq - 1) * p.q_rs + p.hd) * 2));
+  const __amdgpu_buffer_rsrc_t dosrc = make_rsrc(dob, (uint32_t)(((long long)(p.sq - 1) * p.o_rs + p.hd) * 2));
 
   bf16x8 kf[NS], vf[NS];
-  load_row_frags<HD>(kf, kb, p.k_rs, krow, p.sk, lane);
-  load_row_frags<HD>(vf, vb, p.v_rs, krow, p.sk, lane);
+  load_row_frags<HD>(kf, kb, p.k_rs, krow, p.sk, lane, p.hd);
+  load_row_frags<HD>(vf, vb, p.v_rs, krow, p.sk, lane, p.hd);
   const float sc = p.scale_q_bf16 ? 1.0f : p.scale;
   const bool kok = krow < p.sk;
 
@@ -491,8 +492,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     }
   };
   if (c_begin < nchunk) {
-    sq_.issue(qsrc, tid, c_begin * CH, p.sq, p.q_rs);
-    sd_.issue(dosrc, tid, c_begin * CH, p.sq, p.o_rs);
+    sq_.issue(qsrc, tid, c_begin * CH, p.sq, p.q_rs, p.hd);
+    sd_.issue(dosrc, tid, c_begin * CH, p.sq, p.o_rs, p.hd);
     issue_stats(c_begin);
     if (p.scale_q_bf16) sq_.scale_bf16(p.scale);
     sq_.commit(smem, tid);
@@ -503,8 +504,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
   for (int c = c_begin; c < nchunk; ++c) {
     const int cur = (c - c_begin) & 1;
     if (c + 1 < nchunk) {
-      sq_.issue(qsrc, tid, (c + 1) * CH, p.sq, p.q_rs);
-      sd_.issue(dosrc, tid, (c + 1) * CH, p.sq, p.o_rs);
+      sq_.issue(qsrc, tid, (c + 1) * CH, p.sq, p.q_rs, p.hd);
+      sd_.issue(dosrc, tid, (c + 1) * CH, p.sq, p.o_rs, p.hd);
       issue_stats(c + 1);
     }
     const char* ql = smem + cur * 2 * CHUNK_BYTES;
@@ -565,7 +566,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
         const int col = d * 32 + 8 * q4 + 4 * (lane >> 5);
-        if (col < HD) {
+        if (col < p.hd) {
           f32x4 a, c2;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -610,13 +611,13 @@ __device__ __forceinline__ bool decode_bh(const AttnArgs& p, int& b, int& h) {
 // follows in LDS -- the caller orders its regions so that data is finite where finiteness matters.
 template <int HD, int PITCH>
 __device__ __forceinline__ void dma_rows(const __amdgpu_buffer_rsrc_t src, char* lds, int nrows, long long rs, int wave, int nwaves,
-                                         int lane) {
+                                         int lane, int hd = HD) {
   constexpr int CPR = PITCH / 16;
   const int ninstr = (nrows * CPR + 63) / 64;
   for (int i = wave; i < ninstr; i += nwaves) {
     const int g = i * 64 + lane;
     const int row = g / CPR, cc = g - row * CPR;
-    const bool ok = row < nrows && cc * 8 < HD;
+    const bool ok = row < nrows && cc * 8 < hd;
     const uint32_t off = ok ? (uint32_t)(((long long)row * rs + cc * 8) * 2) : 0x80000000u;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (lds_void_t*)(lds + i * 1024), 16, off, 0, 0, 0);
   }
@@ -635,14 +636,14 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(const AttnArgs p) {
   char* vl = rsm;                                                         // [sk][192 B]
   char* kl = rsm + (((long long)p.sk * 192 + 1023) / 1024) * 1024;        // [sk][208 B]; tile over-reads of V land in K (finite)
   const bf16* qb = p.q + b * p.q_bs + h * p.q_hs;
-  const __amdgpu_buffer_rsrc_t ksrc = make_rsrc(p.k + b * p.k_bs + h * p.k_hs, (uint32_t)(((long long)(p.sk - 1) * p.k_rs + HD) * 2));
-  const __amdgpu_buffer_rsrc_t vsrc = make_rsrc(p.v + b * p.v_bs + h * p.v_hs, (uint32_t)(((long long)(p.sk - 1) * p.v_rs + HD) * 2));
-  dma_rows<HD, ROWB>(ksrc, kl, p.sk, p.k_rs, wave, nwaves, lane);
-  dma_rows<HD, 192>(vsrc, vl, p.sk, p.v_rs, wave, nwaves, lane);
+  const __amdgpu_buffer_rsrc_t ksrc = make_rsrc(p.k + b * p.k_bs + h * p.k_hs, (uint32_t)(((long long)(p.sk - 1) * p.k_rs + p.hd) * 2));
+  const __amdgpu_buffer_rsrc_t vsrc = make_rsrc(p.v + b * p.v_bs + h * p.v_hs, (uint32_t)(((long long)(p.sk - 1) * p.v_rs + p.hd) * 2));
+  dma_rows<HD, ROWB>(ksrc, kl, p.sk, p.k_rs, wave, nwaves, lane, p.hd);
+  dma_rows<HD, 192>(vsrc, vl, p.sk, p.v_rs, wave, nwaves, lane, p.hd);
   const int q0 = (blockIdx.x * nwaves + wave) * 32;
   const int qrow = q0 + (lane & 31);
   bf16x8 qf[NS];
-  load_row_frags<HD>(qf, qb, p.q_rs, qrow, p.sq, lane);
+  load_row_frags<HD>(qf, qb, p.q_rs, qrow, p.sq, lane, p.hd);
   float sc = p.scale;
   if (p.scale_q_bf16) {
     scale_frags_bf16(qf, p.scale);
@@ -732,7 +733,7 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(const AttnArgs p) {
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
         const int col = d * 32 + 8 * q4 + 4 * (lane >> 5);
-        if (col < HD) {
+        if (col < p.hd) {
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = oacc[d][4 * q4 + e];
@@ -754,15 +755,15 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const AttnArgs p) 
   const int bh = b * p.heads + h;
   char* vl = rsm;                                                         // [sk][192 B]
   char* kl = rsm + (((long long)p.sk * 192 + 1023) / 1024) * 1024;        // [sk][208 B]; tile over-reads of V land in K (finite)
-  const __amdgpu_buffer_rsrc_t ksrc = make_rsrc(p.k + b * p.k_bs + h * p.k_hs, (uint32_t)(((long long)(p.sk - 1) * p.k_rs + HD) * 2));
-  const __amdgpu_buffer_rsrc_t vsrc = make_rsrc(p.v + b * p.v_bs + h * p.v_hs, (uint32_t)(((long long)(p.sk - 1) * p.v_rs + HD) * 2));
-  dma_rows<HD, ROWB>(ksrc, kl, p.sk, p.k_rs, wave, nwaves, lane);
-  dma_rows<HD, 192>(vsrc, vl, p.sk, p.v_rs, wave, nwaves, lane);
+  const __amdgpu_buffer_rsrc_t ksrc = make_rsrc(p.k + b * p.k_bs + h * p.k_hs, (uint32_t)(((long long)(p.sk - 1) * p.k_rs + p.hd) * 2));
+  const __amdgpu_buffer_rsrc_t vsrc = make_rsrc(p.v + b * p.v_bs + h * p.v_hs, (uint32_t)(((long long)(p.sk - 1) * p.v_rs + p.hd) * 2));
+  dma_rows<HD, ROWB>(ksrc, kl, p.sk, p.k_rs, wave, nwaves, lane, p.hd);
+  dma_rows<HD, 192>(vsrc, vl, p.sk, p.v_rs, wave, nwaves, lane, p.hd);
   const int q0 = (blockIdx.x * nwaves + wave) * 32;
   const int qrow = q0 + (lane & 31);
   bf16x8 qf[NS], dof[NS];
-  load_row_frags<HD>(qf, p.q + b * p.q_bs + h * p.q_hs, p.q_rs, qrow, p.sq, lane);
-  load_row_frags<HD>(dof, p.dO + b * p.o_bs + h * p.o_hs, p.o_rs, qrow, p.sq, lane);
+  load_row_frags<HD>(qf, p.q + b * p.q_bs + h * p.q_hs, p.q_rs, qrow, p.sq, lane, p.hd);
+  load_row_frags<HD>(dof, p.dO + b * p.o_bs + h * p.o_hs, p.o_rs, qrow, p.sq, lane, p.hd);
   float sc = p.scale;
   if (p.scale_q_bf16) {
     scale_frags_bf16(qf, p.scale);
@@ -823,7 +824,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const AttnArgs p) 
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
         const int col = d * 32 + 8 * q4 + 4 * (lane >> 5);
-        if (col < HD) {
+        if (col < p.hd) {
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = dqacc[d][4 * q4 + e] * p.scale;
@@ -850,10 +851,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_res_kernel(const AttnArgs p)
   float* sl = (float*)rsm;                                                  // [lse*log2e | delta] x qrows
   char* dl = rsm + ((2 * qrows * 4 + 1023) / 1024) * 1024;                  // dO [sq][192 B] (its b128 reads are 4-way conflicted: accepted)
   char* ql = dl + (((long long)p.sq * 192 + 1023) / 1024) * 1024;           // Q  [sq][208 B]
-  const __amdgpu_buffer_rsrc_t qsrc = make_rsrc(p.q + b * p.q_bs + h * p.q_hs, (uint32_t)(((long long)(p.sq - 1) * p.q_rs + HD) * 2));
-  const __amdgpu_buffer_rsrc_t dosrc = make_rsrc(p.dO + b * p.o_bs + h * p.o_hs, (uint32_t)(((long long)(p.sq - 1) * p.o_rs + HD) * 2));
-  dma_rows<HD, ROWB>(qsrc, ql, p.sq, p.q_rs, wave, nwaves, lane);
-  dma_rows<HD, 192>(dosrc, dl, p.sq, p.o_rs, wave, nwaves, lane);
+  const __amdgpu_buffer_rsrc_t qsrc = make_rsrc(p.q + b * p.q_bs + h * p.q_hs, (uint32_t)(((long long)(p.sq - 1) * p.q_rs + p.hd) * 2));
+  const __amdgpu_buffer_rsrc_t dosrc = make_rsrc(p.dO + b * p.o_bs + h * p.o_hs, (uint32_t)(((long long)(p.sq - 1) * p.o_rs + p.hd) * 2));
+  dma_rows<HD, ROWB>(qsrc, ql, p.sq, p.q_rs, wave, nwaves, lane, p.hd);
+  dma_rows<HD, 192>(dosrc, dl, p.sq, p.o_rs, wave, nwaves, lane, p.hd);
   for (int r = tid; r < qrows; r += blockDim.x) {   // lse pre-multiplied by log2(e): probabilities are 2^(s*c2 - lse2)
     sl[r] = r < p.sq ? p.lse[(long long)bh * p.sq + r] * 1.4426950408889634f : 1e30f;
     sl[qrows + r] = r < p.sq ? p.delta[(long long)bh * p.sq + r] : 0.f;
@@ -861,8 +862,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_res_kernel(const AttnArgs p)
   const int k0 = (blockIdx.x * nwaves + wave) * 32;
   const int krow = k0 + (lane & 31);
   bf16x8 kf[NS], vf[NS];
-  load_row_frags<HD>(kf, p.k + b * p.k_bs + h * p.k_hs, p.k_rs, krow, p.sk, lane);
-  load_row_frags<HD>(vf, p.v + b * p.v_bs + h * p.v_hs, p.v_rs, krow, p.sk, lane);
+  load_row_frags<HD>(kf, p.k + b * p.k_bs + h * p.k_hs, p.k_rs, krow, p.sk, lane, p.hd);
+  load_row_frags<HD>(vf, p.v + b * p.v_bs + h * p.v_hs, p.v_rs, krow, p.sk, lane, p.hd);
   const float sc = p.scale_q_bf16 ? 1.0f : p.scale;
   const float c2 = sc * 1.4426950408889634f;
   const bool kok = krow < p.sk;
@@ -948,7 +949,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_res_kernel(const AttnArgs p)
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
         const int col = d * 32 + 8 * q4 + 4 * (lane >> 5);
-        if (col < HD) {
+        if (col < p.hd) {
           f32x4 a, c2;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -1079,6 +1080,7 @@ int fill_args(AttnArgs& a, const mpv_attn_desc* d) {
   a.heads = d->heads;
   a.sq = d->sq;
   a.sk = d->sk;
+  a.hd = d->head_dim;
   a.causal = d->causal;
   a.scale = d->scale;
   a.scale_q_bf16 = d->scale_q_bf16;
@@ -1092,8 +1094,8 @@ int fill_args(AttnArgs& a, const mpv_attn_desc* d) {
 int check_desc(const mpv_attn_desc* d, const char* who) {
   MPV_REQUIRE(d && d->q && d->k && d->v && d->o, MPV_E_ARG, "%s: null pointer", who);
   MPV_REQUIRE(d->batch > 0 && d->heads > 0 && d->sq > 0 && d->sk > 0, MPV_E_SHAPE, "%s: empty problem", who);
-  MPV_REQUIRE(d->head_dim == 64 || d->head_dim == 80 || d->head_dim == 96, MPV_E_SHAPE,
-              "%s: head_dim %d not in {64,80,96}", who, d->head_dim);
+  MPV_REQUIRE(d->head_dim >= 8 && d->head_dim <= 96 && d->head_dim % 8 == 0, MPV_E_SHAPE,
+              "%s: head_dim %d must be a multiple of 8 in [8, 96]", who, d->head_dim);
   MPV_REQUIRE(d->q_rs % 8 == 0 && d->k_rs % 8 == 0 && d->v_rs % 8 == 0 && d->o_rs % 4 == 0 && d->q_hs % 8 == 0 &&
                   d->k_hs % 8 == 0 && d->v_hs % 8 == 0 && d->o_hs % 4 == 0 && d->q_bs % 8 == 0 && d->k_bs % 8 == 0 &&
                   d->v_bs % 8 == 0 && d->o_bs % 4 == 0,
@@ -1137,7 +1139,7 @@ extern "C" int mpv_attn_fwd(const mpv_attn_desc* d, hipStream_t stream) {
     const int gy = (d->batch + 7) / 8 * 8 * d->heads;   // decode_bh() needs whole groups of 8 sequences
     dim3 grid((d->sq + 32 * nw - 1) / (32 * nw), gy), block(64 * nw);
     const size_t lds = res_lds_bytes(d->sk, false);
-    switch (d->head_dim) {
+    switch (d->head_dim <= 64 ? 64 : d->head_dim <= 80 ? 80 : 96) {
       case 64: hipLaunchKernelGGL((attn_fwd_res_kernel<64>), grid, block, lds, stream, a); break;
       case 80: hipLaunchKernelGGL((attn_fwd_res_kernel<80>), grid, block, lds, stream, a); break;
       default: hipLaunchKernelGGL((attn_fwd_res_kernel<96>), grid, block, lds, stream, a); break;
@@ -1146,7 +1148,7 @@ extern "C" int mpv_attn_fwd(const mpv_attn_desc* d, hipStream_t stream) {
   }
   const int nw = waves_for(d->sq);
   dim3 grid((d->sq + 32 * nw - 1) / (32 * nw), d->batch * d->heads), block(64 * nw);
-  switch (d->head_dim) {
+  switch (d->head_dim <= 64 ? 64 : d->head_dim <= 80 ? 80 : 96) {
     case 64: hipLaunchKernelGGL((attn_fwd_kernel<64>), grid, block, 0, stream, a); break;
     case 80: hipLaunchKernelGGL((attn_fwd_kernel<80>), grid, block, 0, stream, a); break;
     default: hipLaunchKernelGGL((attn_fwd_kernel<96>), grid, block, 0, stream, a); break;
@@ -1174,7 +1176,7 @@ extern "C" int mpv_attn_bwd(const mpv_attn_desc* d, const void* dO, void* dq, vo
     const int gy = (d->batch + 7) / 8 * 8 * d->heads;
     dim3 gq((d->sq + 32 * nw - 1) / (32 * nw), gy), gk((d->sk + 127) / 128, gy);
     const size_t lq = res_lds_bytes(d->sk, false), lk = res_lds_bytes(d->sq, true);
-    switch (d->head_dim) {
+    switch (d->head_dim <= 64 ? 64 : d->head_dim <= 80 ? 80 : 96) {
       case 64:
         hipLaunchKernelGGL((attn_bwd_dq_res_kernel<64>), gq, dim3(64 * nw), lq, stream, a);
         hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<64>), gk, dim3(256), lk, stream, a);
@@ -1193,7 +1195,7 @@ extern "C" int mpv_attn_bwd(const mpv_attn_desc* d, const void* dO, void* dq, vo
   const int nwq = waves_for(d->sq), nwk = 4;   // dK/dV keeps 4 waves (its accumulators need > 256 VGPRs at 8)
   dim3 gq((d->sq + 32 * nwq - 1) / (32 * nwq), d->batch * d->heads), gk((d->sk + 32 * nwk - 1) / (32 * nwk), d->batch * d->heads);
   dim3 bq(64 * nwq), bk(64 * nwk);
-  switch (d->head_dim) {
+  switch (d->head_dim <= 64 ? 64 : d->head_dim <= 80 ? 80 : 96) {
     case 64:
       hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), gq, bq, 0, stream, a);
       hipLaunchKernelGGL((attn_bwd_dkv_kernel<64>), gk, bk, 0, stream, a);

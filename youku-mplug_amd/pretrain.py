@@ -25,8 +25,8 @@ class _StepFn(torch.autograd.Function):
     """Bridges the explicit forward/backward pipeline into autograd (one node per step)."""
 
     @staticmethod
-    def forward(ctx, anchor, model, video, ids, mask):
-        loss, tape = model._forward_pipeline(video, ids, mask)
+    def forward(ctx, anchor, model, video, ids, mask, prompt_lengths=None):
+        loss, tape = model._forward_pipeline(video, ids, mask, prompt_lengths=prompt_lengths)
         ctx.model, ctx.tape = model, tape
         return loss
 
@@ -34,7 +34,7 @@ class _StepFn(torch.autograd.Function):
     def backward(ctx, grad_loss):
         ctx.model._backward_pipeline(ctx.tape, grad_loss.contiguous().float())
         ctx.tape = None
-        return torch.zeros(1, device=grad_loss.device), None, None, None, None
+        return torch.zeros(1, device=grad_loss.device), None, None, None, None, None
 
 
 class DistributedGPT3_Pretrain(nn.Module):
@@ -47,11 +47,7 @@ class DistributedGPT3_Pretrain(nn.Module):
             visual_cfg = json.load(open(config["visual_cfg"], "r"))                       # :36
         if text_cfg is None:
             text_cfg = GPT3Config.from_json_file(config["text_cfg"])                      # :37
-        self.visual_encoder = TimeSformer(
-            img_size=visual_cfg["img_size"], num_frames=visual_cfg["num_frames"], patch_size=visual_cfg["patch_size"],
-            embed_dim=visual_cfg["embed_dim"], depth=visual_cfg["depth"], num_heads=visual_cfg["num_heads"],
-            mlp_ratio=visual_cfg["mlp_ratio"], eps=1e-6, init_std=0.015, clip_model=visual_cfg.get("clip_model", False),
-            device=device)                                                                # :39-54
+        self.visual_encoder = self._build_visual_encoder(config, visual_cfg, device)
         if config.get("text_decoder") and not config.get("_synthetic", False):
             self.text_decoder = DistributedGPT3(model_dir=config["text_decoder"], device=device)          # :78-84
         else:
@@ -82,11 +78,18 @@ class DistributedGPT3_Pretrain(nn.Module):
         self._anchor = torch.zeros(1, device=device, requires_grad=True)
         self.on_stage_grads_ready = None      # engine hook(stage_name)
 
+    def _build_visual_encoder(self, config, visual_cfg, device):
+        return TimeSformer(
+            img_size=visual_cfg["img_size"], num_frames=visual_cfg["num_frames"], patch_size=visual_cfg["patch_size"],
+            embed_dim=visual_cfg["embed_dim"], depth=visual_cfg["depth"], num_heads=visual_cfg["num_heads"],
+            mlp_ratio=visual_cfg["mlp_ratio"], eps=1e-6, init_std=0.015, clip_model=visual_cfg.get("clip_model", False),
+            device=device)                                                                # :39-54
+
     def no_weight_decay(self):
         return {"visual_encoder.pos_embed", "visual_encoder.cls_token", "visual_encoder.temporal_embed"}       # :224-226
 
     # ---------------------------------------------------------------- pipeline
-    def _forward_pipeline(self, video, ids, mask, want_logits=False):
+    def _forward_pipeline(self, video, ids, mask, want_logits=False, prompt_lengths=None):
         B = video.shape[0]
         Q, Hh = self.num_learnable_token, self.text_width
         tape = {"vit": {}, "pool": {}, "gpt": {}}
@@ -98,7 +101,12 @@ class DistributedGPT3_Pretrain(nn.Module):
         # targets / loss mask exactly as :142-159 (filler id 100 is always masked)
         targets = torch.cat([ids[:, 1:], ids[:, 1:2]], dim=1)
         targets = torch.cat([torch.full((B, Q), 100, dtype=torch.long, device=ids.device), targets], dim=1)
-        loss_mask = torch.cat([torch.zeros((B, Q), dtype=torch.long, device=ids.device), mask[:, 1:]], dim=1)
+        tla = mask[:, 1:]
+        if prompt_lengths is not None:                                                    # models/distributed_gpt3.py:348-351
+            pl = torch.as_tensor(prompt_lengths, device=ids.device).view(-1, 1)
+            tla = tla.clone()
+            tla[torch.arange(tla.shape[1], device=ids.device)[None] < pl] = 0
+        loss_mask = torch.cat([torch.zeros((B, Q), dtype=torch.long, device=ids.device), tla], dim=1)
         out = self.text_decoder.forward_lm(qf, ids, targets, loss_mask, tape["gpt"], want_logits=want_logits)
         tape["out"] = out
         return out["loss"], tape
@@ -130,6 +138,44 @@ class DistributedGPT3_Pretrain(nn.Module):
         """Evaluation helper: full decoder outputs (logits, losses, last_hidden_state, loss)."""
         _, tape = self._forward_pipeline(image, text.input_ids, text.attention_mask, want_logits=True)
         return SimpleNamespace(**tape["out"])
+
+
+class DistributedGPT3_Pretrain_Image(DistributedGPT3_Pretrain):
+    """models/distributed_gpt3.py:229-427 with use_eva_g: the EVA-ViT-g image encoder in front of the same abstractor and
+    frozen decoder; forward(image [B,3,H,W], text) -> (loss_caption, loss_contrastive); `text.prompt_lengths`, when
+    present, is masked out of the caption loss (:348-351)."""
+
+    def _build_visual_encoder(self, config, visual_cfg, device):
+        from .eva_vit import create_eva_vit_g
+        if not config.get("use_eva_g", False):
+            raise NotImplementedError("the image path is built for use_eva_g: true (models/distributed_gpt3.py:256-261)")
+        over = {k: visual_cfg[k] for k in ("embed_dim", "depth", "num_heads", "mlp_ratio", "patch_size") if k in visual_cfg
+                and config.get("_synthetic", False)}
+        return create_eva_vit_g(img_size=visual_cfg["img_size"], drop_path_rate=visual_cfg.get("drop_path", False) or 0.0,
+                                device=device, **over)
+
+    def no_weight_decay(self):
+        return {"visual_encoder.pos_embed", "visual_encoder.cls_token"}                      # :425-427
+
+    def forward(self, image, text):
+        ids, mask = text.input_ids, text.attention_mask
+        pl = getattr(text, "prompt_lengths", None)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            loss = _StepFn.apply(self._anchor, self, image, ids, mask, pl)
+        else:
+            loss, _ = self._forward_pipeline(image, ids, mask, prompt_lengths=pl)
+        return loss, torch.zeros((), device=loss.device)
+
+
+def synthetic_image_model(shapes, device="cuda", **eva) -> "DistributedGPT3_Pretrain_Image":
+    """Random-init image model; `eva` overrides (embed_dim, depth, num_heads, mlp_ratio, patch_size) for reduced shapes."""
+    vis = dict(img_size=shapes.img_size, num_frames=1, embed_dim=eva.get("embed_dim", 1408), num_heads=eva.get("num_heads", 16),
+               mlp_ratio=eva.get("mlp_ratio", 4.3637), depth=eva.get("depth", 40), patch_size=eva.get("patch_size", 14))
+    txt = GPT3Config(vocab_size=shapes.vocab, hidden_size=shapes.hidden, ffn_hidden_size=shapes.ffn,
+                     num_hidden_layers=shapes.layers, num_attention_heads=shapes.heads, max_position_embeddings=shapes.max_pos,
+                     layernorm_epsilon=shapes.gpt_ln_eps)
+    return DistributedGPT3_Pretrain_Image({"num_learnable_token": shapes.num_queries, "_synthetic": True, "use_eva_g": True},
+                                          visual_cfg=vis, text_cfg=txt, device=device)
 
 
 def synthetic_model(shapes, device="cuda", num_frames=None) -> DistributedGPT3_Pretrain:

@@ -113,7 +113,7 @@ class TimeSformer(nn.Module):
                  mlp_ratio=4.0, eps=1e-6, init_std=0.015, clip_model=True, device=None, **_):
         super().__init__()
         D = embed_dim
-        assert (D // num_heads) in (64, 80, 96), "fused attention kernels are built for head_dim 64/80/96"
+        assert (D // num_heads) % 8 == 0 and D // num_heads <= 96, "fused attention kernels take head_dim = multiple of 8, <= 96"
         self.embed_dim = self.num_features = D
         self.num_frames, self.num_heads, self.depth = num_frames, num_heads, depth
         self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, D, bias=not clip_model, std=init_std, device=device)
