@@ -196,6 +196,18 @@ int mpv_gather_rows(const void* src, const int64_t* idx, void* dst, int64_t rows
  * carries gradient: the prompt pass of cls_head, models/distributed_gpt3.py:583-585, 1149-1151) */
 int mpv_scatter_rows(const void* src, const int64_t* idx, void* dst, int64_t rows, int64_t cols, int64_t ld,
                      mpv_stream_t stream);
+/* ------------------------------------------------------------------------------------------
+ * Generation (KV-cache decode, models/modeling_distributed_gpt3.py:1620-1886).  The forward kernels above serve
+ * prefill and the single-row decode steps (mpv_attn_fwd with sq = 1 over the cached keys); two helpers:
+ * dst[r][0:cols] = src[idx[r]][0:cols] with row pitches lds / ldd: the beam re-order of a layer's KV cache
+ * (InferenceParams.swap_key_value_dict :1459-1473). */
+int mpv_gather_rows_ld(const void* src, const int64_t* idx, void* dst, int64_t rows, int64_t cols, int64_t lds, int64_t ldd,
+                       mpv_stream_t stream);
+/* out_val[r][j], out_idx[r][j] = the j-th largest of log_softmax(logits[r]) + add[r] (add optional), fp32 statistics over
+ * bf16 logits, ties broken towards the lower index; k <= 64.  Serves beam_search (:1790-1805: log_softmax, + scores,
+ * sort, top 2*beam) and greedy sample (:1411-1413, k = 1). */
+int mpv_logprob_topk(const void* logits, const float* add, int64_t rows, int64_t vocab, int64_t ld, int k, float* out_val,
+                     int64_t* out_idx, mpv_stream_t stream);
 /* Soft-target contrastive cross-entropy over fp32 similarities sim[rows][cols] (:966-978):
  * targets[i][j] = [row_ids[i]==col_ids[j]] / count_i; losses[i] = -sum_j log_softmax(sim_i)[j] targets[i][j];
  * dsim (bf16, optional) = (softmax - targets) * scale; dts[i] (optional) = sum_j dsim[i][j] * sim[i][j]. */

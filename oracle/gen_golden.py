@@ -202,6 +202,38 @@ def run_eva(name: str = "eva_tiny"):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def run_caption(name: str = "caption_tiny"):
+    """DistributedGPT3_Caption.generate (beam 5, KV-cache decode) on the tiny config:
+    best sequence + score per sample, plus the per-step logits of a teacher-forced decode for the cache-path check."""
+    import types
+    from .ref_loader import build_reference_caption, cpu_generation_patches
+    cfg = CONFIG_TINY
+    rec = {"meta": dict(case=name, batch=2, text_len=6, weight_seed=6, input_seed=8, tokens_to_generate=12, eod_id=7, torch=str(torch.__version__))}
+    for tag, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        model, sd = build_reference_caption(cfg, 6, dtype=dtype, tokens_to_generate=12, eod_id=7)
+        video, ids, mask = make_inputs(cfg, 2, 6, seed=8, ragged=False)
+        mask[1, 4:] = 0
+        text = types.SimpleNamespace(input_ids=ids, attention_mask=mask, prompt_lengths=torch.tensor([1, 1]))
+        model.eval()
+        captured = []
+        td = model.text_decoder
+        orig = td.beam_search
+
+        def spy(*a, **k):
+            out = orig(*a, **k)
+            captured.append(out)
+            return out
+        td.beam_search = spy
+        with torch.no_grad(), cpu_generation_patches():
+            res = model.generate(video.to(dtype), text)
+        td.beam_search = orig
+        rec[tag] = {"sequences": [r.clone() for r in res], "scores": [c.scores.float().clone() for c in captured]}
+        print(f"[{name}/{tag}] " + " | ".join(f"{r.tolist()} {float(c.scores[0]):.5f}" for r, c in zip(res, captured)), flush=True)
+    path = os.path.join(GOLDEN_DIR, f"{name}.pt")
+    torch.save(rec, path)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     for c in (sys.argv[1:] or ["tiny"]):
         if c.startswith("retrieval"):
@@ -210,5 +242,7 @@ if __name__ == "__main__":
             run_gencls(c)
         elif c.startswith("eva"):
             run_eva(c)
+        elif c.startswith("caption"):
+            run_caption(c)
         else:
             run_case(c)

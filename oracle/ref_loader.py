@@ -228,6 +228,49 @@ def build_reference_image(cfg: PathConfig, seed: int = 0, dtype=torch.float32):
 
 
 @contextlib.contextmanager
+def cpu_generation_patches():
+    """sample()/beam_search() build their bookkeeping tensors on torch.cuda.current_device()
+    (models/modeling_distributed_gpt3.py:864, 1664, 1767): point that at the CPU."""
+    old_cur = torch.cuda.current_device
+    torch.cuda.current_device = lambda: torch.device("cpu")
+    try:
+        yield
+    finally:
+        torch.cuda.current_device = old_cur
+
+
+def build_reference_caption(cfg: PathConfig, seed: int = 0, dtype=torch.float32, tokens_to_generate: int = 12, eod_id: int = 7):
+    """DistributedGPT3_Caption (models/distributed_gpt3.py:661-814) on CPU with seeded weights; generate() = per-sample
+    beam search over the KV-cache decode path."""
+    vt, mg, dg = import_reference()
+    sd = make_state_dict(cfg, seed)
+    tmp = tempfile.mkdtemp(prefix="mpv_oracle_")
+    gcfg = dict(_gpt_config_dict(cfg), tokens_to_generate=tokens_to_generate, eod_id=eod_id)
+    for name, d in (("config.json", gcfg), ("visual.json", _visual_config_dict(cfg)), ("text.json", gcfg)):
+        with open(os.path.join(tmp, name), "w") as f:
+            json.dump(d, f)
+    config = {"visual_cfg": os.path.join(tmp, "visual.json"), "text_cfg": os.path.join(tmp, "text.json"), "text_decoder": tmp,
+              "megatron_cfg": {"world_size": 1, "model_parallel_size": 1, "tensor_model_parallel_size": 1}, "freeze_vit": False,
+              "freeze_text_decoder": True, "num_learnable_token": cfg.num_queries, "num_frames": cfg.num_frames}
+    prefix = "text_decoder.dist_model."
+    gpt_sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    old = mg.pre_load
+    mg.pre_load = lambda *a, **k: gpt_sd
+    tok = types.SimpleNamespace(tokenizer=types.SimpleNamespace(eos=eod_id))
+    try:
+        with _cpu_patches():
+            model = dg.DistributedGPT3_Caption(config=config, tokenizer=tok)
+    finally:
+        mg.pre_load = old
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dtype)
+    for m in model.modules():                 # the KV memory is allocated in params_dtype (:864-871): follow the cast
+        if hasattr(m, "params_dtype"):
+            m.params_dtype = dtype
+    return model, sd
+
+
+@contextlib.contextmanager
 def single_rank_collectives():
     """models/distributed_gpt3.py:962-964 call torch.distributed collectives unconditionally: run them on a
     1-rank gloo group so the reference forward works in a plain process."""

@@ -5,6 +5,7 @@ import ctypes
 import os
 import re
 import sys
+import types
 
 import pytest
 import torch
@@ -302,3 +303,109 @@ def test_restatement_eva_image_model_vs_golden():
     out["loss"].backward()
     for n, gn in f["grad_norm"].items():
         assert abs(sd[n].grad.norm().item() - gn) <= 1e-4 * gn + 1e-9, n
+
+
+# ------------------------------------------------------------------------------ generation host logic
+class _StubLogits:
+    """Deterministic logits as a function of a sequence's token prefix, so the reference's search loops and ours can be
+    driven from the SAME source (the search logic is discrete: it must agree token for token)."""
+
+    def __init__(self, vocab, stop, seed=0):
+        self.vocab, self.stop, self.seed = vocab, stop, seed
+
+    def row(self, prefix):
+        g = torch.Generator().manual_seed((hash(tuple(int(t) for t in prefix)) ^ self.seed) & 0x7FFFFFFF)
+        lg = torch.randn(self.vocab, generator=g) * 2.0
+        lg[self.stop] += 1.0 + 0.35 * len(prefix)          # the stop token becomes likely as the sequence grows
+        return lg
+
+
+def _reference_search(kind, stub, tokens, query_embeds, cfg_over, **kw):
+    """Runs the reference's own DistributedGPT3.beam_search / .sample (models/modeling_distributed_gpt3.py:1620-1873) on a
+    stand-in `self` whose forward returns the stub logits; token prefixes ride in the InferenceParams KV dict so that
+    swap_key_value_dict re-orders them exactly as it re-orders a real cache."""
+    from oracle.ref_loader import cpu_generation_patches, import_reference
+    vt, mg, dg = import_reference()
+    import addict                                                       # oracle/shims (on sys.path after import_reference)
+
+    class Fake:
+        config = types.SimpleNamespace(tokens_to_generate=cfg_over["tokens_to_generate"], eod_id=cfg_over["eod_id"], top_k=1, top_p=0.0,
+                                       max_position_embeddings=cfg_over["max_position_embeddings"], vocab_size=stub.vocab)
+        inference_params = None
+
+        def __call__(self, tokens=None, query_embeds=None, attention_mask=None, position_ids=None):
+            d = self.inference_params.key_value_memory_dict
+            new = tokens.t().contiguous()                               # [n, beams]
+            pre = torch.cat([d[1][0], new], dim=0) if 1 in d else new
+            d[1] = (pre, pre)
+            B, n = tokens.shape
+            lg = torch.zeros(B, max(n, 1) + (0 if query_embeds is None else query_embeds.size(1)), stub.vocab)
+            for b in range(B):
+                lg[b, -1] = stub.row(pre[:, b].tolist())
+            return addict.Dict(logits=lg)
+
+    fake = Fake()
+    with torch.no_grad(), cpu_generation_patches():
+        if kind == "beam":
+            return mg.DistributedGPT3.beam_search(fake, tokens, query_embeds=query_embeds, **kw)
+        return mg.DistributedGPT3.sample(fake, tokens, query_embeds=query_embeds, **kw)
+
+
+class _StubState:
+    def __init__(self, stub, batch, max_len):
+        self.stub, self.prefix = stub, None
+
+    def step(self, tokens, query_embeds=None):
+        new = tokens.t().contiguous()
+        self.prefix = new if self.prefix is None else torch.cat([self.prefix, new], dim=0)
+        return torch.stack([self.stub.row(self.prefix[:, b].tolist()) for b in range(tokens.shape[0])])
+
+    def reorder(self, idx):
+        self.prefix = self.prefix[:, idx]
+
+
+def _torch_topk(logits, k, add):
+    lp = torch.log_softmax(logits.float(), dim=-1) + (add.view(-1, 1) if add is not None else 0.0)
+    v, i = torch.sort(lp, dim=-1, descending=True, stable=True)
+    return v[:, :k], i[:, :k]
+
+
+@pytest.mark.parametrize("Q", [0, 3])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_beam_search_host_logic_matches_reference(seed, Q):
+    """generation.beam_search_loop == the reference's beam_search (same hypotheses bookkeeping, stop-token handling,
+    done test, beam re-ordering, final ranking) when both are fed the same logits -- sequences and scores exact."""
+    from youku_mplug_amd import generation
+    stub = _StubLogits(vocab=37, stop=7, seed=seed)
+    cfgd = dict(tokens_to_generate=9, eod_id=7, max_position_embeddings=64)
+    tokens = torch.tensor([[5, 11, 3, 7, 7]])
+    qe = torch.zeros(1, Q, 4) if Q else None
+    ref = _reference_search("beam", stub, tokens.clone(), qe, cfgd, beam_size=4, num_return_gen=3, prompt_length=torch.tensor(3))
+    cfg = types.SimpleNamespace(**cfgd, top_k=1, top_p=0.0, vocab_size=stub.vocab)
+    out = generation.beam_search_loop(cfg, lambda b, m: _StubState(stub, b, m), tokens.clone(), query_embeds=qe, beam_size=4,
+                                      num_return_gen=3, prompt_length=3, topk_fn=_torch_topk)
+    assert out.sequences.shape == ref.sequences.shape
+    assert torch.equal(out.sequences, ref.sequences), (out.sequences.tolist(), ref.sequences.tolist())
+    assert torch.allclose(out.scores, ref.scores.float().view(-1), atol=1e-5)
+
+
+@pytest.mark.parametrize("Q", [0, 2])
+def test_greedy_sample_host_logic_matches_reference(Q):
+    """generation.sample_loop (top_k = 1) == the reference's sample(): ragged prompt lengths, teacher-forced prompt
+    tokens until `started`, termination bookkeeping and the returned slice."""
+    from youku_mplug_amd import generation
+    stub = _StubLogits(vocab=29, stop=7, seed=9)
+    cfgd = dict(tokens_to_generate=8, eod_id=7, max_position_embeddings=40)
+    tokens = torch.tensor([[5, 11, 3, 2], [4, 9, 7, 7], [6, 6, 6, 1]])
+    lengths = torch.tensor([4, 2, 3])
+    qe = torch.zeros(3, Q, 4) if Q else None
+    ref = _reference_search("sample", stub, tokens.clone(), qe, cfgd, prompt_length=lengths.clone())
+    cfg = types.SimpleNamespace(**cfgd, top_k=1, top_p=0.0, vocab_size=stub.vocab)
+    import youku_mplug_amd.generation as G
+    orig = G.sample_token
+    G.sample_token = lambda logits, **kw: torch.argmax(logits, dim=-1)        # greedy without the device kernel
+    try:
+        out = generation.sample_loop(cfg, lambda b, m: _StubState(stub, b, m), tokens.clone(), query_embeds=qe, prompt_length=lengths.clone())
+    finally:
+        G.sample_token = orig
+    assert torch.equal(out, ref), (out.tolist(), ref.tolist())

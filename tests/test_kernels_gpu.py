@@ -431,3 +431,29 @@ def test_gemm_wgrad_fused_bias_grad(dev):
             dyr, xr = dy.float(), x.float()
         close(dw, dyr.t() @ xr, 1e-2, "dW")
         close(bsum, dyr.sum(0), 1e-2, "fused bias grad")
+
+
+# ------------------------------------------------------------------------------ generation helpers
+@pytest.mark.parametrize("rows,V,k", [(5, 51200, 10), (3, 1024, 6), (1, 8, 1), (4, 200, 64)])
+def test_logprob_topk(dev, rows, V, k):
+    from youku_mplug_amd import ops
+    logits = rn(rows, V, dev=dev, seed=70, scale=3.0)
+    add = torch.arange(rows, device=dev, dtype=torch.float32) * -0.37
+    val, idx = ops.logprob_topk(logits, k, add=add)
+    lp = torch.log_softmax(logits.float(), dim=-1) + add[:, None]
+    rv, ri = torch.sort(lp, dim=-1, descending=True, stable=True)
+    assert torch.allclose(val, rv[:, :k], atol=2e-4, rtol=1e-5)
+    assert torch.equal(lp.gather(1, idx), rv[:, :k])                 # same values even where ties permute indices
+    assert (idx[:, 1:] != idx[:, :-1]).all()
+    ties = rv[:, 1:k + 1] == rv[:, :k] if k < V else torch.zeros(1, dtype=torch.bool)
+    if not ties.any():
+        assert torch.equal(idx, ri[:, :k])
+
+
+def test_gather_rows_ld(dev):
+    from youku_mplug_amd import ops
+    src = rn(5, 96 * 7, dev=dev, seed=71)
+    dst = torch.zeros_like(src)
+    idx = torch.tensor([3, 3, 0, 4, 1], device=dev)
+    ops.gather_rows_ld(src, idx, dst, 5, 96 * 4, 96 * 7, 96 * 7)
+    assert torch.equal(dst[:, :96 * 4], src[idx][:, :96 * 4]) and dst[:, 96 * 4:].abs().max().item() == 0

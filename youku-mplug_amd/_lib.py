@@ -75,6 +75,8 @@ _SIGS = {
     "mpv_l2norm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "mpv_gather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "mpv_scatter_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "mpv_gather_rows_ld": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p]),
+    "mpv_logprob_topk": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "mpv_soft_target_ce": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "mpv_grad_sumsq": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "mpv_adamw_step": (c_int, [c_void_p] * 5 + [c_int64] + [c_float] * 5 + [c_int, c_float, c_void_p, c_float, c_void_p]),

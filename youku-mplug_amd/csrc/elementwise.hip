@@ -358,6 +358,76 @@ __global__ void scatter_rows_kernel(const bf16* __restrict__ src, const int64_t*
     *(bf16x4*)(dst + idx[r] * ld + c4 * 4) = *(const bf16x4*)(src + r * cols + c4 * 4);
   }
 }
+// ---------------------------------------------------------------- generation (KV-cache decode)
+// beam re-order of a KV cache (InferenceParams.swap_key_value_dict, models/modeling_distributed_gpt3.py:1459-1473):
+// dst[r][0:cols] = src[idx[r]][0:cols] with separate source / destination row pitches
+__global__ void gather_rows_ld_kernel(const bf16* __restrict__ src, const int64_t* __restrict__ idx, bf16* __restrict__ dst,
+                                      long long rows, long long cols, long long lds, long long ldd) {
+  const long long C8 = cols / 8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < rows * C8; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / C8, c8 = i - r * C8;
+    *(bf16x8*)(dst + r * ldd + c8 * 8) = *(const bf16x8*)(src + idx[r] * lds + c8 * 8);
+  }
+}
+// log_softmax(logits[r]) + add[r], then the k largest entries of the row (descending; ties -> lower index first).
+// One workgroup per row: fp32 max / sum-exp over the bf16 row, then k rounds of a block-wide arg-max over the
+// entries that come after the previous winner in (value desc, index asc) order.  k <= 64.
+__global__ __launch_bounds__(256) void logprob_topk_kernel(const bf16* __restrict__ logits, const float* __restrict__ add, int k,
+                                                           float* __restrict__ out_val, int64_t* __restrict__ out_idx, int vocab,
+                                                           long long ld) {
+  __shared__ float redf[4];
+  __shared__ int redi[4];
+  __shared__ float bestv;
+  __shared__ int besti;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bf16* row = logits + (long long)blockIdx.x * ld;
+  float mx = -INFINITY;
+  for (int c = tid; c < vocab; c += 256) mx = fmaxf(mx, bf2f(row[c]));
+  mx = wave_max(mx);
+  if (lane == 0) redf[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+  __syncthreads();
+  float se = 0.f;
+  for (int c = tid; c < vocab; c += 256) se += __expf(bf2f(row[c]) - mx);
+  se = wave_sum(se);
+  if (lane == 0) redf[wave] = se;
+  __syncthreads();
+  const float lse = mx + __logf((redf[0] + redf[1]) + (redf[2] + redf[3])) - (add ? add[blockIdx.x] : 0.f);
+  float pv = INFINITY;
+  int pi = -1;
+  for (int j = 0; j < k; ++j) {
+    __syncthreads();
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = tid; c < vocab; c += 256) {
+      const float v = bf2f(row[c]);
+      const bool after = v < pv || (v == pv && c > pi);          // not yet taken
+      if (after && (v > bv || (v == bv && c < bi))) { bv = v; bi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { redf[wave] = bv; redi[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      float v = redf[0];
+      int i = redi[0];
+      for (int w = 1; w < 4; ++w)
+        if (redf[w] > v || (redf[w] == v && redi[w] < i)) { v = redf[w]; i = redi[w]; }
+      bestv = v;
+      besti = i;
+      out_val[(long long)blockIdx.x * k + j] = v - lse;
+      out_idx[(long long)blockIdx.x * k + j] = i;
+    }
+    __syncthreads();
+    pv = bestv;
+    pi = besti;
+  }
+}
 // Soft-target contrastive CE (models/distributed_gpt3.py:966-978): targets[i][j] = [ids_r[i]==ids_c[j]] / count_i;
 // loss_i = -sum_j log_softmax(sim_i)[j] * targets[i][j];  dsim = (softmax - targets) * scale (bf16);
 // dts[i] = sum_j dsim[i][j] * sim[i][j] (for the temperature gradient).  One wave per row.
@@ -562,6 +632,25 @@ extern "C" int mpv_scatter_rows(const void* src, const int64_t* idx, void* dst, 
   hipLaunchKernelGGL(scatter_rows_kernel, dim3(ew_grid(rows * (cols / 4))), dim3(256), 0, stream, (const bf16*)src, idx, (bf16*)dst,
                      (long long)rows, (int)cols, (long long)ld);
   return mpv_check_launch("mpv_scatter_rows");
+}
+
+extern "C" int mpv_gather_rows_ld(const void* src, const int64_t* idx, void* dst, int64_t rows, int64_t cols, int64_t lds,
+                                  int64_t ldd, hipStream_t stream) {
+  MPV_REQUIRE(src && idx && dst, MPV_E_ARG, "mpv_gather_rows_ld: null pointer");
+  MPV_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && lds % 8 == 0 && ldd % 8 == 0, MPV_E_SHAPE, "mpv_gather_rows_ld: bad shape");
+  MPV_REQUIRE((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, MPV_E_ALIGN, "mpv_gather_rows_ld: buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(gather_rows_ld_kernel, dim3(ew_grid(rows * (cols / 8))), dim3(256), 0, stream, (const bf16*)src, idx, (bf16*)dst,
+                     (long long)rows, (long long)cols, (long long)lds, (long long)ldd);
+  return mpv_check_launch("mpv_gather_rows_ld");
+}
+
+extern "C" int mpv_logprob_topk(const void* logits, const float* add, int64_t rows, int64_t vocab, int64_t ld, int k,
+                                float* out_val, int64_t* out_idx, hipStream_t stream) {
+  MPV_REQUIRE(logits && out_val && out_idx, MPV_E_ARG, "mpv_logprob_topk: null pointer");
+  MPV_REQUIRE(rows > 0 && vocab > 0 && k > 0 && k <= 64 && k <= vocab, MPV_E_SHAPE, "mpv_logprob_topk: need 0 < k <= min(64, vocab)");
+  hipLaunchKernelGGL(logprob_topk_kernel, dim3((unsigned)rows), dim3(256), 0, stream, (const bf16*)logits, add, k, out_val, out_idx,
+                     (int)vocab, (long long)ld);
+  return mpv_check_launch("mpv_logprob_topk");
 }
 
 extern "C" int mpv_soft_target_ce(const float* sim, const int64_t* row_ids, const int64_t* col_ids, float scale, float* losses,

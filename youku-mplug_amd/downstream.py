@@ -214,6 +214,36 @@ class DistributedGPT3_Retrieval_Cls(_GenCls):
         return self._run(image, text, prompt_text, negative_indices, labels, train)
 
 
+class DistributedGPT3_Caption(_GenCls):
+    """models/distributed_gpt3.py:661-814: caption fine-tuning loss (prompt tokens masked out) and beam-search
+    captioning on the KV-cache decode path (generation.py)."""
+    ITM = False
+
+    def forward(self, image, text=None):
+        return self._run(image, text, None, None, None, True)[0]                              # :768-789 returns loss_caption only
+
+    @torch.no_grad()
+    def generate(self, image, text, termination_id=None, **kw):
+        """One beam search per sample (:790-809): prompt = text.input_ids[i, :mask.sum()-1], prefix = its query features."""
+        Bv = image.shape[0]
+        Q, Hh = self.num_learnable_token, self.text_width
+        was = self.training
+        self.eval()
+        try:
+            qf = self._query_features(image, {"vit": {}, "pool": {}}).view(Bv, Q, Hh)
+            if termination_id is None:
+                tok = getattr(self, "tokenizer", None)
+                termination_id = tok.tokenizer.eos if tok is not None else None
+            res = []
+            for i in range(text.input_ids.shape[0]):
+                out = self.text_decoder.generate(text.input_ids[i:i + 1], query_embeds=qf[i:i + 1], termination_id=termination_id,
+                                                 do_sample=False, prompt_length=int(text.attention_mask.sum(-1)[i]) - 1, **kw)
+                res.append(out.sequences.cpu())
+            return res
+        finally:
+            self.train(was)
+
+
 def synthetic_gencls_model(shapes, kind: str, num_classes: int = 2, device="cuda", num_frames=None):
     """Random-init ITM ("itm") or classification ("cls") model from a PathConfig-like shapes object."""
     vis = dict(img_size=shapes.img_size, patch_size=shapes.patch_size, depth=shapes.vit_depth,
@@ -222,6 +252,6 @@ def synthetic_gencls_model(shapes, kind: str, num_classes: int = 2, device="cuda
     txt = GPT3Config(vocab_size=shapes.vocab, hidden_size=shapes.hidden, ffn_hidden_size=shapes.ffn,
                      num_hidden_layers=shapes.layers, num_attention_heads=shapes.heads, max_position_embeddings=shapes.max_pos,
                      layernorm_epsilon=shapes.gpt_ln_eps)
-    klass = DistributedGPT3_Retrieval_Cls if kind == "itm" else DistributedGPT3_Cls
-    return klass({"num_learnable_token": shapes.num_queries, "_synthetic": True, "use_cls": True, "num_classes": num_classes},
+    klass = {"itm": DistributedGPT3_Retrieval_Cls, "cls": DistributedGPT3_Cls, "caption": DistributedGPT3_Caption}[kind]
+    return klass({"num_learnable_token": shapes.num_queries, "_synthetic": True, "use_cls": kind != "caption", "num_classes": num_classes},
                  visual_cfg=vis, text_cfg=txt, device=device)

@@ -1,0 +1,298 @@
+"""KV-cache generation on the gfx950 kernels -- the inference half of models/modeling_distributed_gpt3.py
+(InferenceParams :1444-1473, sample :1398-1441 / :1620-1735, beam_search :1737-1873, BeamHypotheses :1908-1960)
+and DistributedGPT3_Caption.generate (models/distributed_gpt3.py:790-809).
+
+Layout: one cache per layer, cache[l] = [beams, max_len, 3H] bf16 in the decoder's own head-interleaved q|k|v row
+format -- the qkv GEMM of every new position writes its row straight into the cache through the GEMM's C row map, and
+the fused attention reads K/V from it with (batch, head, row) strides; nothing is transposed or copied (the reference
+keeps [max_s, b, np, hn] K and V tensors and copies into them, :905-915).  A step processes the n new positions of
+every sequence (prefill: the visual prefix + prompt; afterwards one token), attends causally over the cached rows and
+runs the LM head on the last position only.  Beam re-ordering (swap_key_value_dict) is one strided row gather per
+layer into the twin buffer.  The search logic itself stays on the host, as in the reference.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Callable, List, Optional
+
+import torch
+
+from . import ops
+from .ops import ACT_GELU_TANH
+
+
+class BeamHypotheses:
+    """models/modeling_distributed_gpt3.py:1908-1960 (length_penalty 1.0, early_stopping False as constructed at :1763)."""
+
+    def __init__(self, num_beams: int, length_penalty: float = 1.0, early_stopping: bool = False):
+        self.length_penalty, self.early_stopping, self.num_beams = length_penalty, early_stopping, num_beams
+        self.beams: List[tuple] = []
+        self.worst_score = 1e9
+
+    def __len__(self):
+        return len(self.beams)
+
+    def add(self, hyp: torch.Tensor, sum_logprobs: float, beam_indices=None):
+        score = sum_logprobs / (hyp.shape[-1] ** self.length_penalty)                      # :1936
+        if len(self) < self.num_beams or score > self.worst_score:
+            self.beams.append((score, hyp, beam_indices))
+            if len(self) > self.num_beams:
+                order = sorted([(s, i) for i, (s, _, _) in enumerate(self.beams)])
+                del self.beams[order[0][1]]
+                self.worst_score = order[1][0]
+            else:
+                self.worst_score = min(score, self.worst_score)
+
+    def is_done(self, best_sum_logprobs: float, cur_len: int) -> bool:
+        if len(self) < self.num_beams:
+            return False
+        if self.early_stopping:
+            return True
+        return self.worst_score >= best_sum_logprobs / cur_len ** self.length_penalty        # :1958-1960
+
+
+class DecodeState:
+    """Per-generation KV caches of a DistributedGPT3 (the InferenceParams of :1444-1473)."""
+
+    def __init__(self, gpt, batch: int, max_len: int):
+        cfg = gpt.config
+        self.gpt, self.batch, self.max_len = gpt, batch, max_len
+        self.H, self.np_, self.hn, self.V = cfg.hidden_size, cfg.num_attention_heads, cfg.kv_channels, cfg.vocab_size
+        dev = gpt.dist_model.language_model.embedding.word_embeddings.weight.device
+        nl = len(gpt.dist_model.language_model.encoder.layers)
+        shape = (nl, batch * max_len, 3 * self.H)
+        self.cache = torch.zeros(shape, dtype=torch.bfloat16, device=dev)
+        self.twin = None                      # allocated on the first beam re-order
+        self.pos = 0                          # rows cached so far (per sequence)
+
+    # ------------------------------------------------------------------ one incremental forward
+    def step(self, tokens: Optional[torch.Tensor], query_embeds: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """tokens [B, n_tok] int64 (may be None/empty only with query_embeds), query_embeds [B, Q, H] for the first
+        call.  Appends Q + n_tok positions per sequence and returns the logits of the last one: [B, V] bf16."""
+        gpt, B, H, np_, hn, V, Smax = self.gpt, self.batch, self.H, self.np_, self.hn, self.V, self.max_len
+        lm = gpt.dist_model.language_model
+        qf = None if query_embeds is None else query_embeds.reshape(-1, H).to(torch.bfloat16).contiguous()
+        Q = 0 if qf is None else qf.shape[0] // B
+        L = 0 if tokens is None else tokens.shape[1]
+        n, pos0 = Q + L, self.pos
+        assert n > 0 and pos0 + n <= Smax, (n, pos0, Smax)
+        ids = tokens.contiguous() if L else torch.zeros((B, 0), dtype=torch.long, device=self.cache.device)
+        wpe = lm.embedding.position_embeddings.weight[pos0:]
+        h = ops.gpt_embed_fwd(qf, ids, lm.embedding.word_embeddings.weight, wpe, B, Q, L, H)
+        R = B * n
+        st3 = (Smax * 3 * H, 3 * hn, 3 * H)
+        lay = ops.AttnLayout(st3, st3, st3, (n * H, hn, H))
+        scale = 1.0 / math.sqrt(hn)
+        for li, layer in enumerate(lm.encoder.layers):
+            att, mlp = layer.self_attention, layer.mlp
+            c = self.cache[li]
+            x1, _, _ = ops.layernorm_fwd(h, layer.input_layernorm.weight, layer.input_layernorm.bias, layer.input_layernorm.eps, R, H,
+                                         want_stats=False)
+            ops.gemm(x1, att.query_key_value.weight, R, 3 * H, H, bias=att.query_key_value.bias, out=c, cmap=(n, Smax, pos0))
+            ctx = torch.empty((R, H), dtype=torch.bfloat16, device=h.device)
+            ops.attn_fwd(c[pos0:], c[:, hn:], c[:, 2 * hn:], ctx, lay, B, np_, n, pos0 + n, hn, causal=True, scale=scale)
+            h1 = ops.gemm(ctx, att.dense.weight, R, H, H, bias=att.dense.bias, residual=h)
+            x2, _, _ = ops.layernorm_fwd(h1, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.bias,
+                                         layer.post_attention_layernorm.eps, R, H, want_stats=False)
+            F4 = mlp.dense_h_to_4h.out_features
+            g = ops.gemm(x2, mlp.dense_h_to_4h.weight, R, F4, H, bias=mlp.dense_h_to_4h.bias, act=ACT_GELU_TANH)
+            h = ops.gemm(g, mlp.dense_4h_to_h.weight, R, H, F4, bias=mlp.dense_4h_to_h.bias, residual=h1)
+        self.pos = pos0 + n
+        if n > 1:       # LM head on the last position of every sequence only
+            rows = (torch.arange(B, device=h.device) * n + (n - 1)).contiguous()
+            h = ops.gather_rows(h, rows, B, H)
+        fl = lm.encoder.final_layernorm
+        xf, _, _ = ops.layernorm_fwd(h, fl.weight, fl.bias, fl.eps, B, H, want_stats=False)
+        Vp = (V + 7) // 8 * 8
+        assert Vp == V, "vocab_size must be a multiple of 8"
+        return ops.gemm(xf, lm.embedding.word_embeddings.weight, B, V, H)
+
+    def reorder(self, batch_idx: torch.Tensor):
+        """swap_key_value_dict(:1459-1473): sequence j continues from the cache of sequence batch_idx[j]."""
+        if self.twin is None:
+            self.twin = torch.empty_like(self.cache)
+        cols = self.pos * 3 * self.H
+        pitch = self.max_len * 3 * self.H
+        idx = batch_idx.to(torch.int64).contiguous()
+        for li in range(self.cache.shape[0]):
+            ops.gather_rows_ld(self.cache[li], idx, self.twin[li], self.batch, cols, pitch, pitch)
+        self.cache, self.twin = self.twin, self.cache
+
+
+# ---------------------------------------------------------------------------------------------- sampling helpers
+def _filter_top_k(logits, top_k):                                                            # :1369-1373
+    kth = torch.topk(logits, top_k)[0][..., -1, None]
+    logits.masked_fill_(logits < kth, float("-inf"))
+
+
+def _filter_top_p(logits, top_p):                                                            # :1376-1395
+    sorted_logits, sorted_indices = torch.sort(logits, descending=True)
+    cumulative = sorted_logits.softmax(dim=-1).cumsum(dim=-1)
+    filt = cumulative > top_p
+    filt[:, 1:] = filt[:, :-1].clone()
+    filt[..., 0] = 0
+    logits.masked_fill_(filt.scatter(1, sorted_indices, filt), float("-inf"))
+
+
+def sample_token(logits: torch.Tensor, top_k=0, top_p=0.0, temperature=1.0, vocab_size=None, generator=None) -> torch.Tensor:
+    """models/modeling_distributed_gpt3.py:1398-1441.  Greedy (top_k == 1) runs on mpv_logprob_topk; the stochastic
+    filters are a handful of torch calls on the [B, V] logits, as in the reference."""
+    assert logits.ndim == 2
+    if top_k == 1:
+        assert top_p == 0.0, "cannot set both greedy and top-p samplings."
+        samples = ops.logprob_topk(logits, 1)[1].view(-1)
+    else:
+        lg = logits.float().clone()
+        if temperature != 1.0:
+            lg.div_(temperature)
+        if top_k > 1:
+            assert top_p == 0.0, "cannot set both top-k and top-p samplings."
+            _filter_top_k(lg, top_k)
+        elif top_p > 0.0:
+            assert top_p <= 1.0
+            _filter_top_p(lg, top_p)
+        samples = torch.multinomial(lg.softmax(dim=-1), num_samples=1, generator=generator).view(-1)
+    if vocab_size:
+        samples = torch.clamp(samples, min=0, max=vocab_size - 1)
+    return samples
+
+
+# ---------------------------------------------------------------------------------------------- search loops
+def _gen_config(gpt):
+    ex = gpt.config.extra
+    return SimpleNamespace(tokens_to_generate=ex.get("tokens_to_generate", 100), eod_id=ex.get("eod_id", 7), top_k=ex.get("top_k", 0),
+                           top_p=ex.get("top_p", 0.9), max_position_embeddings=gpt.config.max_position_embeddings,
+                           vocab_size=gpt.config.vocab_size)
+
+
+StepFn = Callable[[Optional[torch.Tensor], Optional[torch.Tensor]], torch.Tensor]
+
+
+def beam_search_loop(cfg, make_state: Callable[[int, int], object], tokens: torch.Tensor, query_embeds=None, beam_size=5,
+                     num_return_gen=1, stop_token=None, prompt_length=None, topk_fn=None):
+    """models/modeling_distributed_gpt3.py:1737-1873.  `make_state(batch, max_len)` returns an object with
+    .step(tokens, query_embeds) -> logits [beams, V] and .reorder(batch_idx); `topk_fn(logits, k, add)` ->
+    (values, indices) of log_softmax + add.  Both are injectable so the host logic can be driven from any logits source."""
+    assert tokens.size(0) == 1
+    dev = tokens.device
+    prompt_length = int(prompt_length) if prompt_length is not None else tokens.size(1)
+    stop_token = cfg.eod_id if stop_token is None else int(stop_token)
+    tokens = torch.cat((tokens, torch.full((1, cfg.tokens_to_generate), stop_token, dtype=torch.long, device=dev)), dim=-1)
+    final_len = min(tokens.size(1), cfg.max_position_embeddings)
+    if prompt_length >= final_len:
+        raise ValueError("context length + tokens_to_generate too large")
+    Q = 0 if query_embeds is None else query_embeds.size(1)
+    state = make_state(beam_size, final_len + Q)
+    hyp = BeamHypotheses(beam_size)
+    done = False
+    scores = torch.zeros(beam_size, dtype=torch.float32, device=dev)
+    tokens = tokens.repeat(beam_size, 1)
+    if query_embeds is not None:
+        query_embeds = query_embeds.repeat(beam_size, 1, 1)
+    prev, total_prompt, total_final = 0, prompt_length + Q, final_len + Q
+    context_length = total_prompt
+    for context_length in range(total_prompt, total_final):
+        t2u = tokens[:, max(prev - Q, 0):context_length - Q]
+        logits = state.step(t2u, query_embeds if context_length == total_prompt else None)
+        V = logits.size(-1)
+        k2 = 2 * beam_size
+        vals, idxs = topk_fn(logits, k2, scores)                                             # log_softmax + scores (:1790-1791)
+        vals, idxs = vals.cpu(), idxs.cpu()
+        if context_length == total_prompt:                                                   # all beams identical: row 0 only (:1793-1795)
+            cand = [(vals[0, j].item(), 0, idxs[0, j].item()) for j in range(k2)]
+        else:
+            cand = [(vals[b, j].item(), b, idxs[b, j].item()) for b in range(beam_size) for j in range(k2)]
+            cand.sort(key=lambda c: (-c[0], c[1] * V + c[2]))
+            cand = cand[:k2]
+        next_beams = []
+        for rank, (beam_score, beam_id, token_id) in enumerate(cand):
+            if token_id == stop_token:
+                if rank >= beam_size:                                                        # :1809-1812
+                    continue
+                hyp.add(tokens[beam_id].clone(), beam_score, context_length + 1 - total_prompt)
+            else:
+                next_beams.append((token_id, beam_score, beam_id))
+            if len(next_beams) == beam_size:
+                break
+        if hyp.is_done(max(c[0] for c in cand), context_length + 1 - total_prompt):
+            done = True
+            break
+        best = torch.tensor([b[2] for b in next_beams], dtype=torch.long, device=dev)
+        tokens = tokens[best, :]
+        tokens[:, context_length - Q] = torch.tensor([b[0] for b in next_beams], dtype=torch.long, device=dev)
+        scores = torch.tensor([b[1] for b in next_beams], dtype=torch.float32, device=dev)
+        state.reorder(best)
+        prev = context_length
+    if not done:
+        for b in range(beam_size):
+            hyp.add(tokens[b].clone(), scores[b].item(), context_length + 1 - total_prompt)
+    ranked = sorted(hyp.beams, key=lambda x: x[0], reverse=True)
+    num_return_gen = min(num_return_gen, len(ranked))
+    return SimpleNamespace(sequences=torch.stack([ranked[i][1] for i in range(num_return_gen)], dim=0),
+                           scores=torch.tensor([ranked[i][0] for i in range(num_return_gen)], dtype=torch.float32))
+
+
+def sample_loop(cfg, make_state, tokens: torch.Tensor, query_embeds=None, temperature=1.0, use_eod_token_for_early_termination=True,
+                stop_on_double_eol=False, stop_on_eol=False, termination_id=None, prompt_length=None, generator=None):
+    """models/modeling_distributed_gpt3.py:1620-1735."""
+    B, dev = tokens.size(0), tokens.device
+    lengths = prompt_length if prompt_length is not None else torch.tensor([tokens.size(1)], device=dev)
+    lengths = torch.as_tensor(lengths, device=dev).view(-1)
+    tokens = torch.cat((tokens, torch.full((B, cfg.tokens_to_generate), cfg.eod_id, dtype=torch.long, device=dev)), dim=-1)
+    min_prompt = int(lengths.min().item())
+    max_len = min(tokens.size(1), cfg.max_position_embeddings)
+    if min_prompt >= max_len:
+        raise ValueError("context length + tokens_to_generate too large")
+    Q = 0 if query_embeds is None else query_embeds.size(1)
+    state = make_state(B, max_len + Q)
+    termination_id = cfg.eod_id if termination_id is None else int(termination_id)
+    is_done = torch.zeros(B, dtype=torch.bool, device=dev)
+    prev, total_min, total_max = 0, min_prompt + Q, max_len + Q
+    context_length = total_min
+    for context_length in range(total_min, total_max):
+        t2u = tokens[:, max(prev - Q, 0):context_length - Q]
+        logits = state.step(t2u, query_embeds if context_length == total_min else None)
+        new = sample_token(logits, top_k=cfg.top_k, top_p=cfg.top_p, temperature=temperature, vocab_size=cfg.vocab_size,
+                           generator=generator)
+        started = lengths <= context_length - Q
+        tokens[started, context_length - Q] = new[started]
+        prev = context_length
+        if stop_on_double_eol:
+            done_token = ((new == 628) | ((new == 198) & (tokens[:, context_length - Q - 1] == 198))) & started
+        elif stop_on_eol:
+            done_token = ((new == 628) | (new == 198)) & started
+        else:
+            done_token = (new == termination_id) & started
+        is_done |= done_token
+        if use_eod_token_for_early_termination and bool(is_done.all()):
+            break
+    return tokens[:, :context_length + 1]      # (sic) the reference slices with the prefix-inclusive length (:1733)
+
+
+def install(gpt_cls):
+    """Adds sample / beam_search / generate to DistributedGPT3 (same signatures as the reference methods)."""
+
+    def _make_state(self):
+        return lambda batch, max_len: DecodeState(self, batch, max_len)
+
+    def sample(self, tokens, query_embeds=None, temperature=1.0, **kw):
+        return sample_loop(_gen_config(self), _make_state(self), tokens, query_embeds=query_embeds, temperature=temperature, **kw)
+
+    def beam_search(self, tokens, query_embeds=None, beam_size=5, num_return_gen=1, stop_token=None, **kw):
+        return beam_search_loop(_gen_config(self), _make_state(self), tokens, query_embeds=query_embeds, beam_size=beam_size,
+                                num_return_gen=num_return_gen, stop_token=stop_token, prompt_length=kw.pop("prompt_length", None),
+                                topk_fn=lambda lg, k, add: ops.logprob_topk(lg, k, add=add))
+
+    @torch.no_grad()
+    def generate(self, tokens, do_sample=True, termination_id=None, *args, **kw):                # :1875-1880
+        was = self.training
+        self.eval()
+        try:
+            if do_sample:
+                return self.sample(tokens, termination_id=termination_id, *args, **kw)
+            return self.beam_search(tokens, stop_token=termination_id, *args, **kw)
+        finally:
+            self.train(was)
+
+    gpt_cls.sample, gpt_cls.beam_search, gpt_cls.generate = sample, beam_search, generate

@@ -316,3 +316,8 @@ class DistributedGPT3(nn.Module):
         class _Out(dict):
             __getattr__ = dict.__getitem__
         return _Out(logits=out["logits"], loss=out["loss"], losses=out["losses"], last_hidden_state=out["last_hidden_state"])
+
+
+from . import generation as _generation  # noqa: E402  (sample / beam_search / generate, models/modeling_distributed_gpt3.py:1620-1880)
+
+_generation.install(DistributedGPT3)

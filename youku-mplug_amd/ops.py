@@ -298,6 +298,22 @@ def scatter_rows(src, idx, dst, rows, cols, ld=None):
     return dst
 
 
+def gather_rows_ld(src, idx, dst, rows, cols, lds, ldd):
+    check(_lib.lib().mpv_gather_rows_ld(src.data_ptr(), idx.data_ptr(), dst.data_ptr(), rows, cols, lds, ldd, _stream()), "mpv_gather_rows_ld")
+    return dst
+
+
+def logprob_topk(logits, k, add=None, rows=None, vocab=None, ld=None):
+    """-> (values fp32 [rows,k], indices int64 [rows,k]) of log_softmax(logits) + add[:,None], descending."""
+    rows = rows if rows is not None else logits.shape[0]
+    vocab = vocab if vocab is not None else logits.shape[-1]
+    val = torch.empty((rows, k), dtype=torch.float32, device=logits.device)
+    idx = torch.empty((rows, k), dtype=torch.int64, device=logits.device)
+    check(_lib.lib().mpv_logprob_topk(logits.data_ptr(), _p(add), rows, vocab, ld or vocab, k, val.data_ptr(), idx.data_ptr(), _stream()),
+          "mpv_logprob_topk")
+    return val, idx
+
+
 def soft_target_ce(sim, row_ids, col_ids, scale, rows, cols, want_grad=True):
     losses = torch.empty(rows, dtype=torch.float32, device=sim.device)
     dsim = torch.empty((rows, cols), dtype=torch.bfloat16, device=sim.device) if want_grad else None
