@@ -206,8 +206,31 @@ int mpv_gather_rows_ld(const void* src, const int64_t* idx, void* dst, int64_t r
 /* out_val[r][j], out_idx[r][j] = the j-th largest of log_softmax(logits[r]) + add[r] (add optional), fp32 statistics over
  * bf16 logits, ties broken towards the lower index; k <= 64.  Serves beam_search (:1790-1805: log_softmax, + scores,
  * sort, top 2*beam) and greedy sample (:1411-1413, k = 1). */
+size_t mpv_logprob_topk_workspace_size(int64_t rows, int k);
 int mpv_logprob_topk(const void* logits, const float* add, int64_t rows, int64_t vocab, int64_t ld, int k, float* out_val,
-                     int64_t* out_idx, mpv_stream_t stream);
+                     int64_t* out_idx, void* workspace, size_t workspace_bytes, mpv_stream_t stream);
+/* One incremental decoder forward over per-layer KV caches, all launches issued from C (one FFI call per step):
+ * appends the n = Q + L new positions of every sequence (query [batch*Q][hidden] rows first, then wte[tokens]) at
+ * cache rows [pos0, pos0 + n), attends causally over rows [0, pos0 + n) and writes the logits of the LAST new position
+ * of every sequence to logits [batch][vocab] (bf16).  kv_cache[l] = [batch][max_len][3*hidden] bf16 in the decoder's
+ * head-interleaved q|k|v row format (models/modeling_distributed_gpt3.py:895-902).  Weight tables are host arrays of
+ * device pointers.  Covers :640-666, :868-938 (KV memory), :1034-1078, :1184, :1348-1350. */
+typedef struct mpv_gpt_layer_weights {
+  const void *ln1_w, *ln1_b, *qkv_w, *qkv_b, *dense_w, *dense_b, *ln2_w, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} mpv_gpt_layer_weights;
+typedef struct mpv_gpt_weights {
+  int layers, hidden, heads, ffn, vocab;
+  float ln_eps;
+  const mpv_gpt_layer_weights* layer;
+  const void *wte, *wpe, *lnf_w, *lnf_b;
+} mpv_gpt_weights;
+size_t mpv_gpt_decode_workspace_size(const mpv_gpt_weights* w, int batch, int n_new);
+int mpv_gpt_decode_step(const mpv_gpt_weights* w, void* const* kv_cache, int batch, int max_len, int pos0, const void* query,
+                        int Q, const int64_t* tokens, int L, void* workspace, size_t workspace_bytes, void* logits,
+                        mpv_stream_t stream);
+/* beam re-order of all layers: dst[l][j] = src[l][idx[j]] for the first `rows` cached positions */
+int mpv_kv_reorder(void* const* src, void* const* dst, int layers, const int64_t* idx, int batch, int max_len, int rows,
+                   int hidden, mpv_stream_t stream);
 /* Soft-target contrastive cross-entropy over fp32 similarities sim[rows][cols] (:966-978):
  * targets[i][j] = [row_ids[i]==col_ids[j]] / count_i; losses[i] = -sum_j log_softmax(sim_i)[j] targets[i][j];
  * dsim (bf16, optional) = (softmax - targets) * scale; dts[i] (optional) = sum_j dsim[i][j] * sim[i][j]. */

@@ -434,6 +434,23 @@ def test_gemm_wgrad_fused_bias_grad(dev):
 
 
 # ------------------------------------------------------------------------------ generation helpers
+@pytest.mark.parametrize("B,H,Sk,hd,sqb", [(3, 4, 300, 64, False), (2, 2, 77, 80, False), (5, 32, 301, 64, False), (1, 3, 9, 96, True)])
+def test_attention_decode_step(dev, B, H, Sk, hd, sqb):
+    """sq == 1 against cached keys (attn_decode_kernel): output and log-sum-exp vs fp32 torch."""
+    from youku_mplug_amd import ops
+    q, k, v = rn(B, 1, H, hd, dev=dev, seed=60), rn(B, Sk, H, hd, dev=dev, seed=61), rn(B, Sk, H, hd, dev=dev, seed=62)
+    o = torch.empty_like(q)
+    scale = hd ** -0.5
+    lay = ops.AttnLayout((H * hd, hd, H * hd), (Sk * H * hd, hd, H * hd), (Sk * H * hd, hd, H * hd), (H * hd, hd, H * hd))
+    lse = ops.attn_fwd(q, k, v, o, lay, B, H, 1, Sk, hd, causal=True, scale=scale, scale_q_bf16=sqb)
+    qf = (q * scale).float() if sqb else q.float() * scale
+    s = torch.einsum("bqhd,bkhd->bhqk", qf, k.float())
+    ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, dim=-1), v.float())
+    close(o, ref, 1e-2, "decode attention output")
+    assert torch.allclose(lse.view(B, H), torch.logsumexp(s, dim=-1).view(B, H), atol=2e-3, rtol=1e-3)
+
+
+
 @pytest.mark.parametrize("rows,V,k", [(5, 51200, 10), (3, 1024, 6), (1, 8, 1), (4, 200, 64)])
 def test_logprob_topk(dev, rows, V, k):
     from youku_mplug_amd import ops

@@ -76,13 +76,31 @@ _SIGS = {
     "mpv_gather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "mpv_scatter_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "mpv_gather_rows_ld": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p]),
-    "mpv_logprob_topk": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "mpv_logprob_topk_workspace_size": (c_size_t, [c_int64, c_int]),
+    "mpv_logprob_topk": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mpv_soft_target_ce": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "mpv_grad_sumsq": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "mpv_adamw_step": (c_int, [c_void_p] * 5 + [c_int64] + [c_float] * 5 + [c_int, c_float, c_void_p, c_float, c_void_p]),
     "mpv_adamw_step_grouped": (c_int, [c_void_p] * 5 + [c_int64, c_void_p, C.POINTER(c_float), C.POINTER(c_float), c_int,
                                        c_float, c_float, c_float, c_int, c_float, c_void_p, c_float, c_void_p]),
 }
+class GptLayerWeights(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "dense_w", "dense_b", "ln2_w", "ln2_b", "fc1_w", "fc1_b",
+                                        "fc2_w", "fc2_b")]
+
+
+class GptWeights(C.Structure):
+    _fields_ = [("layers", c_int), ("hidden", c_int), ("heads", c_int), ("ffn", c_int), ("vocab", c_int), ("ln_eps", c_float),
+                ("layer", C.POINTER(GptLayerWeights)), ("wte", c_void_p), ("wpe", c_void_p), ("lnf_w", c_void_p), ("lnf_b", c_void_p)]
+
+
+_SIGS.update({
+    "mpv_gpt_decode_workspace_size": (c_size_t, [C.POINTER(GptWeights), c_int, c_int]),
+    "mpv_gpt_decode_step": (c_int, [C.POINTER(GptWeights), C.POINTER(c_void_p), c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
+                                    c_void_p, c_size_t, c_void_p, c_void_p]),
+    "mpv_kv_reorder": (c_int, [C.POINTER(c_void_p), C.POINTER(c_void_p), c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+})
+
 EXPORTS = tuple(_SIGS)
 
 _lib = None

@@ -1059,6 +1059,108 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TempArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Decode attention (sq == 1: one new token per sequence against its cached keys, models/modeling_distributed_gpt3.py:
+// 905-929).  One wave per (sequence, head): phase 1 -- lane j scores keys j, j+64, ... (fp32 dot over the 128/160-byte
+// key rows, q broadcast from LDS), softmax statistics by wave reduction, probabilities parked in LDS; phase 2 -- lane d
+// accumulates sum_j p_j V[j][d] (each key's value row is one coalesced line).  VALU only: 2*sk*hd MACs per head.
+constexpr int DEC_MAX_SK = 2048;
+// One workgroup per (sequence, head).  LPK lanes share one key row (16 bytes each), so a wave instruction fetches
+// 64/LPK whole rows and the 4 waves cover 256/LPK keys per pass, 8 passes unrolled (the step is latency-bound: every
+// load that can be in flight is).
+template <int LPK>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
+  __shared__ float ps[DEC_MAX_SK];
+  __shared__ float red[4];
+  __shared__ float accs[4][LPK * 8];
+  constexpr int KPI = 256 / LPK;                      // keys per workgroup pass
+  constexpr int UN = 8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.x;
+  const int b = bh / p.heads, h = bh - b * p.heads;
+  const int hd = p.hd;
+  const int kg = tid / LPK, ch = tid - kg * LPK;      // key slot within a pass, 8-wide column chunk
+  const bool cok = ch * 8 < hd;
+  const bf16* kb = p.k + b * p.k_bs + h * p.k_hs + ch * 8;
+  const bf16* vb = p.v + b * p.v_bs + h * p.v_hs + ch * 8;
+  f32x8 qv = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (cok) {
+    qv = cvt8(*(const bf16x8*)(p.q + b * p.q_bs + h * p.q_hs + ch * 8));
+    if (p.scale_q_bf16) qv = cvt8(cvt8(qv * p.scale));
+  }
+  const float sc = p.scale_q_bf16 ? 1.0f : p.scale;
+  const bf16x8 zero8 = cvt8(f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
+  // ---- scores
+  float mx = -INFINITY;
+  for (int j0 = 0; j0 < p.sk; j0 += UN * KPI) {
+    bf16x8 kv[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int j = j0 + u * KPI + kg;
+      kv[u] = (cok && j < p.sk) ? *(const bf16x8*)(kb + (long long)j * p.k_rs) : zero8;
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const f32x8 kf = cvt8(kv[u]);
+      float d = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d += qv[e] * kf[e];
+#pragma unroll
+      for (int o = LPK / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+      const int j = j0 + u * KPI + kg;
+      if (ch == 0 && j < p.sk) {
+        ps[j] = d * sc;
+        mx = fmaxf(mx, d * sc);
+      }
+    }
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float l = 0.f;
+  for (int j = tid; j < p.sk; j += 256) {
+    const float e = __expf(ps[j] - mx);
+    ps[j] = e;
+    l += e;
+  }
+  l = wave_sum(l);
+  if (lane == 0) red[wave] = l;
+  __syncthreads();
+  l = (red[0] + red[1]) + (red[2] + red[3]);
+  // ---- output: thread (kg, ch) accumulates its 8 columns over keys kg, kg + KPI, ...; then the key slots are summed
+  f32x8 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int j0 = 0; j0 < p.sk; j0 += UN * KPI) {
+    bf16x8 vv[UN];
+    float pj[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int j = j0 + u * KPI + kg;
+      const bool ok = cok && j < p.sk;
+      vv[u] = ok ? *(const bf16x8*)(vb + (long long)j * p.v_rs) : zero8;
+      pj[u] = ok ? ps[j] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) acc += cvt8(vv[u]) * pj[u];
+  }
+#pragma unroll
+  for (int o = LPK; o < 64; o <<= 1)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+  if (lane < LPK)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) accs[wave][lane * 8 + e] = acc[e];
+  __syncthreads();
+  if (tid < LPK && tid * 8 < hd) {
+    f32x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = ((accs[0][tid * 8 + e] + accs[1][tid * 8 + e]) + (accs[2][tid * 8 + e] + accs[3][tid * 8 + e])) * (1.0f / l);
+    *(bf16x8*)(p.o + b * p.o_bs + h * p.o_hs + tid * 8) = cvt8(o);
+  }
+  if (tid == 0 && p.lse) p.lse[bh] = mx + __logf(l);
+}
+
 // waves per workgroup: cover a whole sequence with one workgroup when it has <= 256 rows (no idle
 // waves: 160 rows -> 5 waves, 197 -> 7), otherwise 8 waves = 256 rows per workgroup
 int waves_for(int rows) {
@@ -1133,6 +1235,12 @@ extern "C" int mpv_attn_fwd(const mpv_attn_desc* d, hipStream_t stream) {
   if (rc) return rc;
   AttnArgs a = {};
   fill_args(a, d);
+  if (d->sq == 1 && d->dropout_p == 0.f && d->sk <= DEC_MAX_SK && (d->o_hs % 8) == 0 && ((uintptr_t)d->o & 15) == 0) {      // decode step of KV-cache generation
+    const dim3 dg((unsigned)(d->batch * d->heads));
+    if (d->head_dim <= 64) hipLaunchKernelGGL(attn_decode_kernel<8>, dg, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(attn_decode_kernel<16>, dg, dim3(256), 0, stream, a);
+    return mpv_check_launch("mpv_attn_fwd");
+  }
   if (d->sk <= RES_MAX_ROWS) {
     res_attr_once();
     const int nw = waves_for(d->sq);

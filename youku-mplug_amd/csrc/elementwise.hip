@@ -369,63 +369,111 @@ __global__ void gather_rows_ld_kernel(const bf16* __restrict__ src, const int64_
     *(bf16x8*)(dst + r * ldd + c8 * 8) = *(const bf16x8*)(src + idx[r] * lds + c8 * 8);
   }
 }
-// log_softmax(logits[r]) + add[r], then the k largest entries of the row (descending; ties -> lower index first).
-// One workgroup per row: fp32 max / sum-exp over the bf16 row, then k rounds of a block-wide arg-max over the
-// entries that come after the previous winner in (value desc, index asc) order.  k <= 64.
-__global__ __launch_bounds__(256) void logprob_topk_kernel(const bf16* __restrict__ logits, const float* __restrict__ add, int k,
-                                                           float* __restrict__ out_val, int64_t* __restrict__ out_idx, int vocab,
-                                                           long long ld) {
+// log_softmax(logits[r]) + add[r], then the k largest entries of the row (descending; ties -> lower index first), k <= 64.
+// Two stages so that a handful of rows still fills the chip: (1) TOPK_CHUNKS workgroups per row each take a slice of
+// the vocabulary: slice max / sum-exp and the slice's k best by k rounds of a block-wide arg-max over the entries that
+// come after the previous winner in (value desc, index asc) order; (2) one workgroup per row merges the statistics
+// and the TOPK_CHUNKS*k candidates the same way.
+constexpr int TOPK_CHUNKS = 32;
+
+__device__ __forceinline__ void block_argmax(float& bv, int& bi, float* redf, int* redi, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if (lane == 0) { redf[wave] = bv; redi[wave] = bi; }
+  __syncthreads();
+  bv = redf[0];
+  bi = redi[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w)
+    if (redf[w] > bv || (redf[w] == bv && redi[w] < bi)) { bv = redf[w]; bi = redi[w]; }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void logprob_topk_part_kernel(const bf16* __restrict__ logits, int k, float* __restrict__ cval,
+                                                                int* __restrict__ cidx, float* __restrict__ pmax,
+                                                                float* __restrict__ psum, int vocab, long long ld) {
   __shared__ float redf[4];
   __shared__ int redi[4];
-  __shared__ float bestv;
-  __shared__ int besti;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bf16* row = logits + (long long)blockIdx.x * ld;
+  const int chunk = blockIdx.x, rowi = blockIdx.y;
+  const int per = (vocab + TOPK_CHUNKS - 1) / TOPK_CHUNKS;
+  const int c0 = chunk * per, c1 = min(vocab, c0 + per);
+  const bf16* row = logits + (long long)rowi * ld;
   float mx = -INFINITY;
-  for (int c = tid; c < vocab; c += 256) mx = fmaxf(mx, bf2f(row[c]));
+  for (int c = c0 + tid; c < c1; c += 256) mx = fmaxf(mx, bf2f(row[c]));
   mx = wave_max(mx);
   if (lane == 0) redf[wave] = mx;
   __syncthreads();
   mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
   __syncthreads();
   float se = 0.f;
-  for (int c = tid; c < vocab; c += 256) se += __expf(bf2f(row[c]) - mx);
+  for (int c = c0 + tid; c < c1; c += 256) se += __expf(bf2f(row[c]) - mx);
   se = wave_sum(se);
   if (lane == 0) redf[wave] = se;
   __syncthreads();
-  const float lse = mx + __logf((redf[0] + redf[1]) + (redf[2] + redf[3])) - (add ? add[blockIdx.x] : 0.f);
+  if (tid == 0) {
+    pmax[rowi * TOPK_CHUNKS + chunk] = mx;
+    psum[rowi * TOPK_CHUNKS + chunk] = (redf[0] + redf[1]) + (redf[2] + redf[3]);
+  }
+  __syncthreads();
   float pv = INFINITY;
   int pi = -1;
   for (int j = 0; j < k; ++j) {
-    __syncthreads();
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int c = tid; c < vocab; c += 256) {
+    for (int c = c0 + tid; c < c1; c += 256) {
       const float v = bf2f(row[c]);
       const bool after = v < pv || (v == pv && c > pi);          // not yet taken
       if (after && (v > bv || (v == bv && c < bi))) { bv = v; bi = c; }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(bv, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
-    if (lane == 0) { redf[wave] = bv; redi[wave] = bi; }
-    __syncthreads();
+    block_argmax(bv, bi, redf, redi, tid);
     if (tid == 0) {
-      float v = redf[0];
-      int i = redi[0];
-      for (int w = 1; w < 4; ++w)
-        if (redf[w] > v || (redf[w] == v && redi[w] < i)) { v = redf[w]; i = redi[w]; }
-      bestv = v;
-      besti = i;
-      out_val[(long long)blockIdx.x * k + j] = v - lse;
-      out_idx[(long long)blockIdx.x * k + j] = i;
+      cval[((long long)rowi * TOPK_CHUNKS + chunk) * k + j] = bv;     // -inf / 0x7fffffff once the slice is exhausted
+      cidx[((long long)rowi * TOPK_CHUNKS + chunk) * k + j] = bi;
     }
-    __syncthreads();
-    pv = bestv;
-    pi = besti;
+    pv = bv;
+    pi = bi;
+  }
+}
+
+__global__ __launch_bounds__(256) void logprob_topk_merge_kernel(const float* __restrict__ cval, const int* __restrict__ cidx,
+                                                                 const float* __restrict__ pmax, const float* __restrict__ psum,
+                                                                 const float* __restrict__ add, int k, float* __restrict__ out_val,
+                                                                 int64_t* __restrict__ out_idx) {
+  __shared__ float redf[4];
+  __shared__ int redi[4];
+  const int tid = threadIdx.x, rowi = blockIdx.x;
+  float gmax = -INFINITY;
+  for (int c = 0; c < TOPK_CHUNKS; ++c) gmax = fmaxf(gmax, pmax[rowi * TOPK_CHUNKS + c]);
+  float se = 0.f;
+  for (int c = 0; c < TOPK_CHUNKS; ++c) se += psum[rowi * TOPK_CHUNKS + c] * __expf(pmax[rowi * TOPK_CHUNKS + c] - gmax);
+  const float lse = gmax + __logf(se) - (add ? add[rowi] : 0.f);
+  const int ncand = TOPK_CHUNKS * k;
+  const float* cv = cval + (long long)rowi * ncand;
+  const int* ci = cidx + (long long)rowi * ncand;
+  float pv = INFINITY;
+  int pi = -1;
+  for (int j = 0; j < k; ++j) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = tid; c < ncand; c += 256) {
+      const float v = cv[c];
+      const int i = ci[c];
+      const bool after = v < pv || (v == pv && i > pi);
+      if (after && (v > bv || (v == bv && i < bi))) { bv = v; bi = i; }
+    }
+    block_argmax(bv, bi, redf, redi, tid);
+    if (tid == 0) {
+      out_val[(long long)rowi * k + j] = bv - lse;
+      out_idx[(long long)rowi * k + j] = bi;
+    }
+    pv = bv;
+    pi = bi;
   }
 }
 // Soft-target contrastive CE (models/distributed_gpt3.py:966-978): targets[i][j] = [ids_r[i]==ids_c[j]] / count_i;
@@ -644,12 +692,24 @@ extern "C" int mpv_gather_rows_ld(const void* src, const int64_t* idx, void* dst
   return mpv_check_launch("mpv_gather_rows_ld");
 }
 
+extern "C" size_t mpv_logprob_topk_workspace_size(int64_t rows, int k) {
+  return (size_t)rows * TOPK_CHUNKS * ((size_t)k * 8 + 8) + 256;
+}
+
 extern "C" int mpv_logprob_topk(const void* logits, const float* add, int64_t rows, int64_t vocab, int64_t ld, int k,
-                                float* out_val, int64_t* out_idx, hipStream_t stream) {
-  MPV_REQUIRE(logits && out_val && out_idx, MPV_E_ARG, "mpv_logprob_topk: null pointer");
+                                float* out_val, int64_t* out_idx, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  MPV_REQUIRE(logits && out_val && out_idx && workspace, MPV_E_ARG, "mpv_logprob_topk: null pointer");
   MPV_REQUIRE(rows > 0 && vocab > 0 && k > 0 && k <= 64 && k <= vocab, MPV_E_SHAPE, "mpv_logprob_topk: need 0 < k <= min(64, vocab)");
-  hipLaunchKernelGGL(logprob_topk_kernel, dim3((unsigned)rows), dim3(256), 0, stream, (const bf16*)logits, add, k, out_val, out_idx,
-                     (int)vocab, (long long)ld);
+  MPV_REQUIRE(workspace_bytes >= mpv_logprob_topk_workspace_size(rows, k), MPV_E_ARG, "mpv_logprob_topk: workspace too small");
+  const size_t nc = (size_t)rows * TOPK_CHUNKS;
+  float* cval = (float*)workspace;
+  int* cidx = (int*)(cval + nc * k);
+  float* pmax = (float*)(cidx + nc * k);
+  float* psum = pmax + nc;
+  hipLaunchKernelGGL(logprob_topk_part_kernel, dim3(TOPK_CHUNKS, (unsigned)rows), dim3(256), 0, stream, (const bf16*)logits, k, cval,
+                     cidx, pmax, psum, (int)vocab, (long long)ld);
+  hipLaunchKernelGGL(logprob_topk_merge_kernel, dim3((unsigned)rows), dim3(256), 0, stream, (const float*)cval, (const int*)cidx,
+                     (const float*)pmax, (const float*)psum, add, k, out_val, out_idx);
   return mpv_check_launch("mpv_logprob_topk");
 }
 

@@ -472,6 +472,102 @@ __global__ void colsum_finish_kernel(const float* part, bf16* out, int M, int sp
   out[m] = f2bf(a);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Small-M variant (decode steps of KV-cache generation: M = beams <= 16, nn.Linear weights [N][K]).  HBM-bound: the
+// weight is streamed exactly once, straight from global memory into MFMA operand registers -- no LDS staging, no
+// 128-row tile.  A workgroup owns 16 output columns; its 4 waves split K; each lane loads 32 contiguous bytes of a
+// weight row per 64-wide K block (4 lanes cover the row's full 128-byte line) and the matching 32 bytes of an
+// activation row (L2-resident), and feeds them to two v_mfma_f32_16x16x32_bf16 (the k order inside an MFMA is free
+// as long as both operands agree).  Partial tiles meet in LDS; the epilogue handles bias / activation / residual /
+// C row map (the qkv row lands directly in the KV cache).
+struct SmallMArgs {
+  const bf16* A;
+  const bf16* W;
+  bf16* C;
+  int M, N, K;
+  long long lda, ldw, ldc, ldr;
+  RowMap cmap;
+  const bf16* bias;
+  const bf16* residual;
+  int act;
+};
+
+template <bool FULL>   // FULL: N % 16 == 0 and K % 64 == 0 -> branch-free main loop (unrolled 8x: 16 weight loads in flight per lane)
+__global__ __launch_bounds__(256) void gemm_small_m_kernel(const SmallMArgs p) {
+  __shared__ float part[4][16][17];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * 16;
+  const int r = lane & 15, g = lane >> 4;                       // operand row (n for W, m for A), 16-wide k group
+  const int kblocks = (p.K + 63) >> 6;
+  const int per = (kblocks + 3) >> 2;
+  const int kb0 = wave * per, kb1 = min(kblocks, kb0 + per);
+  const bool wok = (n0 + r) < p.N, aok = r < p.M;
+  const bf16* wrow = p.W + (long long)(wok ? n0 + r : 0) * p.ldw + g * 16;
+  const bf16* arow = p.A + (long long)(aok ? r : 0) * p.lda + g * 16;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const i32x4 zero = {0, 0, 0, 0};
+  union Frag { i32x4 i; bf16x8 b; };
+  if constexpr (FULL) {
+    int kb = kb0;
+    for (; kb + 8 <= kb1; kb += 8) {
+      Frag w0[8], w1[8], a0[8], a1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        w0[u].i = *(const i32x4*)(wrow + (kb + u) * 64);
+        w1[u].i = *(const i32x4*)(wrow + (kb + u) * 64 + 8);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a0[u].i = aok ? *(const i32x4*)(arow + (kb + u) * 64) : zero;
+        a1[u].i = aok ? *(const i32x4*)(arow + (kb + u) * 64 + 8) : zero;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[u].b, w0[u].b, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[u].b, w1[u].b, acc, 0, 0, 0);
+      }
+    }
+    for (; kb < kb1; ++kb) {
+      Frag w0, w1, a0, a1;
+      w0.i = *(const i32x4*)(wrow + kb * 64);
+      w1.i = *(const i32x4*)(wrow + kb * 64 + 8);
+      a0.i = aok ? *(const i32x4*)(arow + kb * 64) : zero;
+      a1.i = aok ? *(const i32x4*)(arow + kb * 64 + 8) : zero;
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0.b, w0.b, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1.b, w1.b, acc, 0, 0, 0);
+    }
+  } else {
+    for (int kb = kb0; kb < kb1; ++kb) {
+      const int k = kb * 64 + g * 16;
+      const bool k0 = k < p.K, k1 = k + 8 < p.K;                // K is a multiple of 8: 16-byte chunks are all-in or all-out
+      Frag w0, w1, a0, a1;
+      w0.i = (wok && k0) ? *(const i32x4*)(wrow + kb * 64) : zero;
+      w1.i = (wok && k1) ? *(const i32x4*)(wrow + kb * 64 + 8) : zero;
+      a0.i = (aok && k0) ? *(const i32x4*)(arow + kb * 64) : zero;
+      a1.i = (aok && k1) ? *(const i32x4*)(arow + kb * 64 + 8) : zero;
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0.b, w0.b, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1.b, w1.b, acc, 0, 0, 0);
+    }
+  }
+  // D layout: lane -> column n = lane & 15, rows m = 4 * (lane >> 4) + i
+#pragma unroll
+  for (int i = 0; i < 4; ++i) part[wave][4 * g + i][r] = acc[i];
+  __syncthreads();
+  const int m = tid >> 4, n = n0 + (tid & 15);
+  if (m < p.M && n < p.N) {
+    float v = (part[0][m][tid & 15] + part[1][m][tid & 15]) + (part[2][m][tid & 15] + part[3][m][tid & 15]);
+    if (p.bias) v += bf2f(p.bias[n]);
+    if (p.act) {
+      const float z = bf2f(f2bf(v));
+      v = p.act == 1 ? gelu_erf_f(z) : p.act == 2 ? gelu_tanh_f(z) : fmaxf(z, 0.f);
+    }
+    const long long crow = map_row(p.cmap, m);
+    if (p.residual) v += bf2f(p.residual[crow * p.ldr + n]);
+    p.C[crow * p.ldc + n] = f2bf(v);
+  }
+}
+
 }  // namespace
 
 constexpr int SLOTS = 512;                                   // resident workgroups: 256 CUs x 2
@@ -569,6 +665,20 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
   }
   void* colsum_out = ep ? ep->colsum_out : nullptr;
   MPV_REQUIRE(!colsum_out || (transA && transB && !g.out_f32), MPV_E_ARG, "mpv_gemm_bf16: colsum_out is a wgrad (transA=transB=1) option");
+  // decode regime: a handful of rows against a k-contiguous weight -> the weight-streaming kernel
+  if (!transA && !transB && M <= 16 && !g.out_f32 && !g.accumulate && !g.drop_thr && !g.act_bwd && !g.preact && !g.alpha_dev &&
+      g.alpha == 1.0f && g.amap.group == 0 && !colsum_out) {
+    SmallMArgs sm = {};
+    sm.A = g.A; sm.W = g.B; sm.C = (bf16*)C;
+    sm.M = (int)M; sm.N = (int)N; sm.K = (int)K;
+    sm.lda = lda; sm.ldw = ldb; sm.ldc = ldc; sm.ldr = g.ldr;
+    sm.cmap = g.cmap; sm.bias = g.bias; sm.residual = g.residual; sm.act = g.act;
+    if (N % 16 == 0 && K % 64 == 0)
+      hipLaunchKernelGGL(gemm_small_m_kernel<true>, dim3((unsigned)(N / 16)), dim3(256), 0, stream, sm);
+    else
+      hipLaunchKernelGGL(gemm_small_m_kernel<false>, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, stream, sm);
+    return mpv_check_launch("mpv_gemm_bf16");
+  }
   // byte extents for the buffer descriptors (rows may be gathered through amap/kmap)
   const long long a_rows = transA ? map_row(g.kmap, K - 1) + 1 : map_row(g.amap, M - 1) + 1;
   const long long b_rows = transB ? map_row(g.kmap, K - 1) + 1 : N;

@@ -19,7 +19,6 @@ from typing import Callable, List, Optional
 import torch
 
 from . import ops
-from .ops import ACT_GELU_TANH
 
 
 class BeamHypotheses:
@@ -53,71 +52,71 @@ class BeamHypotheses:
 
 
 class DecodeState:
-    """Per-generation KV caches of a DistributedGPT3 (the InferenceParams of :1444-1473)."""
+    """Per-generation KV caches of a DistributedGPT3 (the InferenceParams of :1444-1473).  A step is ONE call into the
+    C ABI (mpv_gpt_decode_step issues every launch of the incremental forward; the step is launch-bound otherwise)."""
 
     def __init__(self, gpt, batch: int, max_len: int):
+        import ctypes as C
+        from . import _lib
         cfg = gpt.config
         self.gpt, self.batch, self.max_len = gpt, batch, max_len
         self.H, self.np_, self.hn, self.V = cfg.hidden_size, cfg.num_attention_heads, cfg.kv_channels, cfg.vocab_size
-        dev = gpt.dist_model.language_model.embedding.word_embeddings.weight.device
-        nl = len(gpt.dist_model.language_model.encoder.layers)
-        shape = (nl, batch * max_len, 3 * self.H)
-        self.cache = torch.zeros(shape, dtype=torch.bfloat16, device=dev)
+        assert self.V % 8 == 0, "vocab_size must be a multiple of 8"
+        lm = gpt.dist_model.language_model
+        dev = lm.embedding.word_embeddings.weight.device
+        self.nl = nl = len(lm.encoder.layers)
+        self.cache = torch.zeros((nl, batch * max_len, 3 * self.H), dtype=torch.bfloat16, device=dev)
         self.twin = None                      # allocated on the first beam re-order
         self.pos = 0                          # rows cached so far (per sequence)
+        # weight table (device pointers; the parameters outlive the state)
+        self._layers = (_lib.GptLayerWeights * nl)()
+        for i, layer in enumerate(lm.encoder.layers):
+            att, mlp, w = layer.self_attention, layer.mlp, self._layers[i]
+            w.ln1_w, w.ln1_b = layer.input_layernorm.weight.data_ptr(), layer.input_layernorm.bias.data_ptr()
+            w.qkv_w, w.qkv_b = att.query_key_value.weight.data_ptr(), att.query_key_value.bias.data_ptr()
+            w.dense_w, w.dense_b = att.dense.weight.data_ptr(), att.dense.bias.data_ptr()
+            w.ln2_w, w.ln2_b = layer.post_attention_layernorm.weight.data_ptr(), layer.post_attention_layernorm.bias.data_ptr()
+            w.fc1_w, w.fc1_b = mlp.dense_h_to_4h.weight.data_ptr(), mlp.dense_h_to_4h.bias.data_ptr()
+            w.fc2_w, w.fc2_b = mlp.dense_4h_to_h.weight.data_ptr(), mlp.dense_4h_to_h.bias.data_ptr()
+        fl = lm.encoder.final_layernorm
+        self._w = _lib.GptWeights(nl, self.H, self.np_, lm.encoder.layers[0].mlp.dense_h_to_4h.out_features, self.V,
+                                  float(fl.eps), self._layers, lm.embedding.word_embeddings.weight.data_ptr(),
+                                  lm.embedding.position_embeddings.weight.data_ptr(), fl.weight.data_ptr(), fl.bias.data_ptr())
+        self._ptrs = lambda t: (C.c_void_p * nl)(*[t[i].data_ptr() for i in range(nl)])
+        self._cache_ptrs = self._ptrs(self.cache)
+        self._twin_ptrs = None
 
     # ------------------------------------------------------------------ one incremental forward
     def step(self, tokens: Optional[torch.Tensor], query_embeds: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """tokens [B, n_tok] int64 (may be None/empty only with query_embeds), query_embeds [B, Q, H] for the first
-        call.  Appends Q + n_tok positions per sequence and returns the logits of the last one: [B, V] bf16."""
-        gpt, B, H, np_, hn, V, Smax = self.gpt, self.batch, self.H, self.np_, self.hn, self.V, self.max_len
-        lm = gpt.dist_model.language_model
+        """tokens [B, n_tok] int64, query_embeds [B, Q, H] for the first call.  Appends Q + n_tok positions per
+        sequence and returns the logits of the last one: [B, V] bf16."""
+        import ctypes as C
+        from . import _lib
+        B, H = self.batch, self.H
         qf = None if query_embeds is None else query_embeds.reshape(-1, H).to(torch.bfloat16).contiguous()
         Q = 0 if qf is None else qf.shape[0] // B
         L = 0 if tokens is None else tokens.shape[1]
-        n, pos0 = Q + L, self.pos
-        assert n > 0 and pos0 + n <= Smax, (n, pos0, Smax)
-        ids = tokens.contiguous() if L else torch.zeros((B, 0), dtype=torch.long, device=self.cache.device)
-        wpe = lm.embedding.position_embeddings.weight[pos0:]
-        h = ops.gpt_embed_fwd(qf, ids, lm.embedding.word_embeddings.weight, wpe, B, Q, L, H)
-        R = B * n
-        st3 = (Smax * 3 * H, 3 * hn, 3 * H)
-        lay = ops.AttnLayout(st3, st3, st3, (n * H, hn, H))
-        scale = 1.0 / math.sqrt(hn)
-        for li, layer in enumerate(lm.encoder.layers):
-            att, mlp = layer.self_attention, layer.mlp
-            c = self.cache[li]
-            x1, _, _ = ops.layernorm_fwd(h, layer.input_layernorm.weight, layer.input_layernorm.bias, layer.input_layernorm.eps, R, H,
-                                         want_stats=False)
-            ops.gemm(x1, att.query_key_value.weight, R, 3 * H, H, bias=att.query_key_value.bias, out=c, cmap=(n, Smax, pos0))
-            ctx = torch.empty((R, H), dtype=torch.bfloat16, device=h.device)
-            ops.attn_fwd(c[pos0:], c[:, hn:], c[:, 2 * hn:], ctx, lay, B, np_, n, pos0 + n, hn, causal=True, scale=scale)
-            h1 = ops.gemm(ctx, att.dense.weight, R, H, H, bias=att.dense.bias, residual=h)
-            x2, _, _ = ops.layernorm_fwd(h1, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.bias,
-                                         layer.post_attention_layernorm.eps, R, H, want_stats=False)
-            F4 = mlp.dense_h_to_4h.out_features
-            g = ops.gemm(x2, mlp.dense_h_to_4h.weight, R, F4, H, bias=mlp.dense_h_to_4h.bias, act=ACT_GELU_TANH)
-            h = ops.gemm(g, mlp.dense_4h_to_h.weight, R, H, F4, bias=mlp.dense_4h_to_h.bias, residual=h1)
-        self.pos = pos0 + n
-        if n > 1:       # LM head on the last position of every sequence only
-            rows = (torch.arange(B, device=h.device) * n + (n - 1)).contiguous()
-            h = ops.gather_rows(h, rows, B, H)
-        fl = lm.encoder.final_layernorm
-        xf, _, _ = ops.layernorm_fwd(h, fl.weight, fl.bias, fl.eps, B, H, want_stats=False)
-        Vp = (V + 7) // 8 * 8
-        assert Vp == V, "vocab_size must be a multiple of 8"
-        return ops.gemm(xf, lm.embedding.word_embeddings.weight, B, V, H)
+        ids = tokens.contiguous() if L else None
+        wsn = _lib.lib().mpv_gpt_decode_workspace_size(C.byref(self._w), B, Q + L)
+        ws = ops.workspace(wsn, self.cache.device)
+        logits = torch.empty((B, self.V), dtype=torch.bfloat16, device=self.cache.device)
+        ops.check(_lib.lib().mpv_gpt_decode_step(C.byref(self._w), self._cache_ptrs, B, self.max_len, self.pos, ops._p(qf), Q, ops._p(ids), L,
+                                                 ws.data_ptr(), ws.numel(), logits.data_ptr(), ops._stream()), "mpv_gpt_decode_step")
+        self.pos += Q + L
+        return logits
 
     def reorder(self, batch_idx: torch.Tensor):
-        """swap_key_value_dict(:1459-1473): sequence j continues from the cache of sequence batch_idx[j]."""
+        """swap_key_value_dict(:1459-1473): sequence j continues from the cache of sequence batch_idx[j].  The layers
+        are one allocation, so the whole re-order is a single strided row gather over (layer, sequence) rows."""
         if self.twin is None:
             self.twin = torch.empty_like(self.cache)
-        cols = self.pos * 3 * self.H
+            self._twin_ptrs = self._ptrs(self.twin)
+        B, nl = self.batch, self.nl
+        idx = (torch.arange(nl, device=self.cache.device)[:, None] * B + batch_idx.to(torch.int64)[None]).reshape(-1).contiguous()
         pitch = self.max_len * 3 * self.H
-        idx = batch_idx.to(torch.int64).contiguous()
-        for li in range(self.cache.shape[0]):
-            ops.gather_rows_ld(self.cache[li], idx, self.twin[li], self.batch, cols, pitch, pitch)
+        ops.gather_rows_ld(self.cache, idx, self.twin, nl * B, self.pos * 3 * self.H, pitch, pitch)
         self.cache, self.twin = self.twin, self.cache
+        self._cache_ptrs, self._twin_ptrs = self._twin_ptrs, self._cache_ptrs
 
 
 # ---------------------------------------------------------------------------------------------- sampling helpers

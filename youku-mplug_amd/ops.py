@@ -309,8 +309,9 @@ def logprob_topk(logits, k, add=None, rows=None, vocab=None, ld=None):
     vocab = vocab if vocab is not None else logits.shape[-1]
     val = torch.empty((rows, k), dtype=torch.float32, device=logits.device)
     idx = torch.empty((rows, k), dtype=torch.int64, device=logits.device)
-    check(_lib.lib().mpv_logprob_topk(logits.data_ptr(), _p(add), rows, vocab, ld or vocab, k, val.data_ptr(), idx.data_ptr(), _stream()),
-          "mpv_logprob_topk")
+    ws = workspace(_lib.lib().mpv_logprob_topk_workspace_size(rows, k), logits.device)
+    check(_lib.lib().mpv_logprob_topk(logits.data_ptr(), _p(add), rows, vocab, ld or vocab, k, val.data_ptr(), idx.data_ptr(),
+                                      ws.data_ptr(), ws.numel(), _stream()), "mpv_logprob_topk")
     return val, idx
 
 
