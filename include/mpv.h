@@ -231,6 +231,17 @@ int mpv_gpt_decode_step(const mpv_gpt_weights* w, void* const* kv_cache, int bat
 /* beam re-order of all layers: dst[l][j] = src[l][idx[j]] for the first `rows` cached positions */
 int mpv_kv_reorder(void* const* src, void* const* dst, int layers, const int64_t* idx, int batch, int max_len, int rows,
                    int hidden, mpv_stream_t stream);
+/* ------------------------------------------------------------------------------------------
+ * Device-side video input transform (configs' video_pretrain/train/test transforms,
+ * dataset/__init__.py:60-85): the decoder's uint8 clip [T][H][W][3] -> crop (i, j, h, w) ->
+ * torch.nn.functional.interpolate to out_h x out_w (mode 0 nearest / 1 bilinear / 2 bicubic, align_corners=False:
+ * dataset/video_utils/functional.py:51-72, 95-112) -> .long() truncation -> optional horizontal flip
+ * (video_transforms.py:933-936) -> /255 and (x - mean) / std (volume_transforms.py:40-42, functional.py:125-136) ->
+ * bf16, written as planes: element (c, t, y, x) at out[c*c_stride + t*t_stride + y*out_w + x] (a [B,3,T,H,W] batch slot).
+ * mean3 / std3 are host arrays.  (TemporalConsistentRandomAugment is cv2-based and not part of this entry point.) */
+int mpv_video_resized_crop_normalize(const uint8_t* clip, int T, int H, int W, int crop_i, int crop_j, int crop_h, int crop_w,
+                                     int out_h, int out_w, int mode, int flip, const float* mean3, const float* std3, void* out,
+                                     int64_t c_stride, int64_t t_stride, mpv_stream_t stream);
 /* Soft-target contrastive cross-entropy over fp32 similarities sim[rows][cols] (:966-978):
  * targets[i][j] = [row_ids[i]==col_ids[j]] / count_i; losses[i] = -sum_j log_softmax(sim_i)[j] targets[i][j];
  * dsim (bf16, optional) = (softmax - targets) * scale; dts[i] (optional) = sum_j dsim[i][j] * sim[i][j]. */

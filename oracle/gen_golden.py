@@ -234,6 +234,43 @@ def run_caption(name: str = "caption_tiny"):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+VIDEO_CASES = [   # (T, H, W, res, train, python-random seed)
+    (4, 90, 120, 64, True, 3), (3, 120, 90, 64, True, 4), (2, 64, 64, 64, True, 5), (3, 100, 160, 56, False, 0), (2, 48, 40, 64, True, 11),
+]
+
+
+def video_clip(T, H, W, seed):
+    g = torch.Generator().manual_seed(1000 + seed)
+    base = torch.randint(0, 256, (T, H // 4 + 1, W // 4 + 1, 3), generator=g).float()
+    clip = torch.nn.functional.interpolate(base.permute(0, 3, 1, 2), size=(H, W), mode="bilinear").permute(0, 2, 3, 1)
+    noise = torch.randint(-20, 21, (T, H, W, 3), generator=g)
+    return (clip + noise).clamp(0, 255).to(torch.uint8).contiguous()      # smooth + noise: natural-image-like, full 0..255 range
+
+
+def run_video(name: str = "video_tiny"):
+    """the reference's own video transforms (dataset/__init__.py:60-85 minus the cv2
+    RandAugment) on seeded clips; records the crop boxes / flips drawn and the float32 outputs."""
+    import random
+    from .video_ref import import_video_transforms
+    vt, vol = import_video_transforms()
+    mean, std = [0.48145466, 0.4578275, 0.40821073], [0.26862954, 0.26130258, 0.27577711]
+    rec = {"meta": dict(case=name, cases=VIDEO_CASES, torch=str(torch.__version__)), "out": []}
+    for (T, H, W, res, train, seed) in VIDEO_CASES:
+        clip = video_clip(T, H, W, seed)
+        random.seed(seed)
+        if train:
+            tf = vt.Compose([vt.RandomResizedCrop(res, scale=(0.5, 1.0), interpolation="bicubic"), vt.RandomHorizontalFlip(),
+                             vol.ClipToTensor(channel_nb=3), vt.Normalize(mean=mean, std=std)])
+        else:
+            tf = vt.Compose([vt.Resize((res, res)), vol.ClipToTensor(channel_nb=3), vt.Normalize(mean=mean, std=std)])
+        out = tf(clip)
+        rec["out"].append(out.float().clone())
+        print(f"[{name}] T={T} {H}x{W} -> {res} train={train}: min {out.min():.3f} max {out.max():.3f}", flush=True)
+    path = os.path.join(GOLDEN_DIR, f"{name}.pt")
+    torch.save(rec, path)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     for c in (sys.argv[1:] or ["tiny"]):
         if c.startswith("retrieval"):
@@ -244,5 +281,7 @@ if __name__ == "__main__":
             run_eva(c)
         elif c.startswith("caption"):
             run_caption(c)
+        elif c.startswith("video"):
+            run_video(c)
         else:
             run_case(c)

@@ -409,3 +409,27 @@ def test_greedy_sample_host_logic_matches_reference(Q):
     finally:
         G.sample_token = orig
     assert torch.equal(out, ref), (out.tolist(), ref.tolist())
+
+
+def test_video_transform_restatement_and_draws_vs_golden():
+    """with the same python-random seed, VideoInputTransform draws the reference's crop
+    boxes / flips (RandomResizedCrop.get_params + RandomHorizontalFlip call order) and oracle/video_ref.py's plain-torch
+    restatement of crop -> interpolate -> .long() -> flip -> /255 -> normalise reproduces the reference transforms'
+    golden outputs exactly (tests/golden/video_tiny.pt, generated from dataset/video_utils by oracle/gen_golden.py)."""
+    import random
+    from oracle.gen_golden import video_clip
+    from oracle.video_ref import restate_video_transform
+    import youku_mplug_amd  # noqa: F401
+    from youku_mplug_amd.video_input import CLIP_MEAN, CLIP_STD, VideoInputTransform
+    g = torch.load(os.path.join(GOLD, "video_tiny.pt"))
+    for (T, H, W, res, train, seed), ref in zip(g["meta"]["cases"], g["out"]):
+        clip = video_clip(T, H, W, seed)
+        tf = VideoInputTransform(res, train=train)
+        random.seed(seed)
+        if train:
+            box = tf.get_params(H, W)
+            flip = random.random() < 0.5
+        else:
+            box, flip = (0, 0, H, W), False
+        out = restate_video_transform(clip, box, (res, res), tf.interpolation, flip, CLIP_MEAN, CLIP_STD)
+        assert out.shape == ref.shape and torch.equal(out, ref), (T, H, W, res, train, seed, (out - ref).abs().max().item())

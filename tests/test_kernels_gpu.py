@@ -474,3 +474,34 @@ def test_gather_rows_ld(dev):
     idx = torch.tensor([3, 3, 0, 4, 1], device=dev)
     ops.gather_rows_ld(src, idx, dst, 5, 96 * 4, 96 * 7, 96 * 7)
     assert torch.equal(dst[:, :96 * 4], src[idx][:, :96 * 4]) and dst[:, 96 * 4:].abs().max().item() == 0
+
+
+# ------------------------------------------------------------------------------ device-side video input transform
+def test_video_input_transform_vs_reference_golden(dev):
+    """mpv_video_resized_crop_normalize against the reference's own video transforms (tests/golden/video_tiny.pt):
+    same boxes / flips from the same python-random seed; the integer pixel the reference truncates to is reproduced for
+    all but a vanishing fraction of pixels (fp32 summation order inside F.interpolate), never off by more than one level."""
+    import os
+    import random
+    from oracle.gen_golden import video_clip
+    from youku_mplug_amd.video_input import CLIP_STD, VideoInputTransform
+    g = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "video_tiny.pt"))
+    for (T, H, W, res, train, seed), ref in zip(g["meta"]["cases"], g["out"]):
+        clip = video_clip(T, H, W, seed).to(dev)
+        tf = VideoInputTransform(res, train=train)
+        random.seed(seed)
+        out = tf(clip).float().cpu()
+        refb = ref.bfloat16().float()
+        diff = (out - refb).abs()
+        exact = (out == refb).float().mean().item()
+        assert exact >= 0.999, (T, H, W, res, train, exact)
+        assert diff.max().item() <= 1.0 / 255.0 / min(CLIP_STD) + 2e-2, diff.max().item()
+    # batch helper writes every clip into its slot of the [B,3,T,res,res] tensor
+    random.seed(1)
+    clips = [video_clip(2, 40, 56, s).to(dev) for s in (1, 2, 3)]
+    tf = VideoInputTransform(32, train=True)
+    batch = tf.batch(clips)
+    random.seed(1)
+    for b, c in enumerate(clips):
+        assert torch.equal(batch[b], tf(c))
+    assert batch.shape == (3, 3, 2, 32, 32)

@@ -74,6 +74,7 @@ _SIGS = {
     "mpv_l2norm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p]),
     "mpv_l2norm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "mpv_gather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "mpv_video_resized_crop_normalize": (c_int, [c_void_p] + [c_int] * 11 + [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "mpv_scatter_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "mpv_gather_rows_ld": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     "mpv_logprob_topk_workspace_size": (c_size_t, [c_int64, c_int]),

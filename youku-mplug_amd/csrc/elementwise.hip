@@ -476,6 +476,79 @@ __global__ __launch_bounds__(256) void logprob_topk_merge_kernel(const float* __
     pi = bi;
   }
 }
+// ---------------------------------------------------------------- device-side video input transform
+// crop -> F.interpolate (nearest / bilinear / bicubic A=-0.75, align_corners=False: dataset/video_utils/functional.py:
+// 51-72, 95-112) -> .long() (truncation, NO clamp: bicubic overshoot survives) -> flip(W) (video_transforms.py:933-936)
+// -> /255, permute to C,T,H,W (volume_transforms.py:40-42) -> (x - mean) / std (functional.py:125-136) -> bf16
+// (run_pretrain_distributed_gpt3.py:121).  One thread per output pixel, the three interleaved channels together.
+struct VideoTfArgs {
+  const uint8_t* clip;    // [T][H][W][3]
+  bf16* out;              // element (c, t, y, x) at c*c_stride + t*t_stride + y*out_w + x
+  int T, H, W, ci, cj, ch, cw, oh, ow, mode, flip;
+  long long c_stride, t_stride;
+  float mean[3], stdv[3];
+};
+__device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+
+__global__ void video_transform_kernel(const VideoTfArgs p) {
+#pragma clang fp contract(off)
+  const long long n = (long long)p.T * p.oh * p.ow;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % p.ow);
+    const int oy = (int)((i / p.ow) % p.oh);
+    const int t = (int)(i / ((long long)p.ow * p.oh));
+    const uint8_t* frame = p.clip + ((long long)t * p.H + p.ci) * p.W * 3 + (long long)p.cj * 3;   // crop origin
+    const long long rowb = (long long)p.W * 3;
+    float v[3] = {0.f, 0.f, 0.f};
+    if (p.mode == 0) {                       // nearest: min(floor(dst * in/out), in - 1)
+      const int sy = p.oh == p.ch ? oy : min((int)floorf(oy * ((float)p.ch / p.oh)), p.ch - 1);
+      const int sx = p.ow == p.cw ? ox : min((int)floorf(ox * ((float)p.cw / p.ow)), p.cw - 1);
+      const uint8_t* q = frame + sy * rowb + sx * 3;
+      for (int c = 0; c < 3; ++c) v[c] = (float)q[c];
+    } else {
+      const float sch = (float)p.ch / p.oh, scw = (float)p.cw / p.ow;
+      float fy = sch * (oy + 0.5f) - 0.5f, fx = scw * (ox + 0.5f) - 0.5f;
+      if (p.mode == 1) {                     // bilinear
+        fy = fmaxf(fy, 0.f);
+        fx = fmaxf(fx, 0.f);
+        const int y0 = min((int)floorf(fy), p.ch - 1), x0 = min((int)floorf(fx), p.cw - 1);
+        const float ly = fminf(fmaxf(fy - y0, 0.f), 1.f), lx = fminf(fmaxf(fx - x0, 0.f), 1.f);
+        const int y1 = min(y0 + 1, p.ch - 1), x1 = min(x0 + 1, p.cw - 1);
+        const uint8_t *r0 = frame + y0 * rowb, *r1 = frame + y1 * rowb;
+        for (int c = 0; c < 3; ++c) {
+          const float a = (1.f - lx) * r0[x0 * 3 + c] + lx * r0[x1 * 3 + c];
+          const float b = (1.f - lx) * r1[x0 * 3 + c] + lx * r1[x1 * 3 + c];
+          v[c] = (1.f - ly) * a + ly * b;
+        }
+      } else {                               // bicubic, A = -0.75
+        const float A = -0.75f;
+        const int iy = min((int)floorf(fy), p.ch - 1), ix = min((int)floorf(fx), p.cw - 1);
+        const float ly = fminf(fmaxf(fy - iy, 0.f), 1.f), lx = fminf(fmaxf(fx - ix, 0.f), 1.f);
+        const float wy[4] = {cubic2(ly + 1.f, A), cubic1(ly, A), cubic1(1.f - ly, A), cubic2(2.f - ly, A)};
+        const float wx[4] = {cubic2(lx + 1.f, A), cubic1(lx, A), cubic1(1.f - lx, A), cubic2(2.f - lx, A)};
+        int xs[4];
+        for (int k = 0; k < 4; ++k) xs[k] = min(max(ix + k - 1, 0), p.cw - 1) * 3;
+        for (int c = 0; c < 3; ++c) {
+          float acc = 0.f;
+          for (int ky = 0; ky < 4; ++ky) {
+            const uint8_t* r = frame + (long long)min(max(iy + ky - 1, 0), p.ch - 1) * rowb;
+            float rv = wx[0] * r[xs[0] + c];
+            for (int kx = 1; kx < 4; ++kx) rv += wx[kx] * r[xs[kx] + c];
+            acc = ky == 0 ? wy[0] * rv : acc + wy[ky] * rv;
+          }
+          v[c] = acc;
+        }
+      }
+    }
+    const int dx = p.flip ? p.ow - 1 - ox : ox;
+    for (int c = 0; c < 3; ++c) {
+      const float q = truncf(v[c]);                              // .long()
+      const float y = (q / 255.f - p.mean[c]) / p.stdv[c];
+      p.out[c * p.c_stride + t * p.t_stride + (long long)oy * p.ow + dx] = f2bf(y);
+    }
+  }
+}
 // Soft-target contrastive CE (models/distributed_gpt3.py:966-978): targets[i][j] = [ids_r[i]==ids_c[j]] / count_i;
 // loss_i = -sum_j log_softmax(sim_i)[j] * targets[i][j];  dsim = (softmax - targets) * scale (bf16);
 // dts[i] = sum_j dsim[i][j] * sim[i][j] (for the temperature gradient).  One wave per row.
@@ -711,6 +784,23 @@ extern "C" int mpv_logprob_topk(const void* logits, const float* add, int64_t ro
   hipLaunchKernelGGL(logprob_topk_merge_kernel, dim3((unsigned)rows), dim3(256), 0, stream, (const float*)cval, (const int*)cidx,
                      (const float*)pmax, (const float*)psum, add, k, out_val, out_idx);
   return mpv_check_launch("mpv_logprob_topk");
+}
+
+extern "C" int mpv_video_resized_crop_normalize(const uint8_t* clip, int T, int H, int W, int crop_i, int crop_j, int crop_h, int crop_w,
+                                               int out_h, int out_w, int mode, int flip, const float* mean3, const float* std3, void* out,
+                                               int64_t c_stride, int64_t t_stride, hipStream_t stream) {
+  MPV_REQUIRE(clip && out && mean3 && std3, MPV_E_ARG, "mpv_video_resized_crop_normalize: null pointer");
+  MPV_REQUIRE(T > 0 && H > 0 && W > 0 && out_h > 0 && out_w > 0 && crop_h > 0 && crop_w > 0 && crop_i >= 0 && crop_j >= 0 &&
+                  crop_i + crop_h <= H && crop_j + crop_w <= W,
+              MPV_E_SHAPE, "mpv_video_resized_crop_normalize: crop (%d,%d,%d,%d) outside a %dx%d frame", crop_i, crop_j, crop_h, crop_w, H, W);
+  MPV_REQUIRE(mode >= 0 && mode <= 2, MPV_E_ARG, "mpv_video_resized_crop_normalize: mode must be 0 (nearest), 1 (bilinear) or 2 (bicubic)");
+  VideoTfArgs a = {};
+  a.clip = clip; a.out = (bf16*)out;
+  a.T = T; a.H = H; a.W = W; a.ci = crop_i; a.cj = crop_j; a.ch = crop_h; a.cw = crop_w; a.oh = out_h; a.ow = out_w;
+  a.mode = mode; a.flip = flip; a.c_stride = c_stride; a.t_stride = t_stride;
+  for (int c = 0; c < 3; ++c) { a.mean[c] = mean3[c]; a.stdv[c] = std3[c]; }
+  hipLaunchKernelGGL(video_transform_kernel, dim3(ew_grid((long long)T * out_h * out_w)), dim3(256), 0, stream, a);
+  return mpv_check_launch("mpv_video_resized_crop_normalize");
 }
 
 extern "C" int mpv_soft_target_ce(const float* sim, const int64_t* row_ids, const int64_t* col_ids, float scale, float* losses,
