@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE ONLY -- oracle for the device-side video input transform.
 
 (i) import_video_transforms(): the reference's own dataset/video_utils modules, loaded as a synthetic package (the
-    dataset package __init__ pulls in the whole training stack) with import stubs for torchvision / cv2 (oracle/shims);
+    dataset package __init__ pulls in the whole training stack) with import stubs for torchvision / cv2 (oracle/shims_video);
     the tensor code paths used here are pure torch.  This container only.
 (ii) restate_video_transform(): the same chain restated with plain torch (travels to the GPU box):
     crop -> F.interpolate -> .long() -> flip(W) -> /255, C,T,H,W -> (x - mean) / std
@@ -20,17 +20,23 @@ import torch
 import torch.nn.functional as F
 
 REF_ROOT = os.environ.get("MPLUG_REFERENCE_ROOT", "/root/reference")
-_SHIMS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "shims")
+_SHIMS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "shims_video")   # kept apart from oracle/shims: a visible `torchvision` stub confuses transformers
 
 
 def import_video_transforms():
-    if _SHIMS not in sys.path:
-        sys.path.insert(0, _SHIMS)
     if "refvid" not in sys.modules:
         pkg = types.ModuleType("refvid")
         pkg.__path__ = [os.path.join(REF_ROOT, "dataset", "video_utils")]
         sys.modules["refvid"] = pkg
-    return importlib.import_module("refvid.video_transforms"), importlib.import_module("refvid.volume_transforms")
+    sys.path.insert(0, _SHIMS)
+    try:
+        mods = importlib.import_module("refvid.video_transforms"), importlib.import_module("refvid.volume_transforms")
+    finally:
+        sys.path.remove(_SHIMS)
+        for name in [n for n in sys.modules if n == "cv2" or n == "torchvision" or n.startswith("torchvision.")]:
+            if str(getattr(sys.modules[name], "__file__", "") or "").startswith(_SHIMS):
+                del sys.modules[name]          # the stubs must not leak to other importers (transformers probes torchvision)
+    return mods
 
 
 def restate_video_transform(clip_u8, box, size, mode, flip, mean, std):
