@@ -317,17 +317,21 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs p) {
 }
 
 // =========================================================================== delta = rowsum(dO * O)
-__global__ void attn_delta_kernel(const AttnArgs p, int hd) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
-  if (row >= p.sq) return;
-  const bf16* o = p.o + b * p.o_bs + h * p.o_hs + (long long)row * p.o_rs;
-  const bf16* d = p.dO + b * p.o_bs + h * p.o_hs + (long long)row * p.o_rs;
+// delta_i = sum_d dO[i][d] * O[i][d] from the row fragments a dQ wave already holds for dO (and loads once for O):
+// lanes l and l^32 own the two halves of row (l & 31).  The dQ kernel also stores it for the dK/dV kernel that follows.
+template <int HD>
+__device__ __forceinline__ float row_delta(const bf16x8 (&dof)[HD / 16], const bf16* obase, long long rs, int row, int nrows, int lane,
+                                           int hd) {
+  bf16x8 of[HD / 16];
+  load_row_frags<HD>(of, obase, rs, row, nrows, lane, hd);
   float s = 0.f;
-  for (int c = lane * 2; c < hd; c += 128) s += bf2f(o[c]) * bf2f(d[c]) + bf2f(o[c + 1]) * bf2f(d[c + 1]);
-  s = wave_sum(s);
-  if (lane == 0) p.delta[(long long)bh * p.sq + row] = s;
+#pragma unroll
+  for (int st = 0; st < HD / 16; ++st) {
+    const f32x8 a = cvt8(dof[st]), b = cvt8(of[st]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += a[e] * b[e];
+  }
+  return s + __shfl_xor(s, 32, 64);
 }
 
 // =========================================================================== backward: dQ
@@ -358,7 +362,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttnArgs p) {
   }
   const bool qok = qrow < p.sq;
   const float lse = qok ? p.lse[(long long)bh * p.sq + qrow] : INFINITY;
-  const float dl = qok ? p.delta[(long long)bh * p.sq + qrow] : 0.f;
+  const float dl = row_delta<HD>(dof, p.o + b * p.o_bs + h * p.o_hs, p.o_rs, qrow, p.sq, lane, p.hd);
+  if (qok && lane < 32) p.delta[(long long)bh * p.sq + qrow] = dl;
   const int blk_last_q = min(p.sq - 1, blockIdx.x * rows_per_blk + rows_per_blk - 1);
   const int nchunk = last_visible_key(p, blk_last_q) / CH + 1;
   const int my_last = last_visible_key(p, qrow);
@@ -771,7 +776,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const AttnArgs p) 
   }
   const bool qok = qrow < p.sq;
   const float lse = qok ? p.lse[(long long)bh * p.sq + qrow] : INFINITY;
-  const float dl = qok ? p.delta[(long long)bh * p.sq + qrow] : 0.f;
+  const float dl = row_delta<HD>(dof, p.o + b * p.o_bs + h * p.o_hs, p.o_rs, qrow, p.sq, lane, p.hd);
+  if (qok && lane < 32) p.delta[(long long)bh * p.sq + qrow] = dl;
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
   if (q0 >= p.sq) return;
@@ -1276,8 +1282,7 @@ extern "C" int mpv_attn_bwd(const mpv_attn_desc* d, const void* dO, void* dq, vo
   a.dk = (bf16*)dk;
   a.dv = (bf16*)dv;
   a.delta = delta;
-  dim3 block(256);
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((d->sq + 3) / 4, d->batch * d->heads), block, 0, stream, a, d->head_dim);
+  // delta = rowsum(dO * O) is produced by the dQ kernel (row_delta) and read by the dK/dV kernel launched after it
   if (d->sk <= RES_MAX_ROWS && d->sq <= RES_MAX_ROWS) {
     res_attr_once();
     const int nw = waves_for(d->sq);
