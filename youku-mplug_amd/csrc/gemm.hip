@@ -454,8 +454,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
   }
 }
 
-// sum split-K fp32 partials -> bf16 (optionally accumulating into the existing bf16 value)
-__global__ void splitk_reduce_kernel(const float* part, bf16* out, long long MN, int splits, int accumulate) {
+// sum split-K fp32 partials -> bf16 (optionally accumulating into the existing bf16 value); the trailing workgroups of
+// the same launch finish the fused bias gradient (column sums of dY over the K splits)
+__global__ void splitk_reduce_kernel(const float* part, bf16* out, long long MN, int splits, int accumulate, int mn_blocks,
+                                     const float* colsum_part, bf16* colsum_out, int M) {
+  if ((int)blockIdx.x >= mn_blocks) {
+    const int m = ((int)blockIdx.x - mn_blocks) * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float a = 0.f;
+    for (int z = 0; z < splits; ++z) a += colsum_part[(long long)z * M + m];
+    colsum_out[m] = f2bf(a);
+    return;
+  }
   const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= MN) return;
   f32x4 s = *(const f32x4*)(part + i);
@@ -749,11 +759,12 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
     const long long MN = (long long)M * N;
     const int thr = 256;
     const long long blocks = (MN / 4 + thr - 1) / thr;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(thr), 0, stream, (const float*)workspace,
-                       (bf16*)user_c, MN, splitk, user_acc);
-  }
-  if (colsum_out)
+    const int cblocks = colsum_out ? (int)((M + thr - 1) / thr) : 0;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(blocks + cblocks)), dim3(thr), 0, stream, (const float*)workspace,
+                       (bf16*)user_c, MN, splitk, user_acc, (int)blocks, (const float*)g.colsum_part, (bf16*)colsum_out, (int)M);
+  } else if (colsum_out) {
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, (const float*)g.colsum_part,
                        (bf16*)colsum_out, (int)M, splitk);
+  }
   return mpv_check_launch("mpv_gemm_bf16");
 }
