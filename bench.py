@@ -101,6 +101,22 @@ def pmc_traffic():
         return None
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner to the C stdout when its communicator comes up; rank 0's stdout must carry exactly
+    one JSON line, so the banner is steered to stderr (fd-level, restored afterwards)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def host_cores():
     """Cores this process may actually use: min(affinity, cgroup cpu quota)."""
     try:
@@ -181,9 +197,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # MPV_BENCH_FORCE_DIST=1 runs the distributed code path (RCCL init, broadcast, barriers, bucketed all-reduce, max-over-ranks
+    # timing) even at world size 1 -- the only way to exercise it on a 1-GPU box
+    dist_on = world > 1 or os.environ.get("MPV_BENCH_FORCE_DIST", "0") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29577")
+        with _StdoutToStderr():
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.barrier()                                               # brings the communicator (and its banner) up now
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
 
     import youku_mplug_amd  # noqa: F401  raises if libmpv_hip.so is missing
@@ -198,13 +220,15 @@ def main():
         for blk in model.visual_encoder.blocks:
             blk.temporal_fc.weight.normal_(0, 0.015)
         model.visual_encoder.temporal_embed.normal_(0, 0.015)
-    if world > 1:                                                    # identical replicas
+    if dist_on:                                                      # identical replicas
         for p in model.parameters():
             dist.broadcast(p.data, 0)
     model.train()
     groups = eng.get_parameter_groups(model, 0.05, model.no_weight_decay(), visual_backbone_scale=True)
     engine, opt, _, _ = eng.initialize(model=model, model_parameters=groups,
                                        config=dict(lr=1e-4, opt_betas=(0.9, 0.999), opt_eps=1e-6, clip_grad=3.0))
+    if dist_on and world == 1:
+        engine.reducer.always = True
     B, T, L = args.batch, args.frames, args.text_len
     video = torch.randn(B, 3, T, 224, 224, device=dev).to(torch.bfloat16)
     ids = torch.randint(0, Shapes.vocab, (B, L), device=dev)
@@ -229,7 +253,7 @@ def main():
     torch.cuda.synchronize()
     log("warmup done")
     def fence():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
     fence()
@@ -238,7 +262,7 @@ def main():
         loss = step(args.warmup + i)
     fence()
     dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = dt.item()
     final_loss = loss.item()
@@ -265,7 +289,7 @@ def main():
                             for k, v in tot.items()},
                 "step_algorithmic_tflop": round(algorithmic_train_flops(B, T, L) / 1e12, 2),
                 "step_frac": round(algorithmic_train_flops(B, T, L) / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4)}
-    if world > 1:
+    if dist_on:
         dist.barrier()
     if rank == 0:
         cpu = None
@@ -283,7 +307,7 @@ def main():
                           "trainable_params_m": round(engine.flat.numel / 1e6, 1), "final_loss": round(final_loss, 4)},
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -115,9 +115,10 @@ class DPReducer:
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.pending = []
         self.launched = set()
+        self.always = False      # run the collectives even on a 1-rank group (single-GPU validation of the exchange path)
 
     def stage_ready(self, name: str):
-        if self.world == 1 or name in self.launched or name not in self.flat.stage_slices:
+        if (self.world == 1 and not self.always) or name in self.launched or name not in self.flat.stage_slices:
             return
         a, b = self.flat.stage_slices[name]
         self.launched.add(name)
@@ -125,7 +126,7 @@ class DPReducer:
 
     def finish(self):
         """Launch whatever was not announced, then make the current stream wait for every bucket."""
-        if self.world > 1:
+        if self.world > 1 or self.always:
             for name in self.flat.stage_slices:
                 self.stage_ready(name)
             for w in self.pending:
