@@ -328,6 +328,35 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
   constexpr int CP = 132;
   float* cs = (float*)smem;
   __syncthreads();   // every wave is done with the operand tiles
+  // Plain epilogue (bias only, bf16 out: the qkv / projection GEMMs and every plain dgrad): add the bias in the MFMA
+  // layout, round to bf16 in registers and stage the WHOLE tile once as bf16 (pitch 136 elements) -- half the LDS
+  // traffic and one barrier pair instead of two; the stores stay 16-byte row-contiguous.
+  if (parts == 1 && !p.out_f32 && !p.act && !p.act_bwd && !p.residual && !p.drop_thr && !p.accumulate && !p.preact) {
+    constexpr int BP = 136;
+    bf16* cb = (bf16*)smem;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = wcol * 64 + j * 32 + 8 * q + 4 * (lane >> 5);
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * alpha;
+          if (p.bias && n0 + col < p.N) v += cvt4(*(const bf16x4*)(p.bias + n0 + col));
+          *(bf16x4*)(cb + (wrow * 64 + i * 32 + (lane & 31)) * BP + col) = cvt4(v);
+        }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int c = tid + 256 * it;
+      const int row = c >> 4, col = (c & 15) * 8;
+      const int m = m0 + row, n = n0 + col;
+      if (m < p.M && n < p.N) *(bf16x8*)((bf16*)p.C + map_row(p.cmap, m) * p.ldc + n) = *(const bf16x8*)(cb + row * BP + col);
+    }
+    return;
+  }
   auto stage = [&](int half) {
     if (wrow == half) {
 #pragma unroll
