@@ -91,14 +91,14 @@ class GemmTimer:
 
 
 def pmc_traffic():
-    """HBM bytes per GEMM launch from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE doubled per the
+    """(HBM bytes per GEMM launch, provenance) from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE doubled per the
     gfx950 note in MI355X_MICROARCH.md, + WRITE_SIZE; tools/rocpd_pmc.py writes the file).  None when no profile is committed."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_gemm_latest.json")
     try:
         rec = json.load(open(path))
-        return {"hbm_mb_per_launch": rec["hbm_mb_per_launch"], "source": rec.get("source", "profiles/pmc_gemm_latest.json")}
+        return float(rec["hbm_mb_per_launch"]) * 1e6, rec.get("source", "profiles/pmc_gemm_latest.json")
     except (OSError, ValueError, KeyError):
-        return None
+        return None, None
 
 
 class _StdoutToStderr:
@@ -280,9 +280,11 @@ def main():
         tt = sum(v[1] for v in tot.values())
         n = sum(v[2] for v in tot.values())
         by = sum(v[3] for v in tot.values())
+        traffic, traffic_src = pmc_traffic()
         roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel<TA,TB> (fwd/dgrad/wgrad)", "achieved": round(fl / tt / 1e12, 1),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / tt / 1e12 / PEAK_BF16_TFLOPS, 4),
-                "traffic": pmc_traffic(), "algorithmic_mb_per_launch": round(by / n / 1e6, 1),
+                "traffic": traffic, "traffic_unit": "bytes per launch (L2-miss side: 2*FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": round(by / n, 0),
                 "launches_per_step": n // nroof, "avg_launch_us": round(tt / n * 1e6, 1), "avg_launch_gflop": round(fl / n / 1e9, 2),
                 "gemm_ms_per_step": round(tt / nroof * 1e3, 2),
                 "by_kernel": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / nroof * 1e3, 2), "launches": v[2] // nroof}
