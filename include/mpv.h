@@ -77,6 +77,8 @@ typedef struct mpv_gemm_epilogue {
   int accumulate;         /* C += result                                                      */
   void* colsum_out;       /* wgrad only: bf16 [M] = column sums of A over the (mapped) reduction rows,
                              i.e. the bias gradient that goes with dW = dY^T X, fused into the same pass */
+  int tile_hint;          /* 0: the library picks the tile kernel per problem; 128 / 256 pin the 128x128 or the
+                             256x256 eight-phase kernel where it applies (tests and measurements)              */
 } mpv_gemm_epilogue;
 
 size_t mpv_gemm_workspace_size(int64_t M, int64_t N, int64_t K, int transA, int transB);

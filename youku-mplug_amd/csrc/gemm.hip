@@ -24,8 +24,11 @@
 // columns of one output row -> 8-byte packed bf16 stores and a cheap fused epilogue
 // (bias, erf/tanh GELU (+pre-activation copy), GELU-backward multiply, dropout, residual).
 // Workgroup ids are remapped so that each XCD (private L2) walks a contiguous range of tiles.
+#include <stdlib.h>
+
 #include "mpv_common.h"
 #include "mpv_kernels.h"
+#include "gemm_args.h"
 
 namespace {
 
@@ -33,39 +36,6 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand tile
 constexpr unsigned TAIL_WS_BYTES_DEV = 512u * 128 * 128 * 4;   // partial-tile workspace of the tail split (32 MiB)
 
-struct GemmArgs {
-  const bf16* A;
-  const bf16* B;
-  void* C;
-  int M, N, K;
-  long long lda, ldb, ldc;
-  RowMap amap, cmap, kmap;
-  uint32_t a_bytes, b_bytes;
-  const bf16* bias;
-  int act;
-  bf16* preact;
-  const bf16* residual;
-  long long ldr;
-  const bf16* actz;
-  long long ldz;
-  int act_bwd;
-  float drop_scale;
-  uint32_t drop_thr;
-  uint64_t seed, drop_offset;
-  const float* alpha_dev;
-  float alpha;
-  int out_f32;
-  int accumulate;
-  int k_per_split;
-  int tiles_n, tiles_m;
-  int nwg, splits;
-  float* colsum_part;   // wgrad only: [splits][M] fp32 partial column sums of the A operand (bias gradient)
-  // tail split: the last `tiles % 512` tiles (a mostly empty final round of the 512 resident slots) are cut
-  // tail_g ways along K; partial tiles meet in tail_ws and the last workgroup to arrive finishes the tile
-  int tail_start, tail_g, tail_steps;
-  float* tail_ws;
-  unsigned* tail_cnt;
-};
 
 // LDS byte address of 16-byte chunk `kc` (0..7) of `row` in a k-contiguous [128][64] tile.
 __device__ __forceinline__ int lds_addr_kc(int row, int kc) { return row * 128 + ((kc ^ ((row >> 1) & 7)) << 4); }
@@ -652,6 +622,31 @@ static int choose_splitk(int64_t M, int64_t N, int64_t K, size_t ws_bytes) {
   return best;
 }
 
+// MPV_GEMM_KERNEL=128|256 pins the tile kernel (measurement aid); anything else = choose per problem
+static int gemm_variant() {
+  static const int v = [] {
+    const char* e = getenv("MPV_GEMM_KERNEL");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+
+// wgrad split for the 256x256 kernel: fill whole rounds of the 256 CUs, at least 8 K-tiles per split
+static int choose_splitk256(int64_t tiles, int64_t K, int64_t M, int64_t N, size_t ws_bytes) {
+  int best = 1;
+  double best_eff = 0.0;
+  for (int s = 1; s <= 64; ++s) {
+    if (s > 1 && (K / s < 8 * 64 || (size_t)M * N * sizeof(float) * s + (size_t)s * M * sizeof(float) > ws_bytes)) break;
+    const int64_t blocks = tiles * s;
+    const double eff = (double)blocks / (double)(((blocks + 255) / 256) * 256);
+    if (eff > best_eff + 0.02) {
+      best_eff = eff;
+      best = s;
+    }
+  }
+  return best;
+}
+
 extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                              int64_t ldb, int64_t ldc, int transA, int transB, const mpv_gemm_epilogue* ep,
                              void* workspace, size_t workspace_bytes, hipStream_t stream) {
@@ -740,6 +735,52 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
     splitk = (int)((K + kps - 1) / kps);
   }
   g.k_per_split = kps;
+
+  // ---- 256x256 eight-phase kernel (gemm256.hip) for the problems that fill the chip with 256-tiles
+  const int variant = (ep && ep->tile_hint) ? ep->tile_hint : gemm_variant();
+  if (variant != 128 && K % 64 == 0 && M >= 256 && N >= 256) {
+    const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
+    int s256 = 1;
+    if (transA && transB && !g.out_f32) s256 = choose_splitk256(t256, K, M, N, workspace ? workspace_bytes : 0);
+    {   // measured on MI355X (tools/gemm_ab.py): the 256x256 kernel wins on every eligible shape of the path, also when
+        // its tiles fill only 5/8 of the CUs (M = 5120, N = 2048: 959 vs 764 TFLOP/s)
+      GemmArgs h = g;
+      h.splits = s256;
+      h.k_per_split = (int)K;
+      if (s256 > 1) {
+        h.k_per_split = (int)(((K / 64 + s256 - 1) / s256) * 64);
+        h.splits = (int)((K + h.k_per_split - 1) / h.k_per_split);
+      }
+      void* user_c256 = C;
+      const int user_acc256 = g.accumulate;
+      bool ok = true;
+      if (colsum_out) {
+        const size_t need = (size_t)(h.splits > 1 ? h.splits : 0) * M * N * sizeof(float) + (size_t)h.splits * M * sizeof(float);
+        ok = workspace && workspace_bytes >= need;
+        h.colsum_part = (float*)((char*)workspace + (size_t)(h.splits > 1 ? h.splits : 0) * M * N * sizeof(float));
+      }
+      if (h.splits > 1) {
+        ok = ok && !g.bias && !g.act && !g.residual && !g.act_bwd && !g.drop_thr && g.cmap.group == 0 && ldc == N;
+        h.C = workspace;
+        h.out_f32 = 1;
+        h.accumulate = 0;
+      }
+      if (ok && mpv_gemm256_try_launch(h, transA, transB, stream)) {
+        if (h.splits > 1) {
+          const long long MN = (long long)M * N;
+          const int thr = 256;
+          const long long rblocks = (MN / 4 + thr - 1) / thr;
+          const int cblocks = colsum_out ? (int)((M + thr - 1) / thr) : 0;
+          hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(rblocks + cblocks)), dim3(thr), 0, stream, (const float*)workspace,
+                             (bf16*)user_c256, MN, h.splits, user_acc256, (int)rblocks, (const float*)h.colsum_part, (bf16*)colsum_out, (int)M);
+        } else if (colsum_out) {
+          hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, (const float*)h.colsum_part,
+                             (bf16*)colsum_out, (int)M, 1);
+        }
+        return mpv_check_launch("mpv_gemm_bf16");
+      }
+    }
+  }
 
   // tail split of a mostly empty last round (see GemmArgs); needs the partial-tile workspace
   int grid_x = g.nwg;

@@ -1,0 +1,475 @@
+// gemm256.hip -- 256x256x64 eight-phase bf16 MFMA GEMM for gfx950 (CDNA4), hand-written.
+//
+//   C[M,N] = epilogue( sum_k Aop(m,k) * Bop(n,k) )        (same operand conventions as gemm.hip)
+//
+// Replaces the same reference call sites as gemm.hip (F.linear / mpu.Column/RowParallelLinear and their autograd
+// backward: models/vision_transformer.py:104,108,175,205,250; models/modeling_distributed_gpt3.py:562,573,843,852,1348).
+//
+// Structure (one 512-thread workgroup per CU, 8 waves = 2 (M) x 4 (N), each wave a 128x64 output = 32 accumulator
+// tiles of v_mfma_f32_16x16x32_bf16):
+//
+//  * LDS holds a ring of 8 "units" of 16 KiB = two K-tiles (BK = 64) of 4 units each.  A unit is the part of a K-tile
+//    that one phase of the schedule reads:   U0 = A rows {0..63, 128..191}   (first 64-row half of both wave rows)
+//                                             U1 = B rows {64w..64w+31}       (first 32-column half of every wave column)
+//                                             U2 = B rows {64w+32..64w+63}    U3 = A rows {64..127, 192..255}
+//    so that a unit is dead as soon as its phase has read it and can be refilled two phases later.
+//  * Every unit is filled by LDS-DMA (buffer_load_dwordx4 ... lds, 2 per thread per unit).  The DMA writes LDS
+//    lane-linearly, so the bank-conflict-avoiding XOR swizzles are applied to the per-lane GLOBAL source address and
+//    again on the LDS read.  k-contiguous operands: [128 rows][64 k] image, 16-byte chunk index ^ ((row >> 1) & 7),
+//    read with ds_read_b128.  Reduction-slow operands (dgrad / wgrad): [64 k][128 cols] image, 32-byte unit index
+//    ^ f8(k), read with ds_read_b64_tr_b16 (the transposing LDS read) -- no transposed copies of anything.
+//  * The K loop runs 4 phases per K-tile.  A phase is {ds_reads of this phase's unit(s); issue the DMA of the unit
+//    six phases ahead; s_waitcnt vmcnt(6); s_barrier; 16 MFMAs (one 64x32 quadrant x K=64); s_barrier}.  The two wave
+//    rows run the same code offset by one barrier, so on every SIMD one wave is in its MFMA segment while the other
+//    one reads LDS and issues DMA.  vmcnt is never drained inside the loop: three units (6 DMA instructions per lane)
+//    stay in flight across the barriers; a unit is read two phases after the wait that retires it.
+//  * MFMA operands are swapped (D = Bfrag x Afrag) so a lane owns 4 consecutive output columns of one row; the
+//    epilogue rounds (acc * alpha + bias) to bf16 in registers, stages the whole 256x256 tile in LDS and finishes it
+//    row-contiguously with 16-byte loads/stores (activation (+pre-activation copy), activation-backward multiply,
+//    dropout, residual, accumulate, C row map).  fp32 outputs (split-K partials) are staged in four 64-row passes.
+//  * wgrad: the fused bias gradient (column sums of the A operand) is one extra MFMA per A fragment against a
+//    constant ones operand, spread over the four wave columns.
+#include <type_traits>
+
+#include "mpv_common.h"
+#include "mpv_kernels.h"
+#include "gemm_args.h"
+
+namespace {
+
+constexpr int TM = 256, TN = 256, TK = 64;
+constexpr int UNIT = 16384;                    // bytes per ring unit
+constexpr int CPITCH = 264;                    // bf16 staging pitch (elements): 528-byte rows keep 16-byte alignment
+constexpr int FPITCH = 260;                    // fp32 staging pitch (floats) of a 64-row pass
+constexpr int SMEM_BYTES = TM * CPITCH * 2;    // 135168 >= 8 * UNIT
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+template <int V>
+using IC = std::integral_constant<int, V>;
+
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+__device__ __forceinline__ bf16x8 lds_read_tr8(const char* p) {
+  // two transposing reads: k rows +0..3 and +4..7 (1 KiB apart in the [k][256 B] image)
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 1024));
+  union {
+    struct { s16x4 a, b; } s;
+    bf16x8 v;
+  } u;
+  u.s.a = lo;
+  u.s.b = hi;
+  return u.v;
+}
+
+// LDS-DMA of 16 bytes per lane (1 KiB per wave) to LDS byte address `lds_addr` (wave-uniform) + 16 * lane, from
+// rsrc base + soff + voff.  Inline asm on purpose: hipcc orders every LDS read it cannot disambiguate behind a
+// pending buffer_load..lds it knows about with s_waitcnt vmcnt(0) (seen in the .s for ds_read_b64_tr_b16), which would
+// drain the ring every phase; the waits for these DMAs are the counted s_waitcnt vmcnt(N) of the schedule below.
+__device__ __forceinline__ void dma16(i32x4 rsrc, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+               : "memory");
+}
+__device__ __forceinline__ i32x4 raw_rsrc(const void* ptr, uint32_t bytes) {
+  const uint64_t a = (uint64_t)ptr;
+  return i32x4{(int)(uint32_t)a, (int)((uint32_t)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+
+template <bool TA, bool TB, bool KMAP>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
+  __shared__ __attribute__((aligned(1024))) char smem[SMEM_BYTES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int l15 = lane & 15, lg = lane >> 4;
+
+  // ---- workgroup -> (split, tile): XCD-aware bijective remap (workgroup b runs on XCD b % 8; each XCD walks a contiguous
+  // range), then GM m-tiles per n-tile inside the range so the 32 workgroups resident on an XCD share panels in its L2.
+  const int nwg = p.nwg * p.splits;
+  const int bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int split = lin / p.nwg;
+  const int pid = lin - split * p.nwg;
+  const int GM = p.gm;
+  const int gsz = GM * p.tiles_n;
+  const int grp = pid / gsz, rem = pid - grp * gsz;
+  const int gm = min(GM, p.tiles_m - grp * GM);
+  const int tile_n = rem / gm, tile_m = grp * GM + (rem - tile_n * gm);
+  const int m0 = tile_m * TM, n0 = tile_n * TN;
+
+  const int kbeg = split * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int nk = (kend - kbeg) / TK;            // launcher guarantees whole K-tiles
+
+  const i32x4 ra = raw_rsrc(p.A, p.a_bytes);
+  const i32x4 rb = raw_rsrc(p.B, p.b_bytes);
+  const uint32_t smem_base = (uint32_t)(uintptr_t)(lds_void*)smem;
+
+  // ---- per-lane DMA source offsets (bytes) of the 2 instructions a thread issues per unit
+  constexpr uint32_t OOB = 0x80000000u;
+  uint32_t vo[4][2];
+  constexpr bool kmapped = KMAP;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    if constexpr (!TA) {   // [128 rows][64 k] image: instruction (wave, j) covers unit rows 16*wave + 8*j + lane/8
+      const int ur = wave * 16 + j * 8 + (lane >> 3);
+      const int kc = (lane & 7) ^ (j * 4 + (lane >> 4));          // = chunk slot ^ ((ur >> 1) & 7)
+      const int mA = m0 + (ur >> 6) * 128 + (ur & 63);
+      vo[0][j] = mA < p.M ? (uint32_t)((map_row(p.amap, mA) * p.lda + kc * 8) * 2) : OOB;
+      vo[3][j] = mA + 64 < p.M ? (uint32_t)((map_row(p.amap, mA + 64) * p.lda + kc * 8) * 2) : OOB;
+    } else {               // [64 k][128 cols] image: instruction (wave, j) covers k rows 8*wave + 4*j + lane/16
+      const int f8 = (lane >> 4) | ((wave & 1) << 2);
+      const int c = ((((lane & 15) >> 1) ^ f8) << 4) + (lane & 1) * 8;     // unit column of this lane's 8 elements
+      const int mA = m0 + (c >> 6) * 128 + (c & 63);
+      const uint32_t kr = kmapped ? 0u : (uint32_t)((wave * 8 + j * 4 + (lane >> 4)) * p.lda * 2);
+      vo[0][j] = mA < p.M ? kr + (uint32_t)(mA * 2) : OOB;
+      vo[3][j] = mA + 64 < p.M ? kr + (uint32_t)((mA + 64) * 2) : OOB;
+    }
+    if constexpr (!TB) {
+      const int ur = wave * 16 + j * 8 + (lane >> 3);
+      const int kc = (lane & 7) ^ (j * 4 + (lane >> 4));
+      const int nB = n0 + (ur >> 5) * 64 + (ur & 31);
+      vo[1][j] = nB < p.N ? (uint32_t)(((long long)nB * p.ldb + kc * 8) * 2) : OOB;
+      vo[2][j] = nB + 32 < p.N ? (uint32_t)(((long long)(nB + 32) * p.ldb + kc * 8) * 2) : OOB;
+    } else {
+      const int f8 = (lane >> 4) | ((wave & 1) << 2);
+      const int c = ((((lane & 15) >> 1) ^ f8) << 4) + (lane & 1) * 8;
+      const int nB = n0 + (c >> 5) * 64 + (c & 31);
+      const uint32_t kr = kmapped ? 0u : (uint32_t)((wave * 8 + j * 4 + (lane >> 4)) * p.ldb * 2);
+      vo[1][j] = nB < p.N ? kr + (uint32_t)(nB * 2) : OOB;
+      vo[2][j] = nB + 32 < p.N ? kr + (uint32_t)((nB + 32) * 2) : OOB;
+    }
+  }
+  // mapped reduction rows (temporal-branch wgrad): physical row of this lane's k row of the K-tile being issued
+  uint32_t prow[2] = {0u, 0u};
+  auto map_ktile = [&](int kt) {
+    if constexpr (kmapped) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) prow[j] = (uint32_t)map_row(p.kmap, kbeg + kt * TK + wave * 8 + j * 4 + (lane >> 4));
+    }
+  };
+
+  // issue the two DMA instructions of unit X (0..3) of K-tile kt into ring slot `slot`
+  auto issue_unit = [&](auto X, int kt, int slot) {
+    constexpr int x = decltype(X)::value;
+    constexpr bool isA = (x == 0 || x == 3);
+    constexpr bool T = isA ? TA : TB;
+    const bool live = kt < nk;                                     // wave-uniform
+    const uint32_t dead = live ? 0u : OOB;                         // units past the end: every lane out of range -> zero fill, no traffic
+    const i32x4 r = isA ? ra : rb;
+    const long long ld = isA ? p.lda : p.ldb;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint32_t dst = smem_base + (uint32_t)(slot * UNIT + (wave * 2 + j) * 1024);
+      if constexpr (!T) {
+        dma16(r, dst, vo[x][j] | dead, live ? (uint32_t)((kbeg + kt * TK) * 2) : 0u);
+      } else if constexpr (!kmapped) {
+        dma16(r, dst, vo[x][j] | dead, live ? (uint32_t)((long long)(kbeg + kt * TK) * ld * 2) : 0u);
+      } else {
+        dma16(r, dst, (vo[x][j] == OOB ? OOB : vo[x][j] + (uint32_t)(prow[j] * ld * 2)) | dead, 0u);
+      }
+    }
+  };
+
+  // ---- per-lane LDS read offsets
+  // k-contiguous image: fragment (blk, kk) of a wave = base + blk * 2048 (16 rows) with the k-half folded into the base
+  // (one base VGPR per ring buffer: the DS immediate offset is 16 bits, and the second buffer starts at 64 KiB)
+  const int sw = (lane >> 1) & 7;
+  int a_off[2][2], b_off[2][2];       // !T: [buf][kk]
+  int a_tr[2][4], b_tr[2][2];         // T: [buf][blk] (kk adds 8192, the +4 k rows add 1024)
+#pragma unroll
+  for (int bf = 0; bf < 2; ++bf) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      a_off[bf][kk] = bf * 4 * UNIT + (wr * 64 + l15) * 128 + (((kk * 4 + lg) ^ sw) << 4);
+      b_off[bf][kk] = bf * 4 * UNIT + (wc * 32 + l15) * 128 + (((kk * 4 + lg) ^ sw) << 4);
+      asm volatile("" : "+v"(a_off[bf][kk]), "+v"(b_off[bf][kk]));
+    }
+    const int f8 = (l15 >> 2) | ((lg & 1) << 2);
+    const int krow = lg * 8 + (l15 >> 2);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      a_tr[bf][mb] = bf * 4 * UNIT + krow * 256 + ((((wr * 4 + mb) ^ f8) & 7) << 5) + (lane & 3) * 8;
+      asm volatile("" : "+v"(a_tr[bf][mb]));
+    }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      b_tr[bf][nb] = bf * 4 * UNIT + krow * 256 + ((((wc * 2 + nb) ^ f8) & 7) << 5) + (lane & 3) * 8;
+      asm volatile("" : "+v"(b_tr[bf][nb]));
+    }
+  }
+
+  bf16x8 fa[4][2], fb[2][2][2];     // A fragments of the current 64-row half; B fragments of both 32-column halves
+  auto read_a = [&](auto BUF, auto X) {     // unit X (0 or 3) of ring buffer BUF
+    constexpr int bf = decltype(BUF)::value, x = decltype(X)::value;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        if constexpr (!TA) fa[mb][kk] = *(const bf16x8*)(smem + a_off[bf][kk] + x * UNIT + mb * 2048);
+        else fa[mb][kk] = lds_read_tr8(smem + a_tr[bf][mb] + x * UNIT + kk * 8192);
+      }
+  };
+  auto read_b = [&](auto BUF, auto NH) {    // unit 1 + NH of ring buffer BUF
+    constexpr int bf = decltype(BUF)::value, nh = decltype(NH)::value;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        if constexpr (!TB) fb[nh][nb][kk] = *(const bf16x8*)(smem + b_off[bf][kk] + (1 + nh) * UNIT + nb * 2048);
+        else fb[nh][nb][kk] = lds_read_tr8(smem + b_tr[bf][nb] + (1 + nh) * UNIT + kk * 8192);
+      }
+  };
+
+  f32x4 acc[2][2][4][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fused bias gradient (wgrad, n-tile 0 only): wave column wc owns A row block mb == wc of both halves
+  const bool do_colsum = TA && p.colsum_part != nullptr && n0 == 0;
+  f32x4 cs_acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+
+  auto mma = [&](auto MH, auto NH) {
+    constexpr int mh = decltype(MH)::value, nh = decltype(NH)::value;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+          acc[mh][nh][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nh][nb][kk], fa[mb][kk], acc[mh][nh][mb][nb], 0, 0, 0);
+  };
+  auto colsum_mma = [&](auto MH) {
+    constexpr int mh = decltype(MH)::value;
+    if constexpr (TA) {
+      if (do_colsum) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+          if (mb == wc) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) cs_acc[mh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[mb][kk], cs_acc[mh], 0, 0, 0);
+          }
+      }
+    }
+  };
+
+  // one phase J (0..3) of K-tile t living in ring buffer BUF (0/1)
+  auto phase = [&](auto J, auto BUF, int t) {
+    constexpr int j = decltype(J)::value, buf = decltype(BUF)::value;
+    // ---- load segment
+    if constexpr (j == 0) {
+      read_b(BUF, IC<0>{});
+      SCHED_FENCE();
+      read_a(BUF, IC<0>{});
+    } else if constexpr (j == 1) {
+      read_b(BUF, IC<1>{});
+    } else if constexpr (j == 2) {
+      read_a(BUF, IC<3>{});
+    }
+    SCHED_FENCE();
+    // unit (4t + j + 6): K-tile t+1 for j < 2 (other buffer), t+2 for j >= 2 (this buffer); unit-in-buffer (j + 2) & 3
+    if constexpr (j == 2) map_ktile(t + 2);
+    issue_unit(IC<((j + 2) & 3)>{}, t + (j < 2 ? 1 : 2), (j < 2 ? (buf ^ 1) : buf) * 4 + ((j + 2) & 3));
+    __builtin_amdgcn_s_waitcnt(0x0F76);   // vmcnt(6): everything but the three newest units of this wave has landed
+    SCHED_FENCE();
+    __builtin_amdgcn_s_barrier();
+    SCHED_FENCE();
+    // ---- MFMA segment: quadrant order (0,0) (0,1) (1,1) (1,0)
+    __builtin_amdgcn_s_setprio(1);
+    if constexpr (j == 0) { mma(IC<0>{}, IC<0>{}); colsum_mma(IC<0>{}); }
+    else if constexpr (j == 1) mma(IC<0>{}, IC<1>{});
+    else if constexpr (j == 2) { mma(IC<1>{}, IC<1>{}); colsum_mma(IC<1>{}); }
+    else mma(IC<1>{}, IC<0>{});
+    __builtin_amdgcn_s_setprio(0);
+    SCHED_FENCE();
+    __builtin_amdgcn_s_barrier();
+    SCHED_FENCE();
+  };
+  auto ktile = [&](auto BUF, int t) {
+    phase(IC<0>{}, BUF, t);
+    phase(IC<1>{}, BUF, t);
+    phase(IC<2>{}, BUF, t);
+    phase(IC<3>{}, BUF, t);
+  };
+
+  // ---- prologue: units 0..5 (K-tile 0 and U0, U1 of K-tile 1)
+  map_ktile(0);
+  issue_unit(IC<0>{}, 0, 0);
+  issue_unit(IC<1>{}, 0, 1);
+  issue_unit(IC<2>{}, 0, 2);
+  issue_unit(IC<3>{}, 0, 3);
+  map_ktile(1);
+  issue_unit(IC<0>{}, 1, 4);
+  issue_unit(IC<1>{}, 1, 5);
+  __builtin_amdgcn_s_waitcnt(0x0F74);     // vmcnt(4): K-tile 0 has landed (this wave's part)
+  SCHED_FENCE();
+  __builtin_amdgcn_s_barrier();           // ... and everybody else's
+  SCHED_FENCE();
+  if (wr == 1) __builtin_amdgcn_s_barrier();   // stagger: wave row 1 runs one barrier behind wave row 0
+  SCHED_FENCE();
+
+  int t = 0;
+  for (; t + 2 <= nk; t += 2) {
+    ktile(IC<0>{}, t);
+    ktile(IC<1>{}, t + 1);
+  }
+  if (t < nk) ktile(IC<0>{}, t);
+  SCHED_FENCE();
+  __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): the zero-fill DMAs of the dead units are done before LDS is reused
+  if (wr == 0) __builtin_amdgcn_s_barrier();   // un-stagger
+  SCHED_FENCE();
+  __syncthreads();
+
+  // ------------------------------------------------------------------------------------------------ epilogue
+  const float alpha = p.alpha * (p.alpha_dev ? *p.alpha_dev : 1.0f);
+  if (alpha != 1.0f) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int d = 0; d < 2; ++d) acc[a][b][c][d] *= alpha;
+  }
+
+  if constexpr (TA) {
+    if (do_colsum) {
+      // D = ones x Afrag: every D row i holds the same column sums; lane (l15, lg) reg r = D[4*lg + r][m = l15]
+      if (lg == 0) {
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh) {
+          const int m = m0 + wr * 128 + mh * 64 + wc * 16 + l15;
+          if (m < p.M) p.colsum_part[(long long)split * p.M + m] = cs_acc[mh][0];
+        }
+      }
+    }
+  }
+
+  if (p.out_f32) {
+    float* cs = (float*)smem;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int wrq = q >> 1;
+      if (wr == wrq) {
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+          for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+              *(f32x4*)(cs + (mb * 16 + l15) * FPITCH + wc * 64 + nh * 32 + nb * 16 + lg * 4) = (q & 1) ? acc[1][nh][mb][nb] : acc[0][nh][mb][nb];
+            }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int c = tid + 512 * it;
+        const int row = c >> 6, col = (c & 63) * 4;
+        const int m = m0 + wrq * 128 + (q & 1) * 64 + row, n = n0 + col;
+        if (m < p.M && n < p.N) {
+          f32x4 v = *(const f32x4*)(cs + row * FPITCH + col);
+          float* cp = (float*)p.C + (long long)split * p.M * p.N + map_row(p.cmap, m) * p.ldc + n;
+          if (p.accumulate) v += *(const f32x4*)cp;
+          *(f32x4*)cp = v;
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
+
+  bf16* cb = (bf16*)smem;
+#pragma unroll
+  for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const int col = wc * 64 + nh * 32 + nb * 16 + lg * 4;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && n0 + col < p.N) bv = cvt4(*(const bf16x4*)(p.bias + n0 + col));
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+          const int row = wr * 128 + mh * 64 + mb * 16 + l15;
+          *(bf16x4*)(cb + row * CPITCH + col) = cvt4(acc[mh][nh][mb][nb] + bv);
+        }
+      }
+  __syncthreads();
+  const bool plain = !p.act && !p.act_bwd && !p.residual && !p.drop_thr && !p.accumulate;
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int c = tid + 512 * it;
+    const int row = c >> 5, col = (c & 31) * 8;
+    const int m = m0 + row, n = n0 + col;
+    if (m < p.M && n < p.N) {
+      const bf16x8 zb = *(const bf16x8*)(cb + row * CPITCH + col);
+      const long long crow = map_row(p.cmap, m);
+      bf16* cp = (bf16*)p.C + crow * p.ldc + n;
+      if (plain) {
+        *(bf16x8*)cp = zb;
+        continue;
+      }
+      f32x8 v = cvt8(zb);
+      if (p.act) {
+        if (p.preact) *(bf16x8*)(p.preact + crow * p.ldc + n) = zb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = p.act == 1 ? gelu_erf_f(v[e]) : p.act == 2 ? gelu_tanh_f(v[e]) : fmaxf(v[e], 0.f);
+      }
+      if (p.act_bwd) {
+        const f32x8 z = cvt8(*(const bf16x8*)(p.actz + (long long)m * p.ldz + n));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= p.act_bwd == 1 ? gelu_erf_grad_f(z[e]) : p.act_bwd == 2 ? gelu_tanh_grad_f(z[e]) : (z[e] > 0.f ? 1.f : 0.f);
+      }
+      if (p.drop_thr) {
+        const uint64_t base = p.drop_offset + (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = mpv_keep(p.seed, base + e, p.drop_thr) ? v[e] * p.drop_scale : 0.f;
+      }
+      if (p.residual) v += cvt8(*(const bf16x8*)(p.residual + crow * p.ldr + n));
+      if (p.accumulate) v += cvt8(*(const bf16x8*)cp);
+      *(bf16x8*)cp = cvt8(v);
+    }
+  }
+}
+
+}  // namespace
+
+// Takes the problem if the 256x256 kernel is expected to beat the 128x128 one on it.  g is fully populated by
+// mpv_gemm_bf16 (epilogue, maps, byte extents, split-K fields for wgrad: splits / k_per_split / C = fp32 workspace).
+bool mpv_gemm256_try_launch(const GemmArgs& g0, int transA, int transB, hipStream_t stream) {
+  GemmArgs g = g0;
+  if (g.K % TK != 0 || g.k_per_split % TK != 0) return false;
+  if (g.tail_g > 1) return false;
+  g.tiles_m = (g.M + TM - 1) / TM;
+  g.tiles_n = (g.N + TN - 1) / TN;
+  g.nwg = g.tiles_m * g.tiles_n;
+  g.gm = g.gm > 0 ? g.gm : 4;
+  const dim3 grid((unsigned)(g.nwg * g.splits)), block(512);
+  const bool km = (transA || transB) && g.kmap.group != 0;
+  if (!transA && !transB)
+    hipLaunchKernelGGL((gemm256_kernel<false, false, false>), grid, block, 0, stream, g);
+  else if (!transA && transB && !km)
+    hipLaunchKernelGGL((gemm256_kernel<false, true, false>), grid, block, 0, stream, g);
+  else if (!transA && transB)
+    hipLaunchKernelGGL((gemm256_kernel<false, true, true>), grid, block, 0, stream, g);
+  else if (!km)
+    hipLaunchKernelGGL((gemm256_kernel<true, true, false>), grid, block, 0, stream, g);
+  else
+    hipLaunchKernelGGL((gemm256_kernel<true, true, true>), grid, block, 0, stream, g);
+  return true;
+}

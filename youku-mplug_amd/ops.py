@@ -48,7 +48,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: Optio
          ldc: Optional[int] = None, bias=None, act: int = 0, preact_out=None, residual=None, ldr: int = 0,
          act_bwd_z=None, act_bwd: int = 0, ldz: int = 0, dropout_p: float = 0.0, seed: int = 0, offset: int = 0,
          alpha_dev=None, alpha: float = 0.0, amap: RowMap = IDENT, cmap: RowMap = IDENT, kmap: RowMap = IDENT,
-         out_rows: Optional[int] = None, accumulate: bool = False, out_f32: bool = False, colsum_out=None) -> torch.Tensor:
+         out_rows: Optional[int] = None, accumulate: bool = False, out_f32: bool = False, colsum_out=None,
+         tile_hint: int = 0) -> torch.Tensor:
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)).  See include/mpv.h:mpv_gemm_bf16."""
     _need_cuda(a, b)
     lda = lda if lda is not None else (M if trans_a else K)
@@ -77,6 +78,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: Optio
     ep.out_f32 = int(out_f32)
     ep.accumulate = int(accumulate)
     ep.colsum_out = _p(colsum_out)
+    ep.tile_hint = tile_hint
     ws, wsn = None, 0
     if not out_f32:
         wsn = _lib.lib().mpv_gemm_workspace_size(M, N, K, int(trans_a), int(trans_b))
