@@ -80,6 +80,30 @@ def test_gemm256_bitwise_deterministic(dev):
             assert torch.equal(out, ref), (M, N, K, ta, tb)
 
 
+@pytest.mark.parametrize("M,N,K,ta,tb", [(8192, 2304, 768, 0, 0), (10240, 2048, 128, 0, 0), (9000, 2304, 256, 0, 1), (5120, 6144, 2048, 0, 0),
+                                          (2304, 768, 50432, 1, 1), (8200, 8200, 128, 0, 0)])
+def test_gemm256_persistent_multi_item(dev, M, N, K, ta, tb):
+    """More than 256 (tile, split) items: a workgroup walks several tiles and its DMA ring runs across the tile
+    boundaries (csrc/gemm256.hip).  Every element against fp32, then a 20-launch bitwise race screen."""
+    from youku_mplug_amd import ops
+    a = rn(K, M, dev=dev, seed=60) if ta else rn(M, K, dev=dev, seed=60)
+    b = rn(K, N, dev=dev, seed=61, scale=0.1) if tb else rn(N, K, dev=dev, seed=61, scale=0.1)
+    bias, res = rn(N, dev=dev, seed=62), rn(M, N, dev=dev, seed=63)
+    af = a.float().t() if ta else a.float()
+    bf = b.float() if tb else b.float().t()
+    if ta:
+        out = ops.gemm(a, b, M, N, K, trans_a=True, trans_b=True, tile_hint=256)
+        close(out, af @ bf, 1e-2, "persistent wgrad")
+        kw = dict(trans_a=True, trans_b=True)
+    else:
+        kw = dict(trans_b=bool(tb), bias=bias, residual=res)
+        out = ops.gemm(a, b, M, N, K, tile_hint=256, **kw)
+        close(out, af @ bf + bias.float() + res.float(), 1e-2, "persistent + bias + residual")
+    first = out.clone()
+    for _ in range(20):
+        assert torch.equal(ops.gemm(a, b, M, N, K, tile_hint=256, **kw), first)
+
+
 def test_gemm256_large_vs_fp32(dev):
     """Full-size check against fp32 matmul on the device (config-B shapes, every output element)."""
     from youku_mplug_amd import ops

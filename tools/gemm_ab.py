@@ -56,6 +56,15 @@ def main():
                 e.record()
                 torch.cuda.synchronize()
                 best[k] = min(best[k], s.elapsed_time(e) / iters * 1e-3)
+        # never quote a time for a wrong result: both tile kernels against the vendor output, every element
+        ref = torch.matmul(am, bm).float()
+        scale = ref.abs().max().item()
+        errs = []
+        for k in ("128", "256"):
+            fns[k]()
+            errs.append(((out.float() - ref).abs().max().item()) / scale)
+        del ref
+        assert max(errs) < 1e-2, f"{name}: wrong result, rel err 128/256 = {errs}"
         fl = 2.0 * M * N * K
         print(f"{name:16s} {M:6d} {N:6d} {K:6d} | {fl/best['128']/1e12:8.1f} {fl/best['256']/1e12:8.1f} {fl/best['lib']/1e12:8.1f}      | "
               f"{best['128']*1e6:8.1f} {best['256']*1e6:8.1f} {best['lib']*1e6:8.1f}", flush=True)

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmpv_hip.so")
+LIB_PATH = os.environ.get("MPV_LIB_PATH") or os.path.join(_HERE, "libmpv_hip.so")   # override: instrumented measurement builds only
 
 c_void_p, c_int, c_int64, c_float, c_uint64, c_size_t = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
 

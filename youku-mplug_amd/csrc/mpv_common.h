@@ -86,18 +86,40 @@ __host__ __device__ __forceinline__ bool mpv_keep(uint64_t seed, uint64_t idx, u
 }
 
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// Activation math for the GEMM epilogues.  A 256x256 output tile is 128 activations per thread with the matrix pipe idle,
+// so these are built from the hardware transcendentals (v_exp_f32, v_rcp_f32: ~1 ulp) instead of the libm routines
+// (measured: erff/tanhf epilogues cost 10-20 us per tile, more than the K = 768 main loop).  Errors are far below bf16
+// resolution: erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7), tanh(u) = 1 - 2 / (e^{2u} + 1).
+__device__ __forceinline__ float mpv_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+// returns erf(x / sqrt(2)) and hands back e = exp(-x^2 / 2) for the derivative
+__device__ __forceinline__ float mpv_erf_rsqrt2(float x, float& e) {
+  const float u = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
+  float q = fmaf(1.061405429f, t, -1.453152027f);
+  q = fmaf(q, t, 1.421413741f);
+  q = fmaf(q, t, -0.284496736f);
+  q = fmaf(q, t, 0.254829592f);
+  e = mpv_exp(-u * u);
+  return copysignf(fmaf(-q * t, e, 1.0f), x);
+}
+__device__ __forceinline__ float mpv_tanh(float u) {
+  return fmaf(-2.0f, __builtin_amdgcn_rcpf(mpv_exp(2.0f * u) + 1.0f), 1.0f);   // e^{2u} = inf -> 1, = 0 -> -1
+}
+__device__ __forceinline__ float gelu_erf_f(float x) {
+  float e;
+  return 0.5f * x * (1.0f + mpv_erf_rsqrt2(x, e));
+}
 __device__ __forceinline__ float gelu_erf_grad_f(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float e;
+  const float cdf = 0.5f * (1.0f + mpv_erf_rsqrt2(x, e));
+  return fmaf(x * 0.3989422804014327f, e, cdf);
 }
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-  return 0.5f * x * (1.0f + tanhf(0.79788456f * x * (1.0f + 0.044715f * x * x)));
+  return 0.5f * x * (1.0f + mpv_tanh(0.79788456f * x * fmaf(0.044715f * x, x, 1.0f)));
 }
 __device__ __forceinline__ float gelu_tanh_grad_f(float x) {
-  const float t = tanhf(0.79788456f * x * (1.0f + 0.044715f * x * x));
-  return 0.5f * x * ((1.0f - t * t) * (0.79788456f + 0.1070322243f * x * x)) + 0.5f * (1.0f + t);
+  const float t = mpv_tanh(0.79788456f * x * fmaf(0.044715f * x, x, 1.0f));
+  return 0.5f * x * ((1.0f - t * t) * fmaf(0.1070322243f * x, x, 0.79788456f)) + 0.5f * (1.0f + t);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
