@@ -63,6 +63,76 @@ __device__ __forceinline__ bf16x8 lds_read_tr8(const char* p) {
   return u.v;
 }
 
+
+enum EpKind { EP_PLAIN, EP_ERF_PRE, EP_TANH_PRE, EP_BWD_ERF, EP_BWD_TANH, EP_RES, EP_DROP_RES, EP_GENERIC };
+
+template <int ACT>
+__device__ __forceinline__ f32x8 apply_act(f32x8 v) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = ACT == MPV_ACT_GELU_ERF ? gelu_erf_f(v[e]) : ACT == MPV_ACT_GELU_TANH ? gelu_tanh_f(v[e]) : fmaxf(v[e], 0.f);
+  return v;
+}
+template <int ACT>
+__device__ __forceinline__ f32x8 apply_act_grad(f32x8 v, f32x8 z) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    v[e] *= ACT == MPV_ACT_GELU_ERF ? gelu_erf_grad_f(z[e]) : ACT == MPV_ACT_GELU_TANH ? gelu_tanh_grad_f(z[e]) : (z[e] > 0.f ? 1.f : 0.f);
+  return v;
+}
+
+// second half of the epilogue: the staged bf16 tile (acc * alpha + bias, pitch CPITCH) -> global, 8 columns per thread
+template <int KIND>
+__device__ __forceinline__ void finish_rows(const GemmArgs& p, const bf16* cb, int tid, int m0, int n0) {
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int c = tid + 512 * it;
+    const int row = c >> 5, col = (c & 31) * 8;
+    const int m = m0 + row, n = n0 + col;
+    if (m < p.M && n < p.N) {
+      const bf16x8 zb = *(const bf16x8*)(cb + row * CPITCH + col);
+      const long long crow = map_row(p.cmap, m);
+      bf16* cp = (bf16*)p.C + crow * p.ldc + n;
+      if constexpr (KIND == EP_PLAIN) {
+        *(bf16x8*)cp = zb;
+      } else if constexpr (KIND == EP_ERF_PRE || KIND == EP_TANH_PRE) {
+        *(bf16x8*)(p.preact + crow * p.ldc + n) = zb;
+        *(bf16x8*)cp = cvt8(apply_act<KIND == EP_ERF_PRE ? MPV_ACT_GELU_ERF : MPV_ACT_GELU_TANH>(cvt8(zb)));
+      } else if constexpr (KIND == EP_BWD_ERF || KIND == EP_BWD_TANH) {
+        const f32x8 z = cvt8(*(const bf16x8*)(p.actz + (long long)m * p.ldz + n));
+        *(bf16x8*)cp = cvt8(apply_act_grad<KIND == EP_BWD_ERF ? MPV_ACT_GELU_ERF : MPV_ACT_GELU_TANH>(cvt8(zb), z));
+      } else if constexpr (KIND == EP_RES) {
+        *(bf16x8*)cp = cvt8(cvt8(zb) + cvt8(*(const bf16x8*)(p.residual + crow * p.ldr + n)));
+      } else if constexpr (KIND == EP_DROP_RES) {
+        const f32x8 r = cvt8(*(const bf16x8*)(p.residual + crow * p.ldr + n));
+        f32x8 v = cvt8(zb);
+        const uint64_t base = p.drop_offset + (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = mpv_keep(p.seed, base + e, p.drop_thr) ? v[e] * p.drop_scale : 0.f;
+        *(bf16x8*)cp = cvt8(v + r);
+      } else {
+        f32x8 v = cvt8(zb);
+        if (p.act) {
+          if (p.preact) *(bf16x8*)(p.preact + crow * p.ldc + n) = zb;
+          v = p.act == MPV_ACT_GELU_ERF ? apply_act<MPV_ACT_GELU_ERF>(v) : p.act == MPV_ACT_GELU_TANH ? apply_act<MPV_ACT_GELU_TANH>(v) : apply_act<MPV_ACT_RELU>(v);
+        }
+        if (p.act_bwd) {
+          const f32x8 z = cvt8(*(const bf16x8*)(p.actz + (long long)m * p.ldz + n));
+          v = p.act_bwd == MPV_ACT_GELU_ERF ? apply_act_grad<MPV_ACT_GELU_ERF>(v, z)
+              : p.act_bwd == MPV_ACT_GELU_TANH ? apply_act_grad<MPV_ACT_GELU_TANH>(v, z) : apply_act_grad<MPV_ACT_RELU>(v, z);
+        }
+        if (p.drop_thr) {
+          const uint64_t base = p.drop_offset + (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = mpv_keep(p.seed, base + e, p.drop_thr) ? v[e] * p.drop_scale : 0.f;
+        }
+        if (p.residual) v += cvt8(*(const bf16x8*)(p.residual + crow * p.ldr + n));
+        if (p.accumulate) v += cvt8(*(const bf16x8*)cp);
+        *(bf16x8*)cp = cvt8(v);
+      }
+    }
+  }
+}
+
 // LDS-DMA of 16 bytes per lane (1 KiB per wave) to LDS byte address `lds_addr` (wave-uniform) + 16 * lane, from
 // rsrc base + soff + voff.  Inline asm on purpose: hipcc orders every LDS read it cannot disambiguate behind a
 // pending buffer_load..lds it knows about with s_waitcnt vmcnt(0) (seen in the .s for ds_read_b64_tr_b16), which would
@@ -410,41 +480,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
         }
       }
   __syncthreads();
-  const bool plain = !p.act && !p.act_bwd && !p.residual && !p.drop_thr && !p.accumulate;
-#pragma unroll 4
-  for (int it = 0; it < 16; ++it) {
-    const int c = tid + 512 * it;
-    const int row = c >> 5, col = (c & 31) * 8;
-    const int m = m0 + row, n = n0 + col;
-    if (m < p.M && n < p.N) {
-      const bf16x8 zb = *(const bf16x8*)(cb + row * CPITCH + col);
-      const long long crow = map_row(p.cmap, m);
-      bf16* cp = (bf16*)p.C + crow * p.ldc + n;
-      if (plain) {
-        *(bf16x8*)cp = zb;
-        continue;
-      }
-      f32x8 v = cvt8(zb);
-      if (p.act) {
-        if (p.preact) *(bf16x8*)(p.preact + crow * p.ldc + n) = zb;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = p.act == 1 ? gelu_erf_f(v[e]) : p.act == 2 ? gelu_tanh_f(v[e]) : fmaxf(v[e], 0.f);
-      }
-      if (p.act_bwd) {
-        const f32x8 z = cvt8(*(const bf16x8*)(p.actz + (long long)m * p.ldz + n));
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= p.act_bwd == 1 ? gelu_erf_grad_f(z[e]) : p.act_bwd == 2 ? gelu_tanh_grad_f(z[e]) : (z[e] > 0.f ? 1.f : 0.f);
-      }
-      if (p.drop_thr) {
-        const uint64_t base = p.drop_offset + (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = mpv_keep(p.seed, base + e, p.drop_thr) ? v[e] * p.drop_scale : 0.f;
-      }
-      if (p.residual) v += cvt8(*(const bf16x8*)(p.residual + crow * p.ldr + n));
-      if (p.accumulate) v += cvt8(*(const bf16x8*)cp);
-      *(bf16x8*)cp = cvt8(v);
-    }
-  }
+  // Row-contiguous finish, specialised at compile time for the epilogue combinations the step uses (a tile is 128
+  // elements per thread with the matrix pipe idle: per-element runtime switches on act / act_bwd cost more than the
+  // activation itself); anything else takes the generic instance with the switches hoisted to one per 8-element chunk.
+  const int cfg = (p.act ? 1 : 0) | (p.act_bwd ? 2 : 0) | (p.drop_thr ? 4 : 0) | (p.residual ? 8 : 0) | (p.accumulate ? 16 : 0) |
+                  (p.preact ? 32 : 0);
+  if (cfg == 0) finish_rows<EP_PLAIN>(p, cb, tid, m0, n0);
+  else if (cfg == (1 | 32) && p.act == MPV_ACT_GELU_ERF) finish_rows<EP_ERF_PRE>(p, cb, tid, m0, n0);
+  else if (cfg == (1 | 32) && p.act == MPV_ACT_GELU_TANH) finish_rows<EP_TANH_PRE>(p, cb, tid, m0, n0);
+  else if (cfg == 2 && p.act_bwd == MPV_ACT_GELU_ERF) finish_rows<EP_BWD_ERF>(p, cb, tid, m0, n0);
+  else if (cfg == 2 && p.act_bwd == MPV_ACT_GELU_TANH) finish_rows<EP_BWD_TANH>(p, cb, tid, m0, n0);
+  else if (cfg == 8) finish_rows<EP_RES>(p, cb, tid, m0, n0);
+  else if (cfg == (4 | 8)) finish_rows<EP_DROP_RES>(p, cb, tid, m0, n0);
+  else finish_rows<EP_GENERIC>(p, cb, tid, m0, n0);
 }
 
 }  // namespace
