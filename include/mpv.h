@@ -225,6 +225,7 @@ typedef struct mpv_gpt_weights {
   float ln_eps;
   const mpv_gpt_layer_weights* layer;
   const void *wte, *wpe, *lnf_w, *lnf_b;
+  int max_positions; /* rows of wpe (max_position_embeddings); 0 = unchecked */
 } mpv_gpt_weights;
 size_t mpv_gpt_decode_workspace_size(const mpv_gpt_weights* w, int batch, int n_new);
 int mpv_gpt_decode_step(const mpv_gpt_weights* w, void* const* kv_cache, int batch, int max_len, int pos0, const void* query,

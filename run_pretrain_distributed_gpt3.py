@@ -1,0 +1,232 @@
+"""mPLUG-Video pre-training entry point on the MI355X-native path -- drop-in for the reference's
+run_pretrain_distributed_gpt3.py (same command line, same YAML / JSON configs, same per-step protocol), with the model
+and the engine coming from youku_mplug_amd instead of models.distributed_gpt3 + DeepSpeed.
+
+What is kept from the reference loop (run_pretrain_distributed_gpt3.py:56-191, 199-350), because downstream tooling
+depends on it: the step-level lr / weight-decay tables written into optimizer.param_groups before every update
+(lr * lr_scale per group), bf16 video cast, the cross-rank loss all-gather with the NaN / Inf guard, `loss /=
+update_freq` before engine.backward, engine.step, grad-norm read-out through optimizer._global_grad_norm, one
+`log.txt` JSON line and one DeepSpeed-layout checkpoint per epoch.  Launch: one process per GPU,
+`python -m torch.distributed.run --nproc-per-node N run_pretrain_distributed_gpt3.py --config ... --bf16 --enable_deepspeed`
+(`--enable_deepspeed` is accepted and means "use the native engine": there is no other one here).
+
+Data: with `--synthetic_steps N` the loop runs on synthetic clips / token ids (bench, smoke tests, no datasets on the
+box); otherwise it imports the reference's own `dataset` package and tokenizer from PYTHONPATH (data loading, decord and
+the jieba tokenizer stay where they are: SURVEY.md section 2.1)."""
+import argparse
+import datetime
+import json
+import math
+import os
+import random
+import time
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import yaml
+
+import youku_mplug_amd  # noqa: F401
+from youku_mplug_amd import engine as mpv_engine
+from youku_mplug_amd.pretrain import DistributedGPT3_Pretrain
+
+
+def init_distributed(args):
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ:
+        args.rank, args.world_size, args.gpu = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", 0))
+    else:
+        args.rank, args.world_size, args.gpu = 0, 1, 0
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+    args.distributed = True
+    if torch.cuda.is_available():
+        torch.cuda.set_device(args.gpu)
+    if not dist.is_initialized():
+        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo", init_method=args.dist_url,
+                                world_size=args.world_size, rank=args.rank)
+    dist.barrier()
+
+
+class SyntheticClips:
+    """`steps` batches of random clips + token ids with the shapes the real loader yields (video [B,3,T,H,W] float,
+    text = tokenizer output with input_ids / attention_mask [B, max_length])."""
+
+    def __init__(self, steps, batch_size, frames, res, max_length, vocab, seed):
+        self.steps, self.shape, self.L, self.vocab, self.seed = steps, (batch_size, 3, frames, res, res), max_length, vocab, seed
+        self.sampler = types.SimpleNamespace(set_epoch=lambda e: None)
+
+    def __len__(self):
+        return self.steps
+
+    def __iter__(self):
+        g = torch.Generator().manual_seed(self.seed)
+        for _ in range(self.steps):
+            video = torch.randn(self.shape, generator=g)
+            ids = torch.randint(5, self.vocab, (self.shape[0], self.L), generator=g)
+            mask = torch.ones_like(ids)
+            mask[:, self.L - self.L // 4:] = 0            # ragged titles: the last quarter is padding
+            yield video, types.SimpleNamespace(input_ids=ids, attention_mask=mask)
+
+
+def train_one_epoch(model, tokenizer, data_loader, optimizer, device, epoch, num_training_steps_per_epoch, update_freq=1,
+                    start_steps=0, lr_schedule_values=None, wd_schedule_values=None, args=None, log=print):
+    model.train()
+    model.zero_grad()
+    model.micro_steps = 0
+    sums, count = {}, 0
+    world = dist.get_world_size()
+    for data_iter_step, (video, text) in enumerate(data_loader):
+        t0 = time.time()
+        step = data_iter_step // update_freq
+        if step >= num_training_steps_per_epoch:
+            continue
+        it = start_steps + step
+        if lr_schedule_values is not None or wd_schedule_values is not None:
+            for group in optimizer.param_groups:                       # read by the optimizer kernel at the next step()
+                if lr_schedule_values is not None:
+                    group["lr"] = lr_schedule_values[it] * group["lr_scale"]
+                if wd_schedule_values is not None and group["weight_decay"] > 0:
+                    group["weight_decay"] = wd_schedule_values[it]
+        video = video.to(device, non_blocking=True).bfloat16()
+        if tokenizer is not None:
+            text = tokenizer(text, padding="max_length", truncation=True, max_length=args.max_length, return_tensors="pt",
+                             add_special_tokens=True)
+        text = types.SimpleNamespace(input_ids=text.input_ids.to(device), attention_mask=text.attention_mask.to(device))
+        loss_caption, loss_ita = model(video, text)
+        loss = loss_caption + loss_ita
+        loss_value = loss.item()
+        gathered = [torch.zeros_like(loss) for _ in range(world)]
+        dist.all_gather(gathered, loss.detach())
+        all_losses = torch.stack([g.float() for g in gathered])
+        if torch.isnan(all_losses).any() or torch.isinf(all_losses).any():   # some rank diverged: nobody steps on it
+            log(f" ========== non-finite loss on some rank at iteration {it}: {all_losses.tolist()} ========== ")
+            if args is not None and args.output_dir and getattr(args, "auto_resume_iter", False) and os.path.isfile(os.path.join(args.output_dir, "latest")):
+                model.load_checkpoint(args.output_dir)
+                continue
+            raise SystemExit(1)
+        loss = loss / update_freq
+        model.backward(loss)
+        model.step()
+        grad_norm = optimizer._global_grad_norm
+        if device.type == "cuda":
+            torch.cuda.synchronize()
+        lrs = [g["lr"] for g in optimizer.param_groups]
+        stats = dict(loss=loss_value, loss_caption=loss_caption.item(), loss_ita=float(loss_ita), all_loss_mean=all_losses.mean().item(),
+                     lr=max(lrs), min_lr=min(lrs), grad_norm=grad_norm, loss_scale=optimizer.cur_scale, time=time.time() - t0,
+                     weight_decay=max([g["weight_decay"] for g in optimizer.param_groups] + [0.0]))
+        for k, v in stats.items():
+            sums[k] = sums.get(k, 0.0) + float(v)
+        count += 1
+        if data_iter_step % 10 == 0:
+            log(f"Epoch: [{epoch}] [{data_iter_step}/{len(data_loader)}] " + "  ".join(f"{k}: {v:.6g}" for k, v in stats.items()))
+    return {k: v / max(count, 1) for k, v in sums.items()}
+
+
+def main(args, config):
+    init_distributed(args)
+    device = torch.device(args.device if torch.cuda.is_available() else "cpu")
+    seed = args.seed + dist.get_rank()                                   # every rank its own stream; initialize() broadcasts rank 0's weights
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+    visual_cfg = json.load(open(config["visual_cfg"], "r"))
+    tokenizer = None
+    if args.synthetic_steps > 0:
+        text_cfg = json.load(open(config["text_cfg"], "r")) if os.path.isfile(str(config.get("text_cfg", ""))) else {}
+        data_loader = SyntheticClips(args.synthetic_steps * args.update_freq, config["batch_size"], visual_cfg["num_frames"], visual_cfg["img_size"],
+                                     config["max_length"], int(text_cfg.get("vocab_size", 51200)), seed)
+    else:
+        try:   # the reference's data pipeline and tokenizer, untouched (on PYTHONPATH)
+            from dataset import create_dataset, create_loader, create_sampler
+            from models.modeling_distributed_gpt3 import DistributedGPT3Tokenizer
+        except ImportError as e:
+            raise SystemExit(f"real-data runs need the reference's `dataset` package and tokenizer on PYTHONPATH ({e}); "
+                             "use --synthetic_steps N for synthetic clips")
+        datasets = [create_dataset("pretrain_video", config)]
+        samplers = create_sampler(datasets, [True], dist.get_world_size(), dist.get_rank())
+        data_loader = create_loader(datasets, samplers, batch_size=[config["batch_size"]], num_workers=[config["num_workers"]],
+                                    is_trains=[True], collate_fns=[None])[0]
+        tokenizer = DistributedGPT3Tokenizer(model_dir=config["text_decoder"])
+    steps_per_epoch = len(data_loader) // args.update_freq
+    model = DistributedGPT3_Pretrain(config=config, tokenizer=tokenizer, device=device)
+    n_parameters = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    print("number of params (B):", n_parameters / 1e9)
+    groups = mpv_engine.get_parameter_groups(model, config["optimizer"]["weight_decay"], model.no_weight_decay(),
+                                             visual_backbone_scale=config.get("clip_model", False))
+    model, optimizer, _, _ = mpv_engine.initialize(args=args, model=model, model_parameters=groups)
+    lr_values = mpv_engine.cosine_scheduler(args.lr, args.min_lr, args.epochs, steps_per_epoch, warmup_epochs=getattr(args, "warmup_epochs", 0),
+                                            warmup_steps=getattr(args, "warmup_steps", -1), sched_type=getattr(args, "lr_sched_type", "cos"))
+    wd_values = mpv_engine.cosine_scheduler(args.weight_decay, args.weight_decay, args.epochs, steps_per_epoch)
+    start_epoch = 0
+    if args.auto_resume and args.output_dir and os.path.isfile(os.path.join(args.output_dir, "latest")):
+        _, client = model.load_checkpoint(args.output_dir)
+        start_epoch = int(client.get("epoch", -1)) + 1
+        print(f"Auto resume from epoch {start_epoch}")
+    t_start = time.time()
+    stats = {}
+    for epoch in range(start_epoch, args.epochs):
+        data_loader.sampler.set_epoch(epoch)
+        stats = train_one_epoch(model, tokenizer, data_loader, optimizer, device, epoch, steps_per_epoch, update_freq=args.update_freq,
+                                start_steps=epoch * steps_per_epoch, lr_schedule_values=lr_values, wd_schedule_values=wd_values, args=args)
+        if args.output_dir and ((epoch + 1) % args.save_ckpt_freq == 0 or epoch + 1 == args.epochs):
+            model.save_checkpoint(save_dir=args.output_dir, tag=f"checkpoint-{epoch}", client_state={"epoch": epoch})
+        if args.output_dir and dist.get_rank() == 0:
+            with open(os.path.join(args.output_dir, "log.txt"), "a", encoding="utf-8") as f:
+                f.write(json.dumps({**{f"train_{k}": v for k, v in stats.items()}, "epoch": epoch, "n_parameters": n_parameters}) + "\n")
+    print("Training time {}".format(str(datetime.timedelta(seconds=int(time.time() - t_start)))))
+    return stats
+
+
+class _ConfigLoader(yaml.SafeLoader):
+    """PyYAML follows YAML 1.1, where `1e-4` (no dot) is a string; the shipped configs write `lr: 1e-4` and are read
+    with ruamel in the reference (run_pretrain_distributed_gpt3.py:402), which yields a float.  Same result here."""
+
+
+_ConfigLoader.add_implicit_resolver(
+    "tag:yaml.org,2002:float",
+    __import__("re").compile(r"^[-+]?(?:[0-9][0-9_]*)(?:\.[0-9_]*)?(?:[eE][-+]?[0-9]+)$|^[-+]?\.[0-9_]+(?:[eE][-+]?[0-9]+)?$"),
+    list("-+0123456789."))
+
+
+def get_args(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("--config", default="./configs/Pretrain.yaml")
+    p.add_argument("--output_dir", default="Pretrain/")
+    p.add_argument("--log_dir", default=None)
+    p.add_argument("--device", default="cuda")
+    p.add_argument("--seed", default=42, type=int)
+    p.add_argument("--world_size", default=1, type=int)
+    p.add_argument("--local_rank", default=-1, type=int)
+    p.add_argument("--dist_url", default="env://")
+    p.add_argument("--distributed", default=True, type=bool)
+    p.add_argument("--resume", default="")
+    p.add_argument("--auto_resume", action="store_true")
+    p.add_argument("--auto_resume_iter", action="store_true")
+    p.add_argument("--no_auto_resume", action="store_false", dest="auto_resume")
+    p.set_defaults(auto_resume=True, auto_resume_iter=True)
+    p.add_argument("--update_freq", default=1, type=int)
+    p.add_argument("--bf16", action="store_true")
+    p.add_argument("--save_ckpt_freq", default=1, type=int)
+    p.add_argument("--enable_deepspeed", action="store_true", default=False)
+    p.add_argument("--zero_stage", default=1, type=int)
+    p.add_argument("--synthetic_steps", default=0, type=int, help="run on N synthetic batches per epoch instead of the dataset")
+    args, _ = p.parse_known_args(argv)
+    config = yaml.load(open(args.config, "r"), Loader=_ConfigLoader)
+    Path(args.output_dir).mkdir(parents=True, exist_ok=True)
+    for section in ("optimizer", "schedular"):                         # YAML values fill whatever the command line left unset
+        for name, val in (config.get(section) or {}).items():
+            if getattr(args, name, None) is None:
+                setattr(args, name, val)
+    args.max_length, args.batch_size, args.num_workers = config["max_length"], config["batch_size"], config.get("num_workers", 0)
+    vis = json.load(open(config["visual_cfg"], "r"))
+    config["image_res"], config["num_frames"], config["clip_model"] = vis["img_size"], vis["num_frames"], vis.get("clip_model", False)
+    if args.log_dir is None:
+        args.log_dir = os.path.join(args.output_dir, "tensorboard_logs")
+    yaml.safe_dump(config, open(os.path.join(args.output_dir, "config.yaml"), "w"))
+    return args, config
+
+
+if __name__ == "__main__":
+    main(*get_args())

@@ -1,0 +1,326 @@
+"""CPU tests of the host-side engine logic (no GPU): the real MplugEngine at world size 2 over gloo (parameter broadcast at
+initialize(), stage order / bucket slices / hooks, 1/world folded into the optimizer, clip on the reduced gradient),
+gradient accumulation, DeepSpeed-layout checkpoint round trip, `pretrained_ckpt` initialisation and the pos / temporal
+embedding resize.  The two optimizer kernels exist only as HIP: these tests replace exactly those two kernel calls
+(ops.grad_sumsq / ops.adamw_step_grouped / ops.add) with their arithmetic in torch -- test infrastructure, never the product."""
+import math
+import os
+import sys
+import tempfile
+
+import pytest
+import torch
+from torch import nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import youku_mplug_amd  # noqa: E402,F401
+
+
+# ------------------------------------------------------------------------------ kernel-call stubs (arithmetic of optim/adamw.py:66-115)
+def _stub_optimizer_kernels(monkeypatch_target):
+    from youku_mplug_amd import engine as eng
+
+    def grad_sumsq(g, out):
+        out.add_(g.float().pow(2).sum())
+
+    def adamw_step_grouped(p16, master, m, v, g16, tile_group, lrs, wds, beta1, beta2, eps, step, grad_scale=1.0, sumsq=None,
+                           max_norm=0.0):
+        g = g16.float() * grad_scale
+        if max_norm > 0:
+            norm = math.sqrt(float(sumsq)) * grad_scale
+            g = g * min(1.0, max_norm / (norm + 1e-6))
+        tg = tile_group.long().repeat_interleave(eng.TILE)
+        for gi, (lr, wd) in enumerate(zip(lrs, wds)):
+            sel = tg == gi
+            if not sel.any():
+                continue
+            master[sel] *= 1.0 - lr * wd
+            m[sel] = beta1 * m[sel] + (1 - beta1) * g[sel]
+            v[sel] = beta2 * v[sel] + (1 - beta2) * g[sel] ** 2
+            denom = (v[sel].sqrt() / math.sqrt(1 - beta2 ** step)) + eps
+            master[sel] -= (lr / (1 - beta1 ** step)) * m[sel] / denom
+        p16.copy_(master.to(p16.dtype))
+
+    def add(a, b, out=None):
+        out = out if out is not None else torch.empty_like(a)
+        torch.add(a, b, out=out)
+        return out
+
+    from youku_mplug_amd import ops
+    monkeypatch_target.setattr(ops, "grad_sumsq", grad_sumsq)
+    monkeypatch_target.setattr(ops, "adamw_step_grouped", adamw_step_grouped)
+    monkeypatch_target.setattr(ops, "add", add)
+
+
+class _MP:      # minimal monkeypatch for spawned workers (pytest's fixture does not cross processes)
+    def setattr(self, obj, name, val):
+        setattr(obj, name, val)
+
+
+# ------------------------------------------------------------------------------ a stub model with the real model's staging surface
+class _StubVit(nn.Module):
+    def __init__(self, dim, depth):
+        super().__init__()
+        self.stem = nn.Linear(dim, dim)
+        self.blocks = nn.ModuleList([nn.Linear(dim, dim) for _ in range(depth)])
+        self.norm = nn.LayerNorm(dim)
+        self.on_block_grads_ready = None
+
+
+class _StubFn(torch.autograd.Function):
+    """One autograd node whose backward replays an explicit, stage-ordered backward (head -> block n-1 .. 0 -> stem) and
+    fires the engine's hooks exactly as vision.TimeSformer.backward_features / pretrain._backward_pipeline do."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, x, y):
+        with torch.enable_grad():
+            h = model.visual_encoder.stem(x)
+            for blk in model.visual_encoder.blocks:
+                h = h + torch.tanh(blk(h))
+            loss = ((model.head(model.visual_encoder.norm(h)) - y) ** 2).mean()
+        ctx.model, ctx.loss = model, loss
+        return loss.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        m = ctx.model
+        ve = m.visual_encoder
+        params = [p for p in m.parameters() if p.requires_grad]
+        grads = dict(zip([id(p) for p in params], torch.autograd.grad(ctx.loss, params)))
+
+        def put(ps):
+            for p in ps:
+                p.grad.copy_(grads[id(p)] * g)
+        put(list(m.head.parameters()))
+        m.on_stage_grads_ready("head")
+        put(list(ve.norm.parameters()))
+        for bi in range(len(ve.blocks) - 1, -1, -1):
+            put(list(ve.blocks[bi].parameters()))
+            ve.on_block_grads_ready(bi)
+        put(list(ve.stem.parameters()))
+        ve.on_block_grads_ready(-1)
+        return torch.zeros(1), None, None, None
+
+
+class _StubModel(nn.Module):
+    def __init__(self, dim=24, depth=3, seed=0):
+        super().__init__()
+        torch.manual_seed(seed)
+        self.visual_encoder = _StubVit(dim, depth)
+        self.head = nn.Linear(dim, 5)
+        self.on_stage_grads_ready = None
+        self._anchor = torch.zeros(1, requires_grad=True)
+
+    def forward(self, x, y):
+        return _StubFn.apply(self._anchor, self, x, y), None
+
+
+def _data(n=8, dim=24):
+    g = torch.Generator().manual_seed(77)
+    return torch.randn(n, dim, generator=g), torch.randn(n, 5, generator=g)
+
+
+def _engine_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _stub_optimizer_kernels(_MP())
+    from youku_mplug_amd import engine as eng
+    model = _StubModel(seed=1234 + rank)                  # the reference seeds every rank differently (run_pretrain...py:210)
+    launched = []
+    groups = eng.get_parameter_groups(model, 0.05)
+    engine, opt, _, _ = eng.initialize(model=model, model_parameters=groups, config=dict(lr=1e-2, clip_grad=0.5, opt_eps=1e-6))
+    orig = engine.reducer.stage_ready
+    engine.reducer.stage_ready = lambda name: (launched.append(name), orig(name))[1]
+    model.visual_encoder.on_block_grads_ready = lambda bi: engine.reducer.stage_ready("stem" if bi < 0 else f"block{bi}")
+    model.on_stage_grads_ready = engine.reducer.stage_ready
+    p0 = engine.flat.params.clone()
+    x, y = _data()
+    xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
+    for _ in range(2):
+        loss, _ = engine(xs, ys)
+        engine.backward(loss)
+        engine.step()
+    q.put((rank, p0, engine.flat.params.clone(), list(engine.flat.stage_slices.items()), launched[:6], opt._global_grad_norm))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_real_engine_world2_gloo(monkeypatch):
+    """MplugEngine at N=2: replicas are identical after initialize() although built from different seeds; the buckets go
+    out in backward-completion order over the expected flat slices; two steps match a single process that sees the whole
+    batch (mean gradient, clip on the reduced gradient, 1/world folded into AdamW)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 23000 + os.getpid() % 3000
+    procs = [ctx.Process(target=_engine_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r[1:] for r in (q.get(timeout=180) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert torch.equal(res[0][0], res[1][0]), "parameters must be broadcast from rank 0 at initialize()"
+    assert torch.equal(res[0][1], res[1][1]), "replicas diverged"
+    names = [n for n, _ in res[0][2]]
+    assert names == ["head", "block2", "block1", "block0", "stem"]
+    assert res[0][3] == ["head", "block2", "block1", "block0", "stem", "head"], "hooks fire in backward-completion order, every step"
+    slices = dict(res[0][2])
+    assert slices["head"][0] == 0 and all(a % 256 == 0 and b % 256 == 0 for a, b in slices.values())
+    # single-process reference on the whole batch, same kernels-as-arithmetic
+    _stub_optimizer_kernels(monkeypatch)
+    from youku_mplug_amd import engine as eng
+    model = _StubModel(seed=1234)                 # rank 0's initialisation
+    groups = eng.get_parameter_groups(model, 0.05)
+    engine, opt, _, _ = eng.initialize(model=model, model_parameters=groups, config=dict(lr=1e-2, clip_grad=0.5, opt_eps=1e-6))
+    assert torch.equal(engine.flat.params, res[0][0])
+    x, y = _data()
+    for _ in range(2):
+        loss, _ = engine(x, y)
+        engine.backward(loss)
+        engine.step()
+    assert torch.allclose(engine.flat.params, res[0][1], atol=2e-6), (engine.flat.params - res[0][1]).abs().max()
+    assert abs(opt._global_grad_norm - res[0][4]) < 1e-5
+
+
+def test_gradient_accumulation_matches_big_batch(monkeypatch):
+    """`--update_freq 2` (DeepSpeed gradient_accumulation_steps): two micro-batches, one optimizer step on their mean
+    gradient; step() in the middle of the window applies nothing (run_pretrain_distributed_gpt3.py:46-53, 88-96)."""
+    _stub_optimizer_kernels(monkeypatch)
+    from youku_mplug_amd import engine as eng
+    x, y = _data()
+    ma, mb = _StubModel(seed=5), _StubModel(seed=5)
+    ea, _, _, _ = eng.initialize(model=ma, model_parameters=eng.get_parameter_groups(ma, 0.05), config=dict(lr=1e-2, update_freq=2))
+    eb, _, _, _ = eng.initialize(model=mb, model_parameters=eng.get_parameter_groups(mb, 0.05), config=dict(lr=1e-2))
+    assert ea.gas == 2 and eb.gas == 1
+    start = ea.flat.params.clone()
+    loss, _ = ea(x[:4], y[:4])
+    ea.backward(loss)
+    ea.step()
+    assert torch.equal(ea.flat.params, start) and ea.global_steps == 0 and not ea.is_gradient_accumulation_boundary()
+    loss, _ = ea(x[4:], y[4:])
+    ea.backward(loss)
+    ea.step()
+    assert ea.global_steps == 1
+    loss, _ = eb(x, y)
+    eb.backward(loss)
+    eb.step()
+    assert torch.allclose(ea.flat.params, eb.flat.params, atol=2e-6)
+
+
+def test_checkpoint_round_trip_deepspeed_layout(monkeypatch):
+    """save_checkpoint -> load_checkpoint into a fresh engine: module weights, fp32 master / moments and the step counter
+    survive; files follow utils.py:440-480 (<dir>/<tag>/mp_rank_00_model_states.pt with key 'module', <dir>/latest)."""
+    _stub_optimizer_kernels(monkeypatch)
+    from youku_mplug_amd import engine as eng
+    x, y = _data()
+    m1 = _StubModel(seed=9)
+    e1, _, _, _ = eng.initialize(model=m1, model_parameters=eng.get_parameter_groups(m1, 0.05), config=dict(lr=1e-2))
+    for _ in range(3):
+        loss, _ = e1(x, y)
+        e1.backward(loss)
+        e1.step()
+    with tempfile.TemporaryDirectory() as d:
+        e1.save_checkpoint(d, tag="checkpoint-3", client_state={"epoch": 3})
+        assert open(os.path.join(d, "latest")).read().strip() == "checkpoint-3"
+        raw = torch.load(os.path.join(d, "checkpoint-3", "mp_rank_00_model_states.pt"))
+        assert set(raw) == {"module", "epoch"} and set(raw["module"]) == set(m1.state_dict())
+        m2 = _StubModel(seed=10)
+        e2, _, _, _ = eng.initialize(model=m2, model_parameters=eng.get_parameter_groups(m2, 0.05), config=dict(lr=1e-2))
+        path, client = e2.load_checkpoint(d)
+        assert client == {"epoch": 3} and path.endswith("checkpoint-3")
+    assert torch.equal(e1.flat.params, e2.flat.params)
+    for a, b in ((e1.optimizer.master, e2.optimizer.master), (e1.optimizer.exp_avg, e2.optimizer.exp_avg),
+                 (e1.optimizer.exp_avg_sq, e2.optimizer.exp_avg_sq)):
+        assert torch.equal(a, b)
+    assert e2.optimizer.step_count == 3
+    for e in (e1, e2):          # and the two continue identically
+        loss, _ = e(x, y)
+        e.backward(loss)
+        e.step()
+    assert torch.equal(e1.flat.params, e2.flat.params)
+
+
+# ------------------------------------------------------------------------------ pretrained_ckpt / resize
+def test_pretrained_ckpt_initialises_vision_tower(tmp_path, monkeypatch):
+    """visual config `pretrained_ckpt: clip/<file>` (configs/models/clip-b16.json:2; models/distributed_gpt3.py:56-72):
+    a CLIP-layout checkpoint (fused qkv.bias, a head) lands in q_bias / v_bias, strict=False."""
+    from oracle.weights import CONFIG_TINY
+    from youku_mplug_amd.gpt3 import GPT3Config
+    from youku_mplug_amd.pretrain import DistributedGPT3_Pretrain, synthetic_model
+    donor = synthetic_model(CONFIG_TINY, device="cpu").visual_encoder
+    with torch.no_grad():
+        for p in donor.parameters():
+            p.copy_(torch.randn_like(p.float()).to(p.dtype))
+    clip = {}
+    for k, v in donor.state_dict().items():
+        if k.endswith("q_bias"):
+            vb = donor.state_dict()[k.replace("q_bias", "v_bias")]
+            clip[k.replace("q_bias", "qkv.bias")] = torch.cat([v, torch.zeros_like(v), vb]).float()
+        elif k.endswith("v_bias") or "temporal" in k:
+            continue                                        # an image CLIP ViT has no temporal branch
+        else:
+            clip[k] = v.float()
+    clip["head.weight"] = torch.zeros(3, 3)
+    monkeypatch.chdir(tmp_path)
+    torch.save(clip, "clip_vit_tiny.pth")
+    s = CONFIG_TINY
+    vis = dict(img_size=s.img_size, patch_size=s.patch_size, depth=s.vit_depth, num_frames=s.num_frames, embed_dim=s.vit_dim,
+               num_heads=s.vit_heads, mlp_ratio=s.vit_mlp_ratio, clip_model=True, pretrained_ckpt="clip/clip_vit_tiny.pth")
+    txt = GPT3Config(vocab_size=s.vocab, hidden_size=s.hidden, ffn_hidden_size=s.ffn, num_hidden_layers=s.layers,
+                     num_attention_heads=s.heads, max_position_embeddings=s.max_pos, layernorm_epsilon=s.gpt_ln_eps)
+    model = DistributedGPT3_Pretrain({"num_learnable_token": s.num_queries, "_synthetic": True}, visual_cfg=vis, text_cfg=txt, device="cpu")
+    got = model.visual_encoder.state_dict()
+    for k, v in donor.state_dict().items():
+        if "temporal" in k:
+            continue
+        assert torch.equal(got[k], v), k
+    assert any("temporal" in k for k in got)
+    vis["pretrained_ckpt"] = "clip/missing.pth"
+    with pytest.raises(FileNotFoundError):
+        DistributedGPT3_Pretrain({"num_learnable_token": s.num_queries, "_synthetic": True}, visual_cfg=vis, text_cfg=txt, device="cpu")
+
+
+def test_resize_pos_and_temporal_embed():
+    from youku_mplug_amd.vision import resize_pos_embed, resize_temporal_embed
+    g = torch.Generator().manual_seed(3)
+    pos = torch.randn(1, 1 + 14 * 14, 32, generator=g)
+    new = resize_pos_embed(pos, torch.zeros(1, 1 + 16 * 16, 32))
+    assert new.shape == (1, 257, 32) and torch.equal(new[:, 0], pos[:, 0])
+    assert torch.equal(resize_pos_embed(pos, torch.zeros(1, 197, 32)), pos)         # same grid: identity
+    tmp = torch.randn(1, 4, 32, generator=g)
+    t8 = resize_temporal_embed(tmp, torch.zeros(1, 8, 32))
+    assert t8.shape == (1, 8, 32) and torch.allclose(t8[:, 0], tmp[:, 0]) and torch.allclose(t8[:, -1], tmp[:, -1])
+    pad = resize_temporal_embed(tmp, torch.zeros(1, 6, 32), mode="padding")
+    assert torch.equal(pad[:, :4], tmp) and pad[:, 4:].abs().sum() == 0
+    from oracle import ref_loader
+    if ref_loader.reference_available():      # the reference's own functions (build container only), same tensors
+        vt, _, _ = ref_loader.import_reference()
+        assert torch.equal(vt.resize_pos_embed(pos, torch.zeros(1, 257, 32)), new)
+        assert torch.equal(vt.resize_temporal_embed(tmp, torch.zeros(1, 8, 32)), t8)
+        w = {"blocks.0.attn.qkv.bias": torch.arange(9.0), "head.weight": torch.zeros(2), "blocks.0.attn.qkv.weight": torch.ones(3)}
+        from youku_mplug_amd.vision import convert_pretrained_vit
+        a, b = convert_pretrained_vit(dict(w)), vt._convert_pretrained_vit(dict(w))
+        assert set(a) == set(b) and all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_load_checkpoint_resizes_visual_embeds(monkeypatch, tmp_path):
+    """downstream `--resume` path (downstream/run_retrieval_distributed_gpt3.py:402-420): a checkpoint trained at 4 frames /
+    another grid loads into an 8-frame model through resize_pos_embed / resize_temporal_embed."""
+    _stub_optimizer_kernels(monkeypatch)
+    from oracle.weights import CONFIG_TINY
+    from youku_mplug_amd import engine as eng
+    from youku_mplug_amd.pretrain import synthetic_model
+    small = synthetic_model(CONFIG_TINY, device="cpu", num_frames=2)
+    big = synthetic_model(CONFIG_TINY, device="cpu", num_frames=4)
+    with torch.no_grad():
+        small.visual_encoder.temporal_embed.copy_(torch.randn(1, 2, CONFIG_TINY.vit_dim))
+    e_small, _, _, _ = eng.initialize(model=small, model_parameters=eng.get_parameter_groups(small, 0.05), config=dict(lr=1e-3))
+    e_small.save_checkpoint(str(tmp_path), tag="t")
+    e_big, _, _, _ = eng.initialize(model=big, model_parameters=eng.get_parameter_groups(big, 0.05), config=dict(lr=1e-3))
+    e_big.load_checkpoint(str(tmp_path), tag="t")
+    te = big.visual_encoder.temporal_embed
+    assert te.shape[1] == 4 and torch.allclose(te[:, 0].float(), small.visual_encoder.temporal_embed[:, 0].float(), atol=1e-2)
+    assert torch.equal(big.visual_encoder.blocks[0].attn.qkv.weight, small.visual_encoder.blocks[0].attn.qkv.weight)

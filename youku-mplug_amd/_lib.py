@@ -92,7 +92,8 @@ class GptLayerWeights(C.Structure):
 
 class GptWeights(C.Structure):
     _fields_ = [("layers", c_int), ("hidden", c_int), ("heads", c_int), ("ffn", c_int), ("vocab", c_int), ("ln_eps", c_float),
-                ("layer", C.POINTER(GptLayerWeights)), ("wte", c_void_p), ("wpe", c_void_p), ("lnf_w", c_void_p), ("lnf_b", c_void_p)]
+                ("layer", C.POINTER(GptLayerWeights)), ("wte", c_void_p), ("wpe", c_void_p), ("lnf_w", c_void_p), ("lnf_b", c_void_p),
+                ("max_positions", c_int)]
 
 
 _SIGS.update({

@@ -27,6 +27,8 @@ extern "C" int mpv_gpt_decode_step(const mpv_gpt_weights* w, void* const* kv_cac
   const int n = Q + L, H = w->hidden, np = w->heads, hn = H / np, F4 = w->ffn;
   MPV_REQUIRE(batch > 0 && n > 0 && pos0 >= 0 && pos0 + n <= max_len, MPV_E_SHAPE,
               "mpv_gpt_decode_step: positions [%d, %d) do not fit max_len %d", pos0, pos0 + n, max_len);
+  MPV_REQUIRE(w->max_positions <= 0 || pos0 + n <= w->max_positions, MPV_E_SHAPE,
+              "mpv_gpt_decode_step: positions [%d, %d) run past the %d rows of the position embedding", pos0, pos0 + n, w->max_positions);
   MPV_REQUIRE(workspace_bytes >= mpv_gpt_decode_workspace_size(w, batch, n), MPV_E_ARG, "mpv_gpt_decode_step: workspace too small");
   const int64_t R = (int64_t)batch * n;
   char* p = (char*)workspace;

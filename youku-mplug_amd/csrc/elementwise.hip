@@ -243,16 +243,24 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const bf16* __restri
                                                             const float* __restrict__ weight, float* __restrict__ losses,
                                                             float* __restrict__ loss_sum, bf16* dlogits, int vocab,
                                                             long long ld) {
-  __shared__ float red[8];
+  __shared__ float red[9];
   const long long r = blockIdx.x;
   const bf16* row = logits + r * ld;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int V8 = vocab / 8;
+  // a label outside [0, vocab) (e.g. an ignore index) contributes neither loss nor gradient; the reference's
+  // nn.Embedding / vocab-parallel CE would fault on it (models/modeling_distributed_gpt3.py:1352-1359)
+  const int64_t tgt_raw = labels[r];
+  const bool tgt_ok = tgt_raw >= 0 && tgt_raw < (int64_t)vocab;
+  const long long tgt = tgt_ok ? (long long)tgt_raw : -1;
   float mx = -INFINITY;
   for (int c = tid; c < V8; c += 256) {
     const f32x8 v = cvt8(*(const bf16x8*)(row + c * 8));
 #pragma unroll
     for (int e = 0; e < 8; ++e) mx = fmaxf(mx, v[e]);
+    // the target logit is captured here, by the thread that owns its chunk: with dlogits aliasing logits the gradient
+    // sweep below overwrites the row, so it must not be re-read after that sweep has started anywhere in the workgroup
+    if (tgt_ok && (long long)c == (tgt >> 3)) red[8] = v[(int)(tgt & 7)];
   }
   mx = wave_max(mx);
   if (lane == 0) red[wave] = mx;
@@ -268,13 +276,9 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const bf16* __restri
   if (lane == 0) red[4 + wave] = sum;
   __syncthreads();
   sum = red[4] + red[5] + red[6] + red[7];
-  const int64_t tgt = labels[r];
-  const float w = weight ? weight[r] : 1.0f;
+  const float w = (weight ? weight[r] : 1.0f) * (tgt_ok ? 1.0f : 0.0f);
   const float lse = mx + __logf(sum);
-  if (tid == 0) {
-    const float loss = lse - bf2f(row[tgt]);
-    if (losses) losses[r] = loss;
-  }
+  if (tid == 0 && losses) losses[r] = tgt_ok ? lse - red[8] : 0.f;
   if (dlogits) {
     bf16* drow = dlogits + r * ld;
     const float inv = 1.0f / sum;

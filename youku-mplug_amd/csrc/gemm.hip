@@ -581,27 +581,14 @@ __global__ __launch_bounds__(256) void gemm_small_m_kernel(const SmallMArgs p) {
 
 constexpr int SLOTS = 512;                                   // resident workgroups: 256 CUs x 2
 constexpr size_t TAIL_WS_BYTES = (size_t)SLOTS * BM * BN * sizeof(float);   // 32 MiB of partial tiles
+constexpr size_t TAIL_CNT_BYTES = SLOTS * sizeof(unsigned);                  // + their arrival counters, in the caller's workspace
 
 extern "C" size_t mpv_gemm_workspace_size(int64_t M, int64_t N, int64_t K, int transA, int transB) {
-  if (!(transA && transB)) return TAIL_WS_BYTES;
-  // wgrad: split the (long) reduction so that >= ~2 workgroups per CU exist
-  const size_t w = (size_t)M * N * sizeof(float) * 32;
+  if (!(transA && transB)) return TAIL_WS_BYTES + TAIL_CNT_BYTES;
+  // wgrad: split the (long) reduction so that >= ~2 workgroups per CU exist (+ the per-split column sums of the fused
+  // bias gradient)
+  const size_t w = (size_t)M * N * sizeof(float) * 32 + (size_t)M * sizeof(float) * 64;
   return w > TAIL_WS_BYTES ? w : TAIL_WS_BYTES;
-}
-
-// arrival counters of the tail split, one per tail tile; atomicInc wraps them back to zero, so they are
-// zeroed once per device.  (GEMMs of one device are expected on one stream at a time.)
-static unsigned* tail_counters() {
-  static unsigned* cnt[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  if (!cnt[dev]) {
-    unsigned* p = nullptr;
-    if (hipMalloc(&p, SLOTS * sizeof(unsigned)) != hipSuccess) return nullptr;
-    if (hipMemset(p, 0, SLOTS * sizeof(unsigned)) != hipSuccess) return nullptr;
-    cnt[dev] = p;
-  }
-  return cnt[dev];
 }
 
 // wgrad split: pick the split count whose workgroup count best fills whole rounds of the 512 resident
@@ -611,7 +598,7 @@ static int choose_splitk(int64_t M, int64_t N, int64_t K, size_t ws_bytes) {
   int best = 1;
   double best_eff = 0.0;
   for (int s = 1; s <= 32; ++s) {
-    if (s > 1 && (K / s < 4 * BK || (size_t)M * N * sizeof(float) * s > ws_bytes)) break;
+    if (s > 1 && (K / s < 4 * BK || (size_t)M * N * sizeof(float) * s + (size_t)s * M * sizeof(float) > ws_bytes)) break;
     const int64_t blocks = tiles * s;
     const double eff = (double)blocks / (double)(((blocks + 511) / 512) * 512);
     if (eff > best_eff + 0.02) {
@@ -784,7 +771,7 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
 
   // tail split of a mostly empty last round (see GemmArgs); needs the partial-tile workspace
   int grid_x = g.nwg;
-  if (splitk == 1 && !g.out_f32 && !colsum_out && workspace && workspace_bytes >= TAIL_WS_BYTES) {
+  if (splitk == 1 && !g.out_f32 && !colsum_out && workspace && workspace_bytes >= TAIL_WS_BYTES + TAIL_CNT_BYTES) {
     const int R = g.nwg % SLOTS, nk = (int)((K + BK - 1) / BK);
     int tg = R > 0 ? SLOTS / R : 1;
     if (tg > 8) tg = 8;
@@ -792,7 +779,10 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
     if (tg > 1) {
       const int steps = (nk + tg - 1) / tg;
       tg = (nk + steps - 1) / steps;
-      unsigned* cnt = tg > 1 ? tail_counters() : nullptr;
+      // arrival counters live behind the partial tiles in the caller's (stream-ordered) workspace and are zeroed by a
+      // memset node ahead of the launch: no library-owned device state, nothing allocated here
+      unsigned* cnt = tg > 1 ? (unsigned*)((char*)workspace + TAIL_WS_BYTES) : nullptr;
+      if (cnt && hipMemsetAsync(cnt, 0, TAIL_CNT_BYTES, stream) != hipSuccess) cnt = nullptr;
       if (cnt) {
         g.tail_start = g.nwg - R;
         g.tail_g = tg;

@@ -71,10 +71,12 @@ __host__ __device__ __forceinline__ uint32_t mpv_mix32(uint32_t x) {
   x ^= x >> 16;
   return x;
 }
+// The seed halves go through the hash themselves before they meet the counter (an XOR of the raw seed into the counter
+// would make the streams of two seeds index-permutations of each other); both seed hashes are loop-invariant.
 __host__ __device__ __forceinline__ uint32_t mpv_rand32(uint64_t seed, uint64_t idx) {
   uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
-  uint32_t x = mpv_mix32(lo ^ (uint32_t)seed);
-  x = mpv_mix32(x ^ (uint32_t)(seed >> 32) ^ (hi * 0x9e3779b9u));
+  uint32_t x = mpv_mix32(lo + mpv_mix32((uint32_t)seed));
+  x = mpv_mix32(x + mpv_mix32((uint32_t)(seed >> 32) ^ 0x85ebca6bu) + hi * 0x9e3779b9u);
   return x;
 }
 // keep-threshold on the top 24 bits: keep iff r24 >= p * 2^24

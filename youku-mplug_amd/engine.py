@@ -118,6 +118,8 @@ class DPReducer:
         self.always = False      # run the collectives even on a 1-rank group (single-GPU validation of the exchange path)
 
     def stage_ready(self, name: str):
+        if getattr(self, "hold", False):
+            return      # gradient accumulation: buckets go out from step(), once the window's sum is in place
         if (self.world == 1 and not self.always) or name in self.launched or name not in self.flat.stage_slices:
             return
         a, b = self.flat.stage_slices[name]
@@ -184,11 +186,28 @@ class FlatAdamW:
         self.flat.params.copy_(self.master)
 
 
+def broadcast_module_state(model: nn.Module, flat: Optional["FlatParams"], process_group=None, src: int = 0):
+    """What deepspeed.initialize does for the reference (run_pretrain_distributed_gpt3.py:210 seeds every rank
+    differently, :263-267 hands the model to DeepSpeed, whose engine broadcasts it from rank 0): after this call every
+    rank holds rank `src`'s parameters and buffers.  Trainable parameters travel as the one flat buffer."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+        return
+    g_src = dist.get_global_rank(process_group, src) if process_group is not None else src
+    in_flat = set()
+    if flat is not None:
+        dist.broadcast(flat.params, src=g_src, group=process_group)
+        in_flat = {id(p) for p, _, _ in flat.slots}
+    for t in list(model.parameters()) + list(model.buffers()):
+        if id(t) not in in_flat:
+            dist.broadcast(t.data, src=g_src, group=process_group)
+
+
 class MplugEngine(nn.Module):
     def __init__(self, model: nn.Module, param_groups: List[dict], lr=1e-4, betas=(0.9, 0.999), eps=1e-6, clip_grad=0.0,
-                 process_group=None):
+                 process_group=None, gradient_accumulation_steps: int = 1):
         super().__init__()
         self.module = model
+        self.gas = max(1, int(gradient_accumulation_steps))
         group_of = {id(p): gi for gi, g in enumerate(param_groups) for p in g["params"]}
         if hasattr(model, "unused_parameters"):          # never receive gradients: skip them (tile group 255), as an
             for p in model.unused_parameters():          # optimizer over .grad=None parameters would
@@ -197,7 +216,9 @@ class MplugEngine(nn.Module):
         stages = [(n, [p for p in ps if id(p) in group_of]) for n, ps in stages]
         stages = [s for s in stages if s[1]]
         self.flat = FlatParams(stages, group_of)
+        broadcast_module_state(model, self.flat, process_group)     # replicas start identical (before the fp32 master copy)
         self.reducer = DPReducer(self.flat, process_group)
+        self.grad_acc = torch.zeros_like(self.flat.grads) if self.gas > 1 else None
         self.optimizer = FlatAdamW(self.flat, param_groups, lr=lr, betas=betas, eps=eps, clip_grad=clip_grad)
         self.micro_steps = 0
         self.global_steps = 0
@@ -212,17 +233,47 @@ class MplugEngine(nn.Module):
     def forward(self, *a, **k):
         return self.module(*a, **k)
 
+    def is_gradient_accumulation_boundary(self) -> bool:
+        return self.micro_steps % self.gas == 0
+
     def backward(self, loss):
+        """DeepSpeed semantics (`--update_freq`, run_pretrain_distributed_gpt3.py:46-53,88-96): the gradient of a window of
+        `gradient_accumulation_steps` micro-batches is their mean.  The backward kernels overwrite .grad, so micro-batch
+        gradients are summed into a second flat buffer and the 1/steps factor rides in the optimizer's grad_scale; the
+        overlapped bucket all-reduce only exists without accumulation (with it, the window's sum is reduced in step())."""
+        self.reducer.hold = self.gas > 1
         loss.backward()
         self.micro_steps += 1
+        if self.gas > 1:
+            if self.micro_steps % self.gas == 1:
+                self.grad_acc.copy_(self.flat.grads)
+            else:
+                from . import ops
+                ops.add(self.grad_acc, self.flat.grads, self.grad_acc)
+        self._set_dropout_seed()
 
-    def step(self):
-        self.reducer.finish()
-        self.optimizer.step(grad_scale=1.0 / self.reducer.world)
-        self.global_steps += 1
+    def _set_dropout_seed(self):
+        """Fresh, rank-distinct dropout streams for the next micro-batch: a 64-bit mix of (micro step, rank)."""
         td = getattr(self.module, "text_decoder", None)
         if td is not None and hasattr(td, "step_seed"):
-            td.step_seed = self.global_steps * 0x9E3779B1 + (dist.get_rank() if dist.is_initialized() else 0)
+            rank = dist.get_rank() if dist.is_initialized() else 0
+            x = (self.micro_steps * 0x9E3779B97F4A7C15 + (rank + 1) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+            x ^= x >> 30
+            x = (x * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+            x ^= x >> 27
+            x = (x * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+            x ^= x >> 31
+            td.step_seed = x & 0x7FFFFFFFFFFFFFFF
+
+    def step(self):
+        if not self.is_gradient_accumulation_boundary():
+            return                                        # mid-window micro step: nothing to apply yet
+        if self.gas > 1:
+            self.flat.grads.copy_(self.grad_acc)
+        self.reducer.hold = False
+        self.reducer.finish()
+        self.optimizer.step(grad_scale=1.0 / (self.reducer.world * self.gas))
+        self.global_steps += 1
 
     def zero_grad(self):
         pass      # every gradient is overwritten (never accumulated) by the next backward
@@ -250,12 +301,21 @@ class MplugEngine(nn.Module):
                 tag = f.read().strip()
         d = os.path.join(load_dir, str(tag))
         state = torch.load(os.path.join(d, "mp_rank_00_model_states.pt"), map_location="cpu")
-        self.module.load_state_dict(state.pop("module"), strict=False)
+        from .vision import resize_visual_embeds_in_state_dict
+        sd = resize_visual_embeds_in_state_dict(state.pop("module"), self.module)     # other resolution / frame count (downstream --resume)
+        missing, unexpected = self.module.load_state_dict(sd, strict=False)
+        if unexpected:
+            raise KeyError(f"checkpoint {d} holds keys this model does not have: {sorted(unexpected)[:8]}")
+        self.last_load_missing_keys = list(missing)
         op = os.path.join(d, "mp_rank_00_optim_states.pt")
-        if os.path.isfile(op):
-            self.optimizer.load_state_dict(torch.load(op, map_location=self.flat.device))
-        else:
-            self.optimizer.master.copy_(self.flat.params.float())
+        osd = torch.load(op, map_location=self.flat.device) if os.path.isfile(op) else None
+        if osd is not None and osd["master"].numel() == self.optimizer.master.numel():
+            self.optimizer.load_state_dict(osd)
+        else:       # weights only, or a checkpoint of another shape (resized embeddings): fresh optimizer state, as the
+            self.optimizer.master.copy_(self.flat.params.float())     # downstream scripts build a new optimizer after --resume
+            self.optimizer.exp_avg.zero_()
+            self.optimizer.exp_avg_sq.zero_()
+            self.optimizer.step_count = 0
         return d, state
 
 
@@ -270,6 +330,29 @@ def initialize(args=None, model=None, model_parameters=None, dist_init_required=
 
     groups = list(model_parameters) if model_parameters is not None else get_parameter_groups(model, pick("weight_decay", 0.05))
     groups = [g if isinstance(g, dict) else {"params": [g], "weight_decay": 0.0, "lr_scale": 1.0} for g in groups]
+    gas = pick("gradient_accumulation_steps", None) or pick("update_freq", 1) or 1
     engine = MplugEngine(model, groups, lr=pick("lr", 1e-4), betas=tuple(pick("opt_betas", (0.9, 0.999))), eps=pick("opt_eps", 1e-6),
-                         clip_grad=pick("clip_grad", 0.0) or 0.0)
+                         clip_grad=pick("clip_grad", 0.0) or 0.0, process_group=kw.get("process_group"),
+                         gradient_accumulation_steps=gas)
     return engine, engine.optimizer, None, None
+
+
+def cosine_scheduler(base_value, final_value, epochs, niter_per_ep, warmup_epochs=0, start_warmup_value=0.0, warmup_steps=-1,
+                     sched_type="cos"):
+    """Per-iteration schedule table the training loop indexes every step (utils.py:350-372): linear warm-up from
+    `start_warmup_value` to `base_value`, then half-cosine (or linear) decay to `final_value`."""
+    total = int(epochs * niter_per_ep)
+    warm = int(warmup_steps if warmup_steps > 0 else warmup_epochs * niter_per_ep)
+    out = []
+    for i in range(warm):
+        out.append(start_warmup_value + (base_value - start_warmup_value) * (i / (warm - 1) if warm > 1 else 1.0))
+    n = total - warm
+    for i in range(n):
+        if sched_type in ("cos", "cosine"):
+            out.append(final_value + 0.5 * (base_value - final_value) * (1.0 + math.cos(math.pi * i / n)))
+        elif sched_type == "linear":
+            out.append(base_value + (final_value - base_value) * (i / (n - 1) if n > 1 else 0.0))
+        else:
+            raise NotImplementedError(sched_type)
+    assert len(out) == total
+    return out

@@ -81,7 +81,8 @@ class DecodeState:
         fl = lm.encoder.final_layernorm
         self._w = _lib.GptWeights(nl, self.H, self.np_, lm.encoder.layers[0].mlp.dense_h_to_4h.out_features, self.V,
                                   float(fl.eps), self._layers, lm.embedding.word_embeddings.weight.data_ptr(),
-                                  lm.embedding.position_embeddings.weight.data_ptr(), fl.weight.data_ptr(), fl.bias.data_ptr())
+                                  lm.embedding.position_embeddings.weight.data_ptr(), fl.weight.data_ptr(), fl.bias.data_ptr(),
+                                  int(lm.embedding.position_embeddings.weight.shape[0]))
         self._ptrs = lambda t: (C.c_void_p * nl)(*[t[i].data_ptr() for i in range(nl)])
         self._cache_ptrs = self._ptrs(self.cache)
         self._twin_ptrs = None

@@ -184,7 +184,8 @@ class DistributedGPT3(nn.Module):
         p_h = cfg.hidden_dropout if train else 0.0
         p_a = cfg.attention_dropout if train else 0.0
         seed = self.step_seed + 0x51ED2705 * pass_index     # a second decoder pass of one step draws its own dropout masks
-        h = ops.gpt_embed_fwd(query_features, ids.contiguous(), lm.embedding.word_embeddings.weight,
+        ids_dev = ids.contiguous() if L > 0 else torch.zeros(1, dtype=torch.long, device=ids.device)   # never dereferenced when L == 0
+        h = ops.gpt_embed_fwd(query_features, ids_dev, lm.embedding.word_embeddings.weight,
                               lm.embedding.position_embeddings.weight, B, Q, L, H, dropout_p=p_h, seed=seed,
                               offset=_offset(0, _SITE_EMBED))
         st3 = (S * 3 * H, 3 * hn, 3 * H)
@@ -300,11 +301,20 @@ class DistributedGPT3(nn.Module):
         """models/modeling_distributed_gpt3.py:1578-1618 signature (no-grad / evaluation use).  The
         training path goes through DistributedGPT3_Pretrain, which drives forward_lm/backward_lm."""
         if tokens is None:
-            raise NotImplementedError("pass `tokens` (optionally `query_embeds`); raw input_embeds enter via DistributedGPT3_Pretrain")
-        B, L = tokens.shape
-        qf = None
-        if query_embeds is not None:
-            qf = query_embeds.reshape(-1, query_embeds.shape[-1]).contiguous()
+            # models/modeling_distributed_gpt3.py:652-657: without ids the word embeddings ARE input_embeds [B, L, H]
+            # (query_embeds, if any, in front): the whole sequence enters as embedding rows, no token lookups
+            if input_embeds is None:
+                raise ValueError("DistributedGPT3.forward needs `tokens` or `input_embeds`")
+            emb = input_embeds if query_embeds is None else torch.cat([query_embeds, input_embeds], dim=1)
+            B = emb.shape[0]
+            qf = emb.to(torch.bfloat16).reshape(-1, emb.shape[-1]).contiguous()
+            tokens = torch.zeros((B, 0), dtype=torch.long, device=emb.device)
+            L = 0
+        else:
+            B, L = tokens.shape
+            qf = None
+            if query_embeds is not None:
+                qf = query_embeds.to(torch.bfloat16).reshape(-1, query_embeds.shape[-1]).contiguous()
         Q = 0 if qf is None else qf.shape[0] // B
         if labels is None:
             labels = torch.zeros((B, Q + L), dtype=torch.long, device=tokens.device)

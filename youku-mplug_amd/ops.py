@@ -34,8 +34,9 @@ def _need_cuda(*ts):
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
-    """Stream-ordered scratch shared by all ops on a device (grown on demand)."""
-    key = torch.device(device).index or 0
+    """Stream-ordered scratch shared by all ops launched on one (device, stream) pair, grown on demand: launches on
+    different streams may run concurrently and must not share split-K partials or arrival counters."""
+    key = (torch.device(device).index or 0, torch.cuda.current_stream(device).cuda_stream)
     w = _ws.get(key)
     if w is None or w.numel() < nbytes:
         w = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -235,6 +236,8 @@ def add(a, b, out=None):
 
 
 def gpt_embed_fwd(query, ids, wte, wpe, B, Q, L, H, dropout_p=0.0, seed=0, offset=0):
+    if Q + L > wpe.shape[0]:      # nn.Embedding would raise on the position ids (models/modeling_distributed_gpt3.py:640-666)
+        raise _lib.MpvError(f"sequence of {Q + L} positions exceeds max_position_embeddings = {wpe.shape[0]}")
     h = torch.empty((B * (Q + L), H), dtype=torch.bfloat16, device=wte.device)
     check(_lib.lib().mpv_gpt_embed_fwd(_p(query), ids.data_ptr(), wte.data_ptr(), wpe.data_ptr(), h.data_ptr(), B, Q, L, H,
                                        dropout_p, seed, offset, _stream()), "mpv_gpt_embed_fwd")

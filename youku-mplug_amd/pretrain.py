@@ -18,7 +18,7 @@ from torch import nn
 
 from . import ops
 from .gpt3 import DistributedGPT3, GPT3Config
-from .vision import AttentionPool, Linear, TimeSformer, _param, grad_of
+from .vision import AttentionPool, Linear, TimeSformer, _param, convert_pretrained_vit, grad_of
 
 
 class _StepFn(torch.autograd.Function):
@@ -48,6 +48,7 @@ class DistributedGPT3_Pretrain(nn.Module):
         if text_cfg is None:
             text_cfg = GPT3Config.from_json_file(config["text_cfg"])                      # :37
         self.visual_encoder = self._build_visual_encoder(config, visual_cfg, device)
+        self._init_visual_encoder_from_ckpt(visual_cfg)                                   # :56-72
         if config.get("text_decoder") and not config.get("_synthetic", False):
             self.text_decoder = DistributedGPT3(model_dir=config["text_decoder"], device=device)          # :78-84
         else:
@@ -84,6 +85,27 @@ class DistributedGPT3_Pretrain(nn.Module):
             embed_dim=visual_cfg["embed_dim"], depth=visual_cfg["depth"], num_heads=visual_cfg["num_heads"],
             mlp_ratio=visual_cfg["mlp_ratio"], eps=1e-6, init_std=0.015, clip_model=visual_cfg.get("clip_model", False),
             device=device)                                                                # :39-54
+
+    def _init_visual_encoder_from_ckpt(self, visual_cfg):
+        """models/distributed_gpt3.py:56-72: `pretrained_ckpt` of the visual config ("clip/<path>.pth" in every shipped
+        config, configs/models/clip-b16.json:2) initialises the vision tower, strict=False; a missing file raises as
+        torch.load does in the reference.  `timm/<name>` needs the timm package and network access: refused loudly."""
+        pretrained = visual_cfg.get("pretrained_ckpt", None)
+        if pretrained is None:
+            return None
+        if pretrained.startswith("timm"):
+            raise NotImplementedError("pretrained_ckpt 'timm/...' needs the timm model zoo (not available here); "
+                                      "the shipped configs use 'clip/<file>.pth'")
+        if not pretrained.startswith("clip"):
+            return None
+        path = "/".join(pretrained.split("/")[1:])
+        weights = convert_pretrained_vit(torch.load(path, map_location="cpu"))
+        own = self.visual_encoder.state_dict()
+        weights = {k: (v.to(own[k].dtype) if k in own else v) for k, v in weights.items()}
+        msg = self.visual_encoder.load_state_dict(weights, strict=False)
+        print("Initialize Vision Encoder from CKPT {}".format(path))
+        print(msg)
+        return msg
 
     def no_weight_decay(self):
         return {"visual_encoder.pos_embed", "visual_encoder.cls_token", "visual_encoder.temporal_embed"}       # :224-226

@@ -103,6 +103,58 @@ class PatchEmbed(nn.Module):
         self.proj.bias = _param(dim, const=0.0, device=device) if bias else None
 
 
+def convert_pretrained_vit(weights: dict) -> dict:
+    """models/vision_transformer.py:719-729 (_convert_pretrained_vit): a timm / CLIP ViT state dict keeps one fused
+    `qkv.bias`; the video ViT holds `q_bias` / `v_bias` (the key bias is identically zero, :173) and no `head`."""
+    for key in list(weights.keys()):
+        if "qkv.bias" in key:
+            q, _, v_ = weights[key].chunk(3)
+            weights[key.replace("qkv.bias", "q_bias")] = q
+            weights[key.replace("qkv.bias", "v_bias")] = v_
+            del weights[key]
+        elif "head" in key:
+            del weights[key]
+    return weights
+
+
+def resize_pos_embed(posemb: torch.Tensor, posemb_new: torch.Tensor) -> torch.Tensor:
+    """models/vision_transformer.py:731-750: bilinear re-grid of the patch position embeddings (cls slot kept) when a
+    checkpoint was trained at another resolution.  Host-side checkpoint surgery (runs once, on CPU tensors)."""
+    ntok_new = posemb_new.shape[1] - 1
+    tok, grid = posemb[:, :1], posemb[0, 1:]
+    gs_old, gs_new = int(math.sqrt(len(grid))), int(math.sqrt(ntok_new))
+    grid = grid.reshape(1, gs_old, gs_old, -1).permute(0, 3, 1, 2)
+    orig = grid.dtype
+    grid = torch.nn.functional.interpolate(grid.float(), size=(gs_new, gs_new), mode="bilinear").to(orig)
+    grid = grid.permute(0, 2, 3, 1).reshape(1, gs_new * gs_new, -1)
+    return torch.cat([tok, grid], dim=1)
+
+
+def resize_temporal_embed(posemb: torch.Tensor, posemb_new: torch.Tensor, mode: str = "interpolate") -> torch.Tensor:
+    """models/vision_transformer.py:753-764: linear interpolation (or zero padding / truncation) of the per-frame
+    embeddings when the number of frames changes between pre-training and a downstream run."""
+    n_new, n_old = posemb_new.shape[1], posemb.shape[1]
+    if mode == "padding":
+        if n_old <= n_new:
+            out = posemb_new.detach().clone()
+            out[:, :n_old] = posemb
+            return out
+        return posemb[:, :n_new]
+    orig = posemb.dtype
+    out = torch.nn.functional.interpolate(posemb.float().permute(0, 2, 1), n_new, mode="linear")
+    return out.permute(0, 2, 1).to(orig)
+
+
+def resize_visual_embeds_in_state_dict(state_dict: dict, model: nn.Module, prefix: str = "visual_encoder.") -> dict:
+    """What every downstream `--resume` does before load_state_dict (downstream/run_retrieval_distributed_gpt3.py:
+    402-420): fit the checkpoint's pos / temporal embeddings to this model's grid and frame count."""
+    own = dict(model.named_parameters())
+    for key, fn in ((prefix + "pos_embed", resize_pos_embed), (prefix + "temporal_embed", resize_temporal_embed)):
+        if key in state_dict and key in own and tuple(state_dict[key].shape) != tuple(own[key].shape):
+            state_dict[key] = fn(state_dict[key], own[key].detach().cpu())
+    return state_dict
+
+
 def _qkv_bias(att: Attention):
     # models/vision_transformer.py:173: cat(q_bias, zeros, v_bias)
     return torch.cat([att.q_bias.detach(), torch.zeros_like(att.v_bias), att.v_bias.detach()])
