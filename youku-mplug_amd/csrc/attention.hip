@@ -19,6 +19,8 @@
 // Softmax is exact two-pass (pass 1: row max / sum, pass 2: normalised P.V), fp32, which
 // reproduces the reference's "softmax then cast to bf16 then @V" numerics and leaves a
 // per-row log-sum-exp for the backward kernels.
+#include <type_traits>
+
 #include "mpv_common.h"
 #include "mpv_kernels.h"
 
@@ -40,6 +42,13 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 // v_exp_f32 directly: exp2f() wraps it in a denormal-range rescue (6 VALU instead of 1; measured 38% of the forward
 // kernel's VALU instructions); probabilities below 2^-126 may flush to zero, far below bf16 resolution of the result
 __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+#ifdef MPV_ATTN_TIMING   // measurement build only (tools/probe/attn_timeline.py)
+__device__ long long mpv_attn_dbg[4096 * 8];
+#define ASTAMP(i) do { if (threadIdx.x == 0 && blockIdx.y < 4096) mpv_attn_dbg[blockIdx.y * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define ASTAMP(i) do { } while (0)
+#endif
 
 struct AttnArgs {
   const bf16 *q, *k, *v;
@@ -140,6 +149,34 @@ __device__ __forceinline__ bf16x8 frag_cols_c(const char* lds, int t, int ks, in
   u.s.b = hi;
   return u.v;
 }
+
+// ---- fragment reads of the LDS-resident kernels on plain 32-bit LDS offsets: one per-lane base register per operand,
+// tile / step / d-tile strides are immediates or a scalar.  (The clamped readers above recompute a 64-bit address with a
+// min() per fragment: measured ~100 of the ~300 VALU instructions per q-tile of the dK/dV kernel, which is VALU-bound.)
+// Regions hold whole 32-row tiles, the rows past the sequence end zero-filled by the LDS-DMA (out-of-range source), so
+// a tile read never leaves defined data; every product with such a row is masked by a select or multiplied by an exact
+// zero probability.
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(3))) bf16x8 lds_bf16x8;
+template <int PITCH>
+__device__ __forceinline__ int rows_lane_base(int lane) { return (lane & 31) * PITCH + (lane >> 5) * 16; }
+template <int PITCH>
+__device__ __forceinline__ int cols_lane_base(int lane) {
+  return (4 * (lane >> 5) + ((lane & 15) >> 2)) * PITCH + (((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;
+}
+// rows fragment: d-step s; `off` = region offset + tile * 32 * PITCH + lane base
+__device__ __forceinline__ bf16x8 frag_rows_f(const lds_char* sm, int off, int s) { return *(const lds_bf16x8*)(sm + off + s * 32); }
+template <int PITCH>
+__device__ __forceinline__ bf16x8 frag_cols_f(const lds_char* sm, int off, int ks, int dt) {
+  const lds_char* a = sm + off + ks * 16 * PITCH + dt * 64;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 8 * PITCH));
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo;
+  u.s.b = hi;
+  return u.v;
+}
+
 // registers of a 32x32 accumulator that form the B-operand for reduction step ks (see header)
 __device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& a, int ks) {
   f32x8 f;
@@ -622,7 +659,8 @@ template <int HD, int PITCH>
 __device__ __forceinline__ void dma_rows(const __amdgpu_buffer_rsrc_t src, char* lds, int nrows, long long rs, int wave, int nwaves,
                                          int lane, int hd = HD) {
   constexpr int CPR = PITCH / 16;
-  const int ninstr = (nrows * CPR + 63) / 64;
+  const int prows = (nrows + 31) / 32 * 32;          // whole 32-row tiles: rows past nrows are zero-filled (out-of-range source)
+  const int ninstr = (prows * CPR + 63) / 64;
   for (int i = wave; i < ninstr; i += nwaves) {
     const int g = i * 64 + lane;
     const int row = g / CPR, cc = g - row * CPR;
@@ -631,6 +669,8 @@ __device__ __forceinline__ void dma_rows(const __amdgpu_buffer_rsrc_t src, char*
     __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (lds_void_t*)(lds + i * 1024), 16, off, 0, 0, 0);
   }
 }
+// bytes of one LDS region of `rows` rows padded to whole tiles (device twin of the host's res_region)
+__device__ __forceinline__ int region_bytes(int rows, int pitch) { return (((rows + 31) / 32 * 32) * pitch + 1023) / 1024 * 1024; }
 
 template <int HD>
 __global__ __launch_bounds__(512) void attn_fwd_res_kernel(const AttnArgs p) {
@@ -642,13 +682,13 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(const AttnArgs p) {
   int b, h;
   if (!decode_bh(p, b, h)) return;
   const int bh = b * p.heads + h;
-  char* vl = rsm;                                                         // [sk][192 B]
-  char* kl = rsm + (((long long)p.sk * 192 + 1023) / 1024) * 1024;        // [sk][208 B]; tile over-reads of V land in K (finite)
+  char* vl = rsm;                                                         // [sk][208 B]
+  char* kl = rsm + region_bytes(p.sk, ROWB);                               // [sk][208 B]; both regions hold whole zero-padded tiles
   const bf16* qb = p.q + b * p.q_bs + h * p.q_hs;
   const __amdgpu_buffer_rsrc_t ksrc = make_rsrc(p.k + b * p.k_bs + h * p.k_hs, (uint32_t)(((long long)(p.sk - 1) * p.k_rs + p.hd) * 2));
   const __amdgpu_buffer_rsrc_t vsrc = make_rsrc(p.v + b * p.v_bs + h * p.v_hs, (uint32_t)(((long long)(p.sk - 1) * p.v_rs + p.hd) * 2));
   dma_rows<HD, ROWB>(ksrc, kl, p.sk, p.k_rs, wave, nwaves, lane, p.hd);
-  dma_rows<HD, 192>(vsrc, vl, p.sk, p.v_rs, wave, nwaves, lane, p.hd);
+  dma_rows<HD, ROWB>(vsrc, vl, p.sk, p.v_rs, wave, nwaves, lane, p.hd);
   const int q0 = (blockIdx.x * nwaves + wave) * 32;
   const int qrow = q0 + (lane & 31);
   bf16x8 qf[NS];
@@ -666,13 +706,24 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(const AttnArgs p) {
   const int wave_first_last = last_visible_key(p, q0);      // tiles entirely <= this need no masking
   const int nt = wave_last / 32 + 1;
   const float c2 = sc * 1.4426950408889634f;               // work in the exp2 domain: p = 2^(s*c2 - m)
+  const lds_char* sm = (const lds_char*)rsm;
+  const int kbase = (int)(kl - rsm) + rows_lane_base<ROWB>(lane), vbase = cols_lane_base<ROWB>(lane);
   float m = -INFINITY, l = 0.f;
   for (int kt = 0; kt < nt; ++kt) {
     f32x16 s;
 #pragma unroll
     for (int e = 0; e < 16; ++e) s[e] = 0.f;
+{   // two interleaved partial sums: a 6-deep dependent MFMA chain waits on its own latency
+  f32x16 s_odd;
 #pragma unroll
-    for (int st = 0; st < NS; ++st) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_c<ROWB>(kl, kt, st, lane, p.sk - 1), qf[st], s, 0, 0, 0);
+  for (int e = 0; e < 16; ++e) s_odd[e] = 0.f;
+#pragma unroll
+  for (int st = 0; st < NS; ++st) {
+    if (st & 1) s_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, kbase + kt * 32 * ROWB, st), qf[st], s_odd, 0, 0, 0);
+    else s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, kbase + kt * 32 * ROWB, st), qf[st], s, 0, 0, 0);
+  }
+  s += s_odd;
+}
     float mx = -INFINITY;
     if (kt * 32 + 31 <= wave_first_last) {
 #pragma unroll
@@ -710,8 +761,17 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(const AttnArgs p) {
     f32x16 s;
 #pragma unroll
     for (int e = 0; e < 16; ++e) s[e] = 0.f;
+{   // two interleaved partial sums: a 6-deep dependent MFMA chain waits on its own latency
+  f32x16 s_odd;
 #pragma unroll
-    for (int st = 0; st < NS; ++st) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_c<ROWB>(kl, kt, st, lane, p.sk - 1), qf[st], s, 0, 0, 0);
+  for (int e = 0; e < 16; ++e) s_odd[e] = 0.f;
+#pragma unroll
+  for (int st = 0; st < NS; ++st) {
+    if (st & 1) s_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, kbase + kt * 32 * ROWB, st), qf[st], s_odd, 0, 0, 0);
+    else s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, kbase + kt * 32 * ROWB, st), qf[st], s, 0, 0, 0);
+  }
+  s += s_odd;
+}
     if (kt * 32 + 31 <= wave_first_last && !p.drop_thr) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) s[e] = fexp2(s[e] * c2 - m) * inv_l;
@@ -732,7 +792,7 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(const AttnArgs p) {
       const bf16x8 pf = acc_to_frag(s, ks);
 #pragma unroll
       for (int d = 0; d < NDT; ++d)
-        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_c<192>(vl, kt, ks, d, lane, p.sk - 1), pf, oacc[d], 0, 0, 0);
+        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_f<ROWB>(sm, vbase + kt * 32 * ROWB, ks, d), pf, oacc[d], 0, 0, 0);
     }
   }
   if (qrow < p.sq) {
@@ -762,12 +822,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const AttnArgs p) 
   int b, h;
   if (!decode_bh(p, b, h)) return;
   const int bh = b * p.heads + h;
-  char* vl = rsm;                                                         // [sk][192 B]
-  char* kl = rsm + (((long long)p.sk * 192 + 1023) / 1024) * 1024;        // [sk][208 B]; tile over-reads of V land in K (finite)
+  char* vl = rsm;                                                         // [sk][208 B]
+  char* kl = rsm + region_bytes(p.sk, ROWB);                               // [sk][208 B]; both regions hold whole zero-padded tiles
   const __amdgpu_buffer_rsrc_t ksrc = make_rsrc(p.k + b * p.k_bs + h * p.k_hs, (uint32_t)(((long long)(p.sk - 1) * p.k_rs + p.hd) * 2));
   const __amdgpu_buffer_rsrc_t vsrc = make_rsrc(p.v + b * p.v_bs + h * p.v_hs, (uint32_t)(((long long)(p.sk - 1) * p.v_rs + p.hd) * 2));
   dma_rows<HD, ROWB>(ksrc, kl, p.sk, p.k_rs, wave, nwaves, lane, p.hd);
-  dma_rows<HD, 192>(vsrc, vl, p.sk, p.v_rs, wave, nwaves, lane, p.hd);
+  dma_rows<HD, ROWB>(vsrc, vl, p.sk, p.v_rs, wave, nwaves, lane, p.hd);
   const int q0 = (blockIdx.x * nwaves + wave) * 32;
   const int qrow = q0 + (lane & 31);
   bf16x8 qf[NS], dof[NS];
@@ -794,15 +854,30 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const AttnArgs p) 
   for (int d = 0; d < NDT; ++d)
 #pragma unroll
     for (int e = 0; e < 16; ++e) dqacc[d][e] = 0.f;
+  const lds_char* sm = (const lds_char*)rsm;
+  const int kroff = (int)(kl - rsm) + rows_lane_base<ROWB>(lane), vroff = rows_lane_base<ROWB>(lane);
+  const int kcoff = (int)(kl - rsm) + cols_lane_base<ROWB>(lane);
   for (int kt = 0; kt < nt; ++kt) {
     f32x16 s, dp;
 #pragma unroll
     for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
+{   // four interleaved partial sums (see above)
+  f32x16 s_odd, dp_odd;
 #pragma unroll
-    for (int st = 0; st < NS; ++st) {
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_c<ROWB>(kl, kt, st, lane, p.sk - 1), qf[st], s, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_c<192>(vl, kt, st, lane, p.sk - 1), dof[st], dp, 0, 0, 0);
+  for (int e = 0; e < 16; ++e) s_odd[e] = dp_odd[e] = 0.f;
+#pragma unroll
+  for (int st = 0; st < NS; ++st) {
+    if (st & 1) {
+      s_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, kroff + kt * 32 * ROWB, st), qf[st], s_odd, 0, 0, 0);
+      dp_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, vroff + kt * 32 * ROWB, st), dof[st], dp_odd, 0, 0, 0);
+    } else {
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, kroff + kt * 32 * ROWB, st), qf[st], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, vroff + kt * 32 * ROWB, st), dof[st], dp, 0, 0, 0);
     }
+  }
+  s += s_odd;
+  dp += dp_odd;
+}
     if (kt * 32 + 31 <= wave_first_last && !p.drop_thr) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) s[e] = fexp2(s[e] * c2 - lse2) * (dp[e] - dl);
@@ -824,7 +899,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const AttnArgs p) 
       const bf16x8 dsf = acc_to_frag(s, ks);
 #pragma unroll
       for (int d = 0; d < NDT; ++d)
-        dqacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_c<ROWB>(kl, kt, ks, d, lane, p.sk - 1), dsf, dqacc[d], 0, 0, 0);
+        dqacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_f<ROWB>(sm, kcoff + kt * 32 * ROWB, ks, d), dsf, dqacc[d], 0, 0, 0);
     }
   }
   if (qok) {
@@ -844,8 +919,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const AttnArgs p) 
   }
 }
 
+// One workgroup of ceil(sk / 32) waves per (batch, head): Q and dO are loaded once, and the 512-thread bound keeps the
+// kernel within 256 VGPRs so that two workgroups (14 waves at S = 197) share a CU.  (As a 256-thread kernel it was
+// allocated 336 VGPRs: one 4-wave workgroup per CU, two workgroups per (batch, head) each re-loading Q and dO.)
 template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_res_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(const AttnArgs p) {
   constexpr int NS = HD / 16;
   constexpr int NDT = (HD + 31) / 32;
   extern __shared__ __attribute__((aligned(1024))) char rsm[];
@@ -853,32 +931,34 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_res_kernel(const AttnArgs p)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
   int b, h;
   if (!decode_bh(p, b, h)) return;
+  ASTAMP(0);
   const int bh = b * p.heads + h;
   const int qtiles = (p.sq + 31) / 32, qrows = qtiles * 32;
   // LDS order matters: tile over-reads of dO land in Q (finite), over-reads of Q run past the allocation
   // (hardware returns 0 for out-of-range LDS reads); the fp32 stats sit in front so no bf16 fragment read
   // can ever interpret them as (possibly Inf/NaN) bf16.
   float* sl = (float*)rsm;                                                  // [lse*log2e | delta] x qrows
-  char* dl = rsm + ((2 * qrows * 4 + 1023) / 1024) * 1024;                  // dO [sq][192 B] (its b128 reads are 4-way conflicted: accepted)
-  char* ql = dl + (((long long)p.sq * 192 + 1023) / 1024) * 1024;           // Q  [sq][208 B]
+  char* dl = rsm + ((2 * qrows * 4 + 1023) / 1024) * 1024;                  // dO [sq][208 B]
+  char* ql = dl + region_bytes(p.sq, ROWB);                                  // Q  [sq][208 B]
   const __amdgpu_buffer_rsrc_t qsrc = make_rsrc(p.q + b * p.q_bs + h * p.q_hs, (uint32_t)(((long long)(p.sq - 1) * p.q_rs + p.hd) * 2));
   const __amdgpu_buffer_rsrc_t dosrc = make_rsrc(p.dO + b * p.o_bs + h * p.o_hs, (uint32_t)(((long long)(p.sq - 1) * p.o_rs + p.hd) * 2));
   dma_rows<HD, ROWB>(qsrc, ql, p.sq, p.q_rs, wave, nwaves, lane, p.hd);
-  dma_rows<HD, 192>(dosrc, dl, p.sq, p.o_rs, wave, nwaves, lane, p.hd);
+  dma_rows<HD, ROWB>(dosrc, dl, p.sq, p.o_rs, wave, nwaves, lane, p.hd);
   for (int r = tid; r < qrows; r += blockDim.x) {   // lse pre-multiplied by log2(e): probabilities are 2^(s*c2 - lse2)
     sl[r] = r < p.sq ? p.lse[(long long)bh * p.sq + r] * 1.4426950408889634f : 1e30f;
     sl[qrows + r] = r < p.sq ? p.delta[(long long)bh * p.sq + r] : 0.f;
   }
   const int k0 = (blockIdx.x * nwaves + wave) * 32;
   const int krow = k0 + (lane & 31);
-  bf16x8 kf[NS], vf[NS];
+  bf16x8 kf[NS];
   load_row_frags<HD>(kf, p.k + b * p.k_bs + h * p.k_hs, p.k_rs, krow, p.sk, lane, p.hd);
-  load_row_frags<HD>(vf, p.v + b * p.v_bs + h * p.v_hs, p.v_rs, krow, p.sk, lane, p.hd);
   const float sc = p.scale_q_bf16 ? 1.0f : p.scale;
   const float c2 = sc * 1.4426950408889634f;
   const bool kok = krow < p.sk;
+  ASTAMP(1);
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
+  ASTAMP(2);
   if (p.scale_q_bf16) {   // q' = bf16(q * scale) in place, once
     for (int g = tid; g < p.sq * (HD / 8); g += blockDim.x) {
       const int row = g / (HD / 8), cc = g - row * (HD / 8);
@@ -890,37 +970,52 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_res_kernel(const AttnArgs p)
     }
     __syncthreads();
   }
+  ASTAMP(3);
   if (k0 >= p.sk) return;
   const int first_q = p.causal ? max(0, k0 - (p.sk - p.sq)) : 0;
-  f32x16 dkacc[NDT], dvacc[NDT];
+  // Two passes over the q-tiles, dV first and dK second, each with ONE 32 x HD accumulator set: holding both sets plus
+  // K, V, S, dP fragments needs ~330 VGPRs (one wave per SIMD, or scratch traffic inside the loop when capped at 256:
+  // measured 5k clocks per q-tile).  The second pass recomputes S = Q K^T (+25% MFMAs) and the probabilities; both
+  // passes draw identical dropout masks (pure function of the element index).
+  const lds_char* sm = (const lds_char*)rsm;
+  const int qroff = (int)(ql - rsm) + rows_lane_base<ROWB>(lane), droff = (int)(dl - rsm) + rows_lane_base<ROWB>(lane);
+  const int qcoff = (int)(ql - rsm) + cols_lane_base<ROWB>(lane), dcoff = (int)(dl - rsm) + cols_lane_base<ROWB>(lane);
+  bf16* dkrow = p.dk + b * p.k_bs + h * p.k_hs + (long long)krow * p.k_rs;
+  bf16* dvrow = p.dv + b * p.v_bs + h * p.v_hs + (long long)krow * p.v_rs;
+  auto store_rows = [&](const f32x16 (&acc)[NDT], bf16* row, float mul) {
+    if (kok) {
 #pragma unroll
-  for (int d = 0; d < NDT; ++d)
+      for (int d = 0; d < NDT; ++d)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) dkacc[d][e] = dvacc[d][e] = 0.f;
-  for (int qt = first_q / 32; qt < qtiles; ++qt) {
-    f32x16 s, dp;
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int col = d * 32 + 8 * q4 + 4 * (lane >> 5);
+          if (col < p.hd) {
+            f32x4 a;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
-#pragma unroll
-    for (int st = 0; st < NS; ++st) {
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_c<ROWB>(ql, qt, st, lane, p.sq - 1), kf[st], s, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_c<192>(dl, qt, st, lane, p.sq - 1), vf[st], dp, 0, 0, 0);
+            for (int e = 0; e < 4; ++e) a[e] = acc[d][4 * q4 + e] * mul;
+            *(bf16x4*)(row + col) = cvt4(a);
+          }
+        }
     }
-    f32x16 pd;
+  };
+  // probability (and, in the dK pass, dS) of one 32 x 32 tile, in place: s -> P (WANT_DS = false) or dS (true)
+  auto softmax_bwd_tile = [&](auto WANT_DS, int qt, f32x16& s, const f32x16& dp) {
+    constexpr bool want_ds = decltype(WANT_DS)::value;
     // a q-tile is "interior" for this wave when every (q,key) pair is visible and in range
     const bool interior = !p.drop_thr && (k0 + 31 < p.sk) && (qt * 32 + 31 < p.sq) &&
                           (!p.causal || (k0 + 31 <= qt * 32 + (p.sk - p.sq)));
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
       const int qb4 = qt * 32 + 8 * q4 + 4 * (lane >> 5);
-      const f32x4 l4 = *(const f32x4*)(sl + qb4), d4 = *(const f32x4*)(sl + qrows + qb4);
+      const f32x4 l4 = *(const f32x4*)(sl + qb4);
+      f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (want_ds) d4 = *(const f32x4*)(sl + qrows + qb4);
       if (interior) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int e = 4 * q4 + j;
           const float pr = fexp2(s[e] * c2 - l4[j]);
-          pd[e] = pr;
-          s[e] = pr * (dp[e] - d4[j]);
+          s[e] = want_ds ? pr * (dp[e] - d4[j]) : pr;
         }
       } else {
 #pragma unroll
@@ -935,42 +1030,86 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_res_kernel(const AttnArgs p)
             const uint64_t idx = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qr) * (uint64_t)p.sk + (uint64_t)krow;
             keep = mpv_keep(p.seed, idx, p.drop_thr) ? p.drop_scale : 0.f;
           }
-          pd[e] = vis ? pr * keep : 0.f;
-          s[e] = vis ? pr * (dp[e] * keep - d4[j]) : 0.f;
+          if constexpr (want_ds) s[e] = vis ? pr * (dp[e] * keep - d4[j]) : 0.f;
+          else s[e] = vis ? pr * keep : 0.f;
         }
       }
     }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8 pf = acc_to_frag(pd, ks);
-      const bf16x8 dsf = acc_to_frag(s, ks);
-#pragma unroll
-      for (int d = 0; d < NDT; ++d) {
-        dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_c<192>(dl, qt, ks, d, lane, p.sq - 1), pf, dvacc[d], 0, 0, 0);
-        dkacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_c<ROWB>(ql, qt, ks, d, lane, p.sq - 1), dsf, dkacc[d], 0, 0, 0);
-      }
-    }
-  }
-  if (kok) {
-    bf16* dkrow = p.dk + b * p.k_bs + h * p.k_hs + (long long)krow * p.k_rs;
-    bf16* dvrow = p.dv + b * p.v_bs + h * p.v_hs + (long long)krow * p.v_rs;
+  };
+  {   // ---- pass 1: dV = P^T dO
+    f32x16 acc[NDT];
 #pragma unroll
     for (int d = 0; d < NDT; ++d)
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const int col = d * 32 + 8 * q4 + 4 * (lane >> 5);
-        if (col < p.hd) {
-          f32x4 a, c2;
+      for (int e = 0; e < 16; ++e) acc[d][e] = 0.f;
+    for (int qt = first_q / 32; qt < qtiles; ++qt) {
+      f32x16 s;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            a[e] = dkacc[d][4 * q4 + e] * sc;
-            c2[e] = dvacc[d][4 * q4 + e];
-          }
-          *(bf16x4*)(dkrow + col) = cvt4(a);
-          *(bf16x4*)(dvrow + col) = cvt4(c2);
-        }
-      }
+      for (int e = 0; e < 16; ++e) s[e] = 0.f;
+{   // two interleaved partial sums: a 6-deep dependent MFMA chain waits on its own latency
+  f32x16 s_odd;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s_odd[e] = 0.f;
+#pragma unroll
+  for (int st = 0; st < NS; ++st) {
+    if (st & 1) s_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, qroff + qt * 32 * ROWB, st), kf[st], s_odd, 0, 0, 0);
+    else s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, qroff + qt * 32 * ROWB, st), kf[st], s, 0, 0, 0);
   }
+  s += s_odd;
+}
+      softmax_bwd_tile(std::false_type{}, qt, s, s);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 pf = acc_to_frag(s, ks);
+#pragma unroll
+        for (int d = 0; d < NDT; ++d)
+          acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_f<ROWB>(sm, dcoff + qt * 32 * ROWB, ks, d), pf, acc[d], 0, 0, 0);
+      }
+    }
+    store_rows(acc, dvrow, 1.0f);
+  }
+  {   // ---- pass 2: dK = scale * dS^T Q
+    bf16x8 vf[NS];
+    load_row_frags<HD>(vf, p.v + b * p.v_bs + h * p.v_hs, p.v_rs, krow, p.sk, lane, p.hd);
+    f32x16 acc[NDT];
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[d][e] = 0.f;
+    for (int qt = first_q / 32; qt < qtiles; ++qt) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
+{   // four interleaved partial sums (see above)
+  f32x16 s_odd, dp_odd;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s_odd[e] = dp_odd[e] = 0.f;
+#pragma unroll
+  for (int st = 0; st < NS; ++st) {
+    if (st & 1) {
+      s_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, qroff + qt * 32 * ROWB, st), kf[st], s_odd, 0, 0, 0);
+      dp_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, droff + qt * 32 * ROWB, st), vf[st], dp_odd, 0, 0, 0);
+    } else {
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, qroff + qt * 32 * ROWB, st), kf[st], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, droff + qt * 32 * ROWB, st), vf[st], dp, 0, 0, 0);
+    }
+  }
+  s += s_odd;
+  dp += dp_odd;
+}
+      softmax_bwd_tile(std::true_type{}, qt, s, dp);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 dsf = acc_to_frag(s, ks);
+#pragma unroll
+        for (int d = 0; d < NDT; ++d)
+          acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_f<ROWB>(sm, qcoff + qt * 32 * ROWB, ks, d), dsf, acc[d], 0, 0, 0);
+      }
+    }
+    ASTAMP(4);
+    store_rows(acc, dkrow, sc);
+  }
+  ASTAMP(5);
 }
 
 // =========================================================================== temporal attention (VALU)
@@ -1222,10 +1361,11 @@ int check_desc(const mpv_attn_desc* d, const char* who) {
 }  // namespace
 
 constexpr int RES_MAX_ROWS = 256;
-static size_t res_region(int rows, int pitch) { return ((size_t)rows * pitch + 1023) / 1024 * 1024; }
+// whole zero-filled 32-row tiles per region (one workgroup per CU is register-bound anyway: 90 KiB at S = 197 costs nothing)
+static size_t res_region(int rows, int pitch) { return ((size_t)((rows + 31) / 32 * 32) * pitch + 1023) / 1024 * 1024; }
 static size_t res_lds_bytes(int rows, bool stats) {
   const int padded = (rows + 31) / 32 * 32;
-  return res_region(rows, 192) + res_region(rows, ROWB) + (stats ? (2 * (size_t)padded * sizeof(float) + 1023) / 1024 * 1024 : 0);
+  return 2 * res_region(rows, ROWB) + (stats ? (2 * (size_t)padded * sizeof(float) + 1023) / 1024 * 1024 : 0);
 }
 template <typename K>
 static void allow_lds(K kernel) {
@@ -1291,20 +1431,21 @@ extern "C" int mpv_attn_bwd(const mpv_attn_desc* d, const void* dO, void* dq, vo
     res_attr_once();
     const int nw = waves_for(d->sq);
     const int gy = (d->batch + 7) / 8 * 8 * d->heads;
-    dim3 gq((d->sq + 32 * nw - 1) / (32 * nw), gy), gk((d->sk + 127) / 128, gy);
+    const int nwk = waves_for(d->sk);
+    dim3 gq((d->sq + 32 * nw - 1) / (32 * nw), gy), gk((d->sk + 32 * nwk - 1) / (32 * nwk), gy);
     const size_t lq = res_lds_bytes(d->sk, false), lk = res_lds_bytes(d->sq, true);
     switch (d->head_dim <= 64 ? 64 : d->head_dim <= 80 ? 80 : 96) {
       case 64:
         hipLaunchKernelGGL((attn_bwd_dq_res_kernel<64>), gq, dim3(64 * nw), lq, stream, a);
-        hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<64>), gk, dim3(256), lk, stream, a);
+        hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<64>), gk, dim3(64 * nwk), lk, stream, a);
         break;
       case 80:
         hipLaunchKernelGGL((attn_bwd_dq_res_kernel<80>), gq, dim3(64 * nw), lq, stream, a);
-        hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<80>), gk, dim3(256), lk, stream, a);
+        hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<80>), gk, dim3(64 * nwk), lk, stream, a);
         break;
       default:
         hipLaunchKernelGGL((attn_bwd_dq_res_kernel<96>), gq, dim3(64 * nw), lq, stream, a);
-        hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<96>), gk, dim3(256), lk, stream, a);
+        hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<96>), gk, dim3(64 * nwk), lk, stream, a);
         break;
     }
     return mpv_check_launch("mpv_attn_bwd");
@@ -1394,3 +1535,9 @@ extern "C" int mpv_temporal_attn_bwd(const void* qkv, const void* dout, void* dq
   hipLaunchKernelGGL((temporal_attn_kernel<true>), dim3(grid), dim3(64 * nwv), lds, stream, t);
   return mpv_check_launch("mpv_temporal_attn_bwd");
 }
+
+#ifdef MPV_ATTN_TIMING
+extern "C" int mpv_attn_read_timeline(long long* host_out /* [4096*8] */) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mpv_attn_dbg), sizeof(long long) * 4096 * 8) == hipSuccess ? 0 : -4;
+}
+#endif
