@@ -1,6 +1,6 @@
 """bench.py -- whole-job throughput of the mPLUG-Video pre-train step on N MI355X GPUs.
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -33,6 +33,22 @@ class Shapes:
     img_size, patch_size, vit_dim, vit_depth, vit_heads, vit_mlp_ratio, num_frames = 224, 16, 768, 12, 8, 4, 8
     vit_ln_eps, num_queries = 1e-6, 128
     hidden, layers, heads, ffn, vocab, max_pos, gpt_ln_eps = 2048, 24, 32, 8192, 51200, 2048, 1e-5
+
+
+class ShapesD(Shapes):
+    """2.7B decoder dims (BASELINE.json configs[3]: hidden 2560, 32 layers, head_dim 80) -- `--config D`, a side line only."""
+    hidden, layers, heads, ffn = 2560, 32, 32, 10240
+
+
+def gemm_source_digest():
+    """Content hash of the GEMM kernel sources: a PMC traffic figure is only quoted for the kernels it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "youku-mplug_amd", "csrc")
+    for name in ("gemm.hip", "gemm256.hip", "gemm_args.h", "mpv_common.h"):
+        with open(os.path.join(base, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def algorithmic_train_flops(B, T, L, s=Shapes):
@@ -92,10 +108,13 @@ class GemmTimer:
 
 def pmc_traffic():
     """(HBM bytes per GEMM launch, provenance) from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE doubled per the
-    gfx950 note in MI355X_MICROARCH.md, + WRITE_SIZE; tools/rocpd_pmc.py writes the file).  None when no profile is committed."""
+    gfx950 note in MI355X_MICROARCH.md, + WRITE_SIZE; tools/profile_round.sh + tools/rocpd_pmc.py write the file).  The file records the
+    digest of the GEMM sources it was measured on: a figure from other kernels is refused (None), as is a missing profile."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_gemm_latest.json")
     try:
         rec = json.load(open(path))
+        if rec.get("gemm_src_sha") != gemm_source_digest():
+            return None, f"profiles/pmc_gemm_latest.json was measured on other GEMM sources ({rec.get('gemm_src_sha')}): re-run tools/profile_round.sh"
         return float(rec["hbm_mb_per_launch"]) * 1e6, rec.get("source", "profiles/pmc_gemm_latest.json")
     except (OSError, ValueError, KeyError):
         return None, None
@@ -181,9 +200,10 @@ def cpu_baseline(threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", choices=["B", "D"], default="B", help="B = the headline 1.3B config; D = 2.7B decoder dims (side line)")
+    ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--text-len", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -213,16 +233,18 @@ def main():
     from youku_mplug_amd.pretrain import synthetic_model
     _lib.check(_lib.lib().mpv_check_device(), "mpv_check_device")
 
+    global Shapes
+    if args.config == "D":
+        Shapes = ShapesD
+    if args.batch is None:
+        args.batch = 32 if args.config == "B" else 16
     Shapes.num_frames = args.frames
-    torch.manual_seed(1234 + rank)                                   # run_pretrain_distributed_gpt3.py:210
+    torch.manual_seed(1234 + rank)                                   # run_pretrain_distributed_gpt3.py:210 (initialize() broadcasts rank 0's weights)
     model = synthetic_model(Shapes, device=dev, num_frames=args.frames)
     with torch.no_grad():                                            # module-default init zeroes the temporal branch
         for blk in model.visual_encoder.blocks:
             blk.temporal_fc.weight.normal_(0, 0.015)
         model.visual_encoder.temporal_embed.normal_(0, 0.015)
-    if dist_on:                                                      # identical replicas
-        for p in model.parameters():
-            dist.broadcast(p.data, 0)
     model.train()
     groups = eng.get_parameter_groups(model, 0.05, model.no_weight_decay(), visual_backbone_scale=True)
     engine, opt, _, _ = eng.initialize(model=model, model_parameters=groups,
@@ -256,12 +278,18 @@ def main():
         if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
+    # per-step HIP events on the launch stream (torch's current stream is the stream every kernel of the step is launched
+    # on) give the distribution; the reported value is the whole timed region between two fences (the contract)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     fence()
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         loss = step(args.warmup + i)
+        marks[i + 1].record()
     fence()
     dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     if dist_on:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = dt.item()
@@ -281,7 +309,7 @@ def main():
         n = sum(v[2] for v in tot.values())
         by = sum(v[3] for v in tot.values())
         traffic, traffic_src = pmc_traffic()
-        roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel<TA,TB> (fwd/dgrad/wgrad)", "achieved": round(fl / tt / 1e12, 1),
+        roof = {"bound": "mfma", "kernel": "gemm256_kernel<TA,TB,KMAP> (256x256 eight-phase; fwd/dgrad/wgrad) + gemm_bf16_kernel (128x128 fallback)", "achieved": round(fl / tt / 1e12, 1),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / tt / 1e12 / PEAK_BF16_TFLOPS, 4),
                 "traffic": traffic, "traffic_unit": "bytes per launch (L2-miss side: 2*FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": round(by / n, 0),
@@ -289,8 +317,8 @@ def main():
                 "gemm_ms_per_step": round(tt / nroof * 1e3, 2),
                 "by_kernel": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / nroof * 1e3, 2), "launches": v[2] // nroof}
                             for k, v in tot.items()},
-                "step_algorithmic_tflop": round(algorithmic_train_flops(B, T, L) / 1e12, 2),
-                "step_frac": round(algorithmic_train_flops(B, T, L) / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4)}
+                "step_algorithmic_tflop": round(algorithmic_train_flops(B, T, L, Shapes) / 1e12, 2),
+                "step_frac": round(algorithmic_train_flops(B, T, L, Shapes) / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4)}
     if dist_on:
         dist.barrier()
     if rank == 0:
@@ -302,9 +330,12 @@ def main():
             log("cpu baseline done")
         rec = {"metric": "video-text samples/sec/node, mPLUG-Video 1.3B pretrain step", "value": round(world * B * args.steps / dt, 2),
                "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "ms_per_step": round(dt / args.steps * 1e3, 2),
+               "ms_per_step_hip_events": {"median": round(per_step[len(per_step) // 2], 2), "mean": round(sum(per_step) / len(per_step), 2),
+                                          "p10": round(per_step[len(per_step) // 10], 2), "p90": round(per_step[(9 * len(per_step)) // 10], 2)},
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": f"mPLUG-Video GPT3-1.3B pretrain step (freezeGPT, TimeSformer CLIP-B/16), per-GPU bs={B} x {T} frames x 224^2 + {L}-token titles",
+               "config": {"workload": f"mPLUG-Video GPT3-{'1.3B' if args.config == 'B' else '2.7B (side line, not the headline config)'} pretrain step (freezeGPT, TimeSformer CLIP-B/16), per-GPU bs={B} x {T} frames x 224^2 + {L}-token titles",
                           "global_batch": world * B, "frames": T, "text_len": L, "queries": Shapes.num_queries, "parallelism": f"dp{world}",
                           "trainable_params_m": round(engine.flat.numel / 1e6, 1), "final_loss": round(final_loss, 4)},
                "roofline": roof, "cpu_baseline": cpu}

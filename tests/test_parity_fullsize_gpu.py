@@ -1,0 +1,128 @@
+"""Parity where the benchmark runs: the HIP path at the TRUE dims and FULL depth of BASELINE.json configs[1] (1.3B, T=8),
+configs[3] (2.7B decoder, 32 layers) and configs[4] (ITC retrieval, 16 frames) against the oracle restatement
+(oracle/restate.py, pinned to the reference's own modules at 1e-5 by tests/test_host_cpu.py) run live in fp32 on the host,
+at batch sizes the host finishes in seconds.  eval() mode.  The measured deviations are appended to a parity report
+(gpurun_out/r02_parity.txt, committed under profiles/), and each case also records what the restatement itself loses when
+it runs in bf16 -- the yardstick for "within bf16 tolerance": gate = max(1e-2, 1.5 x that).
+"""
+import dataclasses
+import math
+import os
+import time
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPORT = os.environ.get("MPV_PARITY_REPORT", os.path.join(ROOT, "gpurun_out", "r02_parity.txt"))
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def report(line):
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    with open(REPORT, "a") as f:
+        f.write(line + "\n")
+    print(line)
+
+
+def _pretrain_case(name, cfg, dev, B, L, wseed, grad_keys):
+    from oracle import restate
+    from oracle.weights import make_inputs, make_state_dict
+    from youku_mplug_amd.pretrain import synthetic_model
+    t0 = time.time()
+    model = synthetic_model(cfg, device=dev)
+    sd = make_state_dict(cfg, wseed)
+    model.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+    model.eval()
+    video, ids, mask = make_inputs(cfg, B, L, seed=31, ragged=True)
+    text = types.SimpleNamespace(input_ids=ids.to(dev), attention_mask=mask.to(dev))
+    vid = video.to(dev).to(torch.bfloat16)
+    out = model.forward_outputs(vid, text)
+    loss, _ = model(vid, text)
+    loss.backward()
+    torch.cuda.synchronize()
+    # fp32 restatement on the same bf16-rounded weights and inputs
+    sdr = {k: v.bfloat16().float() for k, v in sd.items()}
+    for k in grad_keys:
+        sdr[k].requires_grad_(True)
+    ref = restate.pretrain_forward(video.bfloat16().float(), ids, mask, sdr, cfg)
+    ref["loss"].backward()
+    # the restatement in bf16 (what the reference's own bf16 run loses against its fp32 run)
+    with torch.no_grad():
+        sdb = {k: v.bfloat16() for k, v in sd.items()}
+        refb = restate.pretrain_forward(video.bfloat16(), ids, mask, sdb, cfg)
+    e = dict(logits=rel(out.logits, ref["logits"].detach()), hidden=rel(out.last_hidden_state, ref["last_hidden_state"].detach()),
+             losses=rel(out.losses, ref["losses"].detach()), loss=abs(out.loss.item() - ref["loss"].item()) / abs(ref["loss"].item()))
+    eb = dict(logits=rel(refb["logits"], ref["logits"].detach()), hidden=rel(refb["last_hidden_state"], ref["last_hidden_state"].detach()),
+              losses=rel(refb["losses"], ref["losses"].detach()))
+    params = dict(model.named_parameters())
+    worst = 0.0
+    for k in grad_keys:
+        g, r = params[k].grad.float().cpu(), sdr[k].grad
+        worst = max(worst, rel(g, r))
+        assert abs(g.norm().item() - r.norm().item()) <= 5e-2 * r.norm().item(), (k, g.norm().item(), r.norm().item())
+    report(f"{name}: B={B} L={L} frames={cfg.num_frames} layers={cfg.layers} vit_depth={cfg.vit_depth} | HIP vs fp32 oracle: "
+           f"logits {e['logits']:.3e} hidden {e['hidden']:.3e} losses {e['losses']:.3e} loss {e['loss']:.3e} worst-grad {worst:.3e} | "
+           f"oracle bf16 vs fp32: logits {eb['logits']:.3e} hidden {eb['hidden']:.3e} losses {eb['losses']:.3e} | {time.time() - t0:.0f} s")
+    assert e["logits"] <= max(1e-2, 1.5 * eb["logits"]), e
+    assert e["hidden"] <= max(2e-2, 1.5 * eb["hidden"]), e
+    assert e["losses"] <= max(1e-2, 1.5 * eb["losses"]), e
+    assert e["loss"] <= 5e-3, e
+    assert worst <= 8e-2, worst
+
+
+GRAD_KEYS = ["visual_fc.weight", "learnable_queries", "visual_encoder.blocks.0.attn.qkv.weight", "visual_encoder.blocks.11.mlp.fc2.weight",
+             "visual_encoder.blocks.5.temporal_fc.weight", "visual_encoder.pos_embed", "visual_encoder.norm.weight"]
+
+
+def test_configB_full_depth_vs_oracle(dev):
+    """configs[1] dims exactly (ViT-B/16 x 12 blocks x 8 frames, 128 queries, 24-layer 1.3B decoder, V = 51200), B = 2."""
+    from oracle.weights import CONFIG_B
+    _pretrain_case("config B (1.3B, T=8, full depth)", CONFIG_B, dev, B=2, L=32, wseed=11, grad_keys=GRAD_KEYS)
+
+
+def test_configD_full_depth_vs_oracle(dev):
+    """configs[3] dims exactly (2.7B decoder: 32 layers, hidden 2560, head_dim 80, ffn 10240), B = 1."""
+    from oracle.weights import CONFIG_D
+    _pretrain_case("config D (2.7B, T=8, full depth)", CONFIG_D, dev, B=1, L=32, wseed=12, grad_keys=GRAD_KEYS[:4])
+
+
+def test_retrieval_config5_shape_vs_oracle(dev):
+    """configs[4]: ITC retrieval fine-tune at 16 frames, 1.3B dims, full depth; B = 8 (the contrastive loss needs a batch)."""
+    from oracle import restate
+    from oracle.weights import CONFIG_B, make_inputs, make_state_dict, retrieval_spec
+    from youku_mplug_amd.retrieval import synthetic_retrieval_model
+    cfg = dataclasses.replace(CONFIG_B, num_frames=16)
+    t0 = time.time()
+    model = synthetic_retrieval_model(cfg, device=dev)
+    sd = make_state_dict(cfg, 13, spec_fn=retrieval_spec)
+    model.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+    model.eval()
+    B, L = 8, 32   # the similarity GEMMs take a global batch that is a multiple of 8
+    video, ids, mask = make_inputs(cfg, B, L, seed=41, ragged=True)
+    idx = torch.arange(B)
+    text = types.SimpleNamespace(input_ids=ids.to(dev), attention_mask=mask.to(dev))
+    vid = video.to(dev).to(torch.bfloat16)
+    loss = model(vid, text, idx.to(dev))
+    loss.backward()
+    torch.cuda.synchronize()
+    sdr = {k: v.bfloat16().float() for k, v in sd.items()}
+    keys = ["vision_proj.weight", "text_proj.weight", "visual_encoder.blocks.0.attn.qkv.weight", "visual_encoder.temporal_embed"]
+    for k in keys:
+        sdr[k].requires_grad_(True)
+    ref = restate.retrieval_forward(video.bfloat16().float(), ids, mask, idx, sdr, cfg)
+    ref["loss"].backward()
+    vf, tf = model.extract_vision_feature(vid), model.extract_text_feature(text)
+    e = dict(vision=rel(vf, ref["vision_feats"].detach()), text=rel(tf, ref["text_feat"].detach()),
+             loss=abs(loss.item() - ref["loss"].item()) / abs(ref["loss"].item()))
+    params = dict(model.named_parameters())
+    worst = max(rel(params[k].grad, sdr[k].grad) for k in keys)
+    report(f"retrieval config 5 shape (1.3B, T=16, full depth): B={B} L={L} | HIP vs fp32 oracle: vision feats {e['vision']:.3e} "
+           f"text feats {e['text']:.3e} loss {e['loss']:.3e} worst-grad {worst:.3e} | {time.time() - t0:.0f} s")
+    assert e["vision"] <= 2e-2 and e["text"] <= 2e-2 and e["loss"] <= 1e-2 and worst <= 1e-1, (e, worst)

@@ -38,9 +38,12 @@ def main():
     print(out)
     if len(sys.argv) > 4:       # GEMM-family summary consumed by bench.py (roofline.traffic)
         import json
-        gem = [(tot, n) for tot, k, n, fk, wk in rows if k.startswith("gemm_bf16_kernel")]
+        gem = [(tot, n) for tot, k, n, fk, wk in rows if k.startswith("gemm_bf16_kernel") or k.startswith("gemm256_kernel")]
         nl = sum(n for _, n in gem)
-        json.dump({"hbm_mb_per_launch": round(sum(t for t, _ in gem) / nl / 1024, 1), "launches": nl,
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from bench import gemm_source_digest
+        json.dump({"hbm_mb_per_launch": round(sum(t for t, _ in gem) / nl / 1024, 1), "launches": nl, "gemm_src_sha": gemm_source_digest(),
                    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 1 --warmup 1`, 2*FETCH+WRITE, " + sys.argv[3]},
                   open(sys.argv[4], "w"))  # note: copy into profiles/ with a repo-relative source
 
