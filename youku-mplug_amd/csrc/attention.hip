@@ -922,8 +922,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const AttnArgs p) 
 // One workgroup of ceil(sk / 32) waves per (batch, head): Q and dO are loaded once, and the 512-thread bound keeps the
 // kernel within 256 VGPRs so that two workgroups (14 waves at S = 197) share a CU.  (As a 256-thread kernel it was
 // allocated 336 VGPRs: one 4-wave workgroup per CU, two workgroups per (batch, head) each re-loading Q and dO.)
-template <int HD>
-__global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(const AttnArgs p) {
+// (head_dim 64 fits both accumulator sets in 256 VGPRs and keeps one pass: measured 80 us against 106 us for the two-pass
+// form on the GPT shape)
+template <int HD, int THREADS>
+__global__ __launch_bounds__(THREADS) void attn_bwd_dkv_res_kernel(const AttnArgs p) {
   constexpr int NS = HD / 16;
   constexpr int NDT = (HD + 31) / 32;
   extern __shared__ __attribute__((aligned(1024))) char rsm[];
@@ -1036,78 +1038,146 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(const AttnArgs p)
       }
     }
   };
-  {   // ---- pass 1: dV = P^T dO
-    f32x16 acc[NDT];
-#pragma unroll
-    for (int d = 0; d < NDT; ++d)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[d][e] = 0.f;
-    for (int qt = first_q / 32; qt < qtiles; ++qt) {
-      f32x16 s;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) s[e] = 0.f;
-{   // two interleaved partial sums: a 6-deep dependent MFMA chain waits on its own latency
-  f32x16 s_odd;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) s_odd[e] = 0.f;
-#pragma unroll
-  for (int st = 0; st < NS; ++st) {
-    if (st & 1) s_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, qroff + qt * 32 * ROWB, st), kf[st], s_odd, 0, 0, 0);
-    else s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, qroff + qt * 32 * ROWB, st), kf[st], s, 0, 0, 0);
-  }
-  s += s_odd;
-}
-      softmax_bwd_tile(std::false_type{}, qt, s, s);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 pf = acc_to_frag(s, ks);
-#pragma unroll
-        for (int d = 0; d < NDT; ++d)
-          acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_f<ROWB>(sm, dcoff + qt * 32 * ROWB, ks, d), pf, acc[d], 0, 0, 0);
-      }
-    }
-    store_rows(acc, dvrow, 1.0f);
-  }
-  {   // ---- pass 2: dK = scale * dS^T Q
+  if constexpr (HD <= 64) {
+    // head_dim 64 (GPT): one pass, S and P computed once
     bf16x8 vf[NS];
     load_row_frags<HD>(vf, p.v + b * p.v_bs + h * p.v_hs, p.v_rs, krow, p.sk, lane, p.hd);
-    f32x16 acc[NDT];
+    f32x16 dkacc[NDT], dvacc[NDT];
 #pragma unroll
     for (int d = 0; d < NDT; ++d)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[d][e] = 0.f;
+      for (int e = 0; e < 16; ++e) dkacc[d][e] = dvacc[d][e] = 0.f;
     for (int qt = first_q / 32; qt < qtiles; ++qt) {
-      f32x16 s, dp;
+      f32x16 s, dp, pd;
 #pragma unroll
       for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
-{   // four interleaved partial sums (see above)
-  f32x16 s_odd, dp_odd;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) s_odd[e] = dp_odd[e] = 0.f;
+      for (int st = 0; st < NS; ++st) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, qroff + qt * 32 * ROWB, st), kf[st], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, droff + qt * 32 * ROWB, st), vf[st], dp, 0, 0, 0);
+      }
+      {   // P -> pd and dS -> s in one sweep (one exponential and one dropout draw per element)
+        const bool interior = !p.drop_thr && (k0 + 31 < p.sk) && (qt * 32 + 31 < p.sq) &&
+                              (!p.causal || (k0 + 31 <= qt * 32 + (p.sk - p.sq)));
 #pragma unroll
-  for (int st = 0; st < NS; ++st) {
-    if (st & 1) {
-      s_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, qroff + qt * 32 * ROWB, st), kf[st], s_odd, 0, 0, 0);
-      dp_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, droff + qt * 32 * ROWB, st), vf[st], dp_odd, 0, 0, 0);
-    } else {
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, qroff + qt * 32 * ROWB, st), kf[st], s, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, droff + qt * 32 * ROWB, st), vf[st], dp, 0, 0, 0);
-    }
-  }
-  s += s_odd;
-  dp += dp_odd;
-}
-      softmax_bwd_tile(std::true_type{}, qt, s, dp);
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int qb4 = qt * 32 + 8 * q4 + 4 * (lane >> 5);
+          const f32x4 l4 = *(const f32x4*)(sl + qb4), d4 = *(const f32x4*)(sl + qrows + qb4);
+          if (interior) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int e = 4 * q4 + j;
+              const float pr = fexp2(s[e] * c2 - l4[j]);
+              pd[e] = pr;
+              s[e] = pr * (dp[e] - d4[j]);
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int e = 4 * q4 + j;
+              const int qr = qb4 + j;
+              const int lastk = p.causal ? qr + (p.sk - p.sq) : p.sk - 1;
+              const bool vis = kok && krow <= lastk && qr < p.sq;
+              const float pr = vis ? fexp2(s[e] * c2 - l4[j]) : 0.f;
+              float keep = 1.0f;
+              if (p.drop_thr) {
+                const uint64_t idx = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qr) * (uint64_t)p.sk + (uint64_t)krow;
+                keep = mpv_keep(p.seed, idx, p.drop_thr) ? p.drop_scale : 0.f;
+              }
+              pd[e] = vis ? pr * keep : 0.f;
+              s[e] = vis ? pr * (dp[e] * keep - d4[j]) : 0.f;
+            }
+          }
+        }
+      }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 pf = acc_to_frag(pd, ks);
         const bf16x8 dsf = acc_to_frag(s, ks);
 #pragma unroll
-        for (int d = 0; d < NDT; ++d)
-          acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_f<ROWB>(sm, qcoff + qt * 32 * ROWB, ks, d), dsf, acc[d], 0, 0, 0);
+        for (int d = 0; d < NDT; ++d) {
+          dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_f<ROWB>(sm, dcoff + qt * 32 * ROWB, ks, d), pf, dvacc[d], 0, 0, 0);
+          dkacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_f<ROWB>(sm, qcoff + qt * 32 * ROWB, ks, d), dsf, dkacc[d], 0, 0, 0);
+        }
       }
     }
     ASTAMP(4);
-    store_rows(acc, dkrow, sc);
+    store_rows(dvacc, dvrow, 1.0f);
+    store_rows(dkacc, dkrow, sc);
+  } else {
+    {   // ---- pass 1: dV = P^T dO
+      f32x16 acc[NDT];
+  #pragma unroll
+      for (int d = 0; d < NDT; ++d)
+  #pragma unroll
+        for (int e = 0; e < 16; ++e) acc[d][e] = 0.f;
+      for (int qt = first_q / 32; qt < qtiles; ++qt) {
+        f32x16 s;
+  #pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+  {   // two interleaved partial sums: a 6-deep dependent MFMA chain waits on its own latency
+    f32x16 s_odd;
+  #pragma unroll
+    for (int e = 0; e < 16; ++e) s_odd[e] = 0.f;
+  #pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      if (st & 1) s_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, qroff + qt * 32 * ROWB, st), kf[st], s_odd, 0, 0, 0);
+      else s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, qroff + qt * 32 * ROWB, st), kf[st], s, 0, 0, 0);
+    }
+    s += s_odd;
+  }
+        softmax_bwd_tile(std::false_type{}, qt, s, s);
+  #pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8 pf = acc_to_frag(s, ks);
+  #pragma unroll
+          for (int d = 0; d < NDT; ++d)
+            acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_f<ROWB>(sm, dcoff + qt * 32 * ROWB, ks, d), pf, acc[d], 0, 0, 0);
+        }
+      }
+      store_rows(acc, dvrow, 1.0f);
+    }
+    {   // ---- pass 2: dK = scale * dS^T Q
+      bf16x8 vf[NS];
+      load_row_frags<HD>(vf, p.v + b * p.v_bs + h * p.v_hs, p.v_rs, krow, p.sk, lane, p.hd);
+      f32x16 acc[NDT];
+  #pragma unroll
+      for (int d = 0; d < NDT; ++d)
+  #pragma unroll
+        for (int e = 0; e < 16; ++e) acc[d][e] = 0.f;
+      for (int qt = first_q / 32; qt < qtiles; ++qt) {
+        f32x16 s, dp;
+  #pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
+  {   // four interleaved partial sums (see above)
+    f32x16 s_odd, dp_odd;
+  #pragma unroll
+    for (int e = 0; e < 16; ++e) s_odd[e] = dp_odd[e] = 0.f;
+  #pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      if (st & 1) {
+        s_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, qroff + qt * 32 * ROWB, st), kf[st], s_odd, 0, 0, 0);
+        dp_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, droff + qt * 32 * ROWB, st), vf[st], dp_odd, 0, 0, 0);
+      } else {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, qroff + qt * 32 * ROWB, st), kf[st], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, droff + qt * 32 * ROWB, st), vf[st], dp, 0, 0, 0);
+      }
+    }
+    s += s_odd;
+    dp += dp_odd;
+  }
+        softmax_bwd_tile(std::true_type{}, qt, s, dp);
+  #pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8 dsf = acc_to_frag(s, ks);
+  #pragma unroll
+          for (int d = 0; d < NDT; ++d)
+            acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_f<ROWB>(sm, qcoff + qt * 32 * ROWB, ks, d), dsf, acc[d], 0, 0, 0);
+        }
+      }
+      ASTAMP(4);
+      store_rows(acc, dkrow, sc);
+    }
   }
   ASTAMP(5);
 }
@@ -1376,7 +1446,7 @@ static void res_attr_once() {
   if (done) return;
   allow_lds(attn_fwd_res_kernel<64>); allow_lds(attn_fwd_res_kernel<80>); allow_lds(attn_fwd_res_kernel<96>);
   allow_lds(attn_bwd_dq_res_kernel<64>); allow_lds(attn_bwd_dq_res_kernel<80>); allow_lds(attn_bwd_dq_res_kernel<96>);
-  allow_lds(attn_bwd_dkv_res_kernel<64>); allow_lds(attn_bwd_dkv_res_kernel<80>); allow_lds(attn_bwd_dkv_res_kernel<96>);
+  allow_lds(attn_bwd_dkv_res_kernel<64, 512>); allow_lds(attn_bwd_dkv_res_kernel<80, 512>); allow_lds(attn_bwd_dkv_res_kernel<96, 512>);
   done = true;
 }
 
@@ -1437,15 +1507,15 @@ extern "C" int mpv_attn_bwd(const mpv_attn_desc* d, const void* dO, void* dq, vo
     switch (d->head_dim <= 64 ? 64 : d->head_dim <= 80 ? 80 : 96) {
       case 64:
         hipLaunchKernelGGL((attn_bwd_dq_res_kernel<64>), gq, dim3(64 * nw), lq, stream, a);
-        hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<64>), gk, dim3(64 * nwk), lk, stream, a);
+        hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<64, 512>), gk, dim3(64 * nwk), lk, stream, a);
         break;
       case 80:
         hipLaunchKernelGGL((attn_bwd_dq_res_kernel<80>), gq, dim3(64 * nw), lq, stream, a);
-        hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<80>), gk, dim3(64 * nwk), lk, stream, a);
+        hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<80, 512>), gk, dim3(64 * nwk), lk, stream, a);
         break;
       default:
         hipLaunchKernelGGL((attn_bwd_dq_res_kernel<96>), gq, dim3(64 * nw), lq, stream, a);
-        hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<96>), gk, dim3(64 * nwk), lk, stream, a);
+        hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<96, 512>), gk, dim3(64 * nwk), lk, stream, a);
         break;
     }
     return mpv_check_launch("mpv_attn_bwd");
