@@ -58,33 +58,54 @@ __global__ void embed_assemble_fwd_kernel(const bf16* __restrict__ patch, const 
   }
 }
 
-// dpos[s] = sum_{b,t} dx[b,t,s]; dcls = dpos[0]; one block per slot s, threads over D.
-__global__ void embed_bwd_pos_kernel(const bf16* __restrict__ dx, bf16* __restrict__ dcls, bf16* __restrict__ dpos, int B,
-                                     int T, int N, int D) {
-  const int s = blockIdx.x;
-  for (int c = threadIdx.x; c < D; c += blockDim.x) {
-    float a = 0.f;
-    for (int bt = 0; bt < B * T; ++bt) a += bf2f(dx[((long long)bt * (N + 1) + s) * D + c]);
-    dpos[(long long)s * D + c] = f2bf(a);
-    if (s == 0) dcls[c] = f2bf(a);
+// dpos[s] = sum_{b,t} dx[b,t,s] (dcls = the s = 0 row): columns of the flattened [(1+N) * D] row, 8 per thread (16-byte
+// loads), 64 column groups x 4 row lanes per workgroup, the B*T rows looped per lane and folded through LDS.
+__global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const bf16* __restrict__ dx, bf16* __restrict__ dcls, bf16* __restrict__ dpos,
+                                                            int BT, long long C, int D) {
+  __shared__ float red[4][64][8];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const long long c8 = (long long)blockIdx.x * 64 + cl;     // column group
+  f32x8 a = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c8 * 8 < C)
+    for (int r = rl; r < BT; r += 4) a += cvt8(*(const bf16x8*)(dx + (long long)r * C + c8 * 8));
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rl][cl][e] = a[e];
+  __syncthreads();
+  if (rl == 0 && c8 * 8 < C) {
+    f32x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (red[0][cl][e] + red[1][cl][e]) + (red[2][cl][e] + red[3][cl][e]);
+    const bf16x8 ob = cvt8(o);
+    *(bf16x8*)(dpos + c8 * 8) = ob;
+    if (c8 * 8 < D) *(bf16x8*)(dcls + c8 * 8) = ob;
   }
 }
-// dtemporal[t] = sum_{b,n} dx[b,t,1+n]; grid (T, nsplit) with fp32 atomics into a zeroed scratch is
-// avoided: one block per (t, column stripe) loops over b,n.
-__global__ void embed_bwd_temporal_kernel(const bf16* __restrict__ dx, bf16* __restrict__ dtemporal, int B, int T, int N,
-                                          int D) {
+// dtemporal[t] = sum_{b,n} dx[b,t,1+n]: one workgroup per (t, 64-column stripe) = 8 column groups x 32 row lanes, every
+// lane looping over its share of the B*N token rows with 16-byte loads (a row's stripe is one 128-byte line); no scratch.
+__global__ __launch_bounds__(256) void embed_bwd_temporal_kernel(const bf16* __restrict__ dx, bf16* __restrict__ dtemporal, int B, int T,
+                                                                 int N, int D) {
+  __shared__ float red[32][8][8];
   const int t = blockIdx.x;
-  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
-  const int part = threadIdx.x >> 6;  // 4 waves split the rows
-  __shared__ float red[4][64];
-  float a = 0.f;
+  const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int c = blockIdx.y * 64 + cg * 8;
+  f32x8 a = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (c < D) {
-    for (int b = 0; b < B; ++b)
-      for (int n = part; n < N; n += 4) a += bf2f(dx[(((long long)b * T + t) * (N + 1) + 1 + n) * D + c]);
+    const int rows = B * N;
+    for (int r = rl; r < rows; r += 32) {
+      const int b = r / N, n = r - b * N;
+      a += cvt8(*(const bf16x8*)(dx + (((long long)b * T + t) * (N + 1) + 1 + n) * D + c));
+    }
   }
-  red[part][threadIdx.x & 63] = a;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rl][cg][e] = a[e];
   __syncthreads();
-  if (part == 0 && c < D) dtemporal[(long long)t * D + c] = f2bf(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (threadIdx.x < 64 && blockIdx.y * 64 + (int)threadIdx.x < D) {
+    const int g = threadIdx.x >> 3, e = threadIdx.x & 7;
+    float o = 0.f;
+#pragma unroll
+    for (int l = 0; l < 32; ++l) o += red[l][g][e];
+    dtemporal[(long long)t * D + blockIdx.y * 64 + threadIdx.x] = f2bf(o);
+  }
 }
 
 // ---------------------------------------------------------------- cls merge
@@ -623,11 +644,13 @@ extern "C" int mpv_vit_embed_assemble_fwd(const void* patch, const void* cls_tok
 extern "C" int mpv_vit_embed_assemble_bwd(const void* dx, void* dpatch, void* dcls, void* dpos, void* dtemporal, int B,
                                           int T, int N, int D, hipStream_t stream) {
   MPV_REQUIRE(dx && dpatch && dcls && dpos && dtemporal, MPV_E_ARG, "mpv_vit_embed_assemble_bwd: null pointer");
-  MPV_REQUIRE(D % 4 == 0 && B > 0 && T > 0 && N > 0, MPV_E_SHAPE, "mpv_vit_embed_assemble_bwd: bad shape");
+  MPV_REQUIRE(D % 8 == 0 && B > 0 && T > 0 && N > 0, MPV_E_SHAPE, "mpv_vit_embed_assemble_bwd: bad shape (D must be a multiple of 8)");
   const long long rows = (long long)B * T * N;
   hipLaunchKernelGGL(copy_rows_kernel, dim3(ew_grid(rows * (D / 4))), dim3(256), 0, stream, (const bf16*)dx, (bf16*)dpatch, rows, D,
                      (long long)D, (long long)D, RowMap{N, N + 1, 1}, RowMap{0, 0, 0});
-  hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3(N + 1), dim3(256), 0, stream, (const bf16*)dx, (bf16*)dcls, (bf16*)dpos, B, T, N, D);
+  const long long C = (long long)(N + 1) * D;
+  hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3((unsigned)((C / 8 + 63) / 64)), dim3(256), 0, stream, (const bf16*)dx, (bf16*)dcls, (bf16*)dpos,
+                     B * T, C, D);
   hipLaunchKernelGGL(embed_bwd_temporal_kernel, dim3(T, (D + 63) / 64), dim3(256), 0, stream, (const bf16*)dx, (bf16*)dtemporal, B, T,
                      N, D);
   return mpv_check_launch("mpv_vit_embed_assemble_bwd");
