@@ -68,24 +68,64 @@ enum EpKind { EP_PLAIN, EP_ERF_PRE, EP_TANH_PRE, EP_BWD_ERF, EP_BWD_TANH, EP_RES
 
 template <int ACT>
 __device__ __forceinline__ f32x8 apply_act(f32x8 v) {
+  if constexpr (ACT == MPV_ACT_GELU_ERF || ACT == MPV_ACT_GELU_TANH) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = ACT == MPV_ACT_GELU_ERF ? gelu_erf_f(v[e]) : ACT == MPV_ACT_GELU_TANH ? gelu_tanh_f(v[e]) : fmaxf(v[e], 0.f);
+    for (int e = 0; e < 8; e += 2) {       // two lanes of the register pair per instruction (v_pk_fma_f32)
+      const f32x2 r = mpv_gelu_t<ACT == MPV_ACT_GELU_ERF ? 1 : 2>(f32x2{v[e], v[e + 1]});
+      v[e] = r[0];
+      v[e + 1] = r[1];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+  }
   return v;
 }
 template <int ACT>
 __device__ __forceinline__ f32x8 apply_act_grad(f32x8 v, f32x8 z) {
+  if constexpr (ACT == MPV_ACT_GELU_ERF || ACT == MPV_ACT_GELU_TANH) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e)
-    v[e] *= ACT == MPV_ACT_GELU_ERF ? gelu_erf_grad_f(z[e]) : ACT == MPV_ACT_GELU_TANH ? gelu_tanh_grad_f(z[e]) : (z[e] > 0.f ? 1.f : 0.f);
+    for (int e = 0; e < 8; e += 2) {
+      const f32x2 r = mpv_gelu_grad_mul_t<ACT == MPV_ACT_GELU_ERF ? 1 : 2>(f32x2{v[e], v[e + 1]}, f32x2{z[e], z[e + 1]});
+      v[e] = r[0];
+      v[e + 1] = r[1];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = z[e] > 0.f ? v[e] : 0.f;
+  }
   return v;
 }
 
-// second half of the epilogue: the staged bf16 tile (acc * alpha + bias, pitch CPITCH) -> global, 8 columns per thread
+// second half of the epilogue: the staged bf16 tile (acc * alpha + bias, pitch CPITCH) -> global, 8 columns per thread.
+// Everything the finish reads from global memory (GELU' pre-activation, residual) is fetched for all 16 chunks of the
+// thread BEFORE the staging barrier: interleaved with the stores each load sat behind `s_waitcnt vmcnt(0)` (stores
+// count in vmcnt, and the compiler cannot prove C does not alias z / the residual), 16 serial round trips = 14 us per
+// tile at K = 768; up front they cost one latency, hidden behind the barrier.
 template <int KIND>
 __device__ __forceinline__ void finish_rows(const GemmArgs& p, const bf16* cb, int tid, int m0, int n0) {
-#pragma unroll 4
-  for (int it = 0; it < 16; ++it) {
-    const int c = tid + 512 * it;
+  constexpr bool EXT = KIND == EP_BWD_ERF || KIND == EP_BWD_TANH || KIND == EP_RES || KIND == EP_DROP_RES;
+  bf16x8 ext[EXT ? 16 : 1];
+  if constexpr (EXT) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int c = tid + 512 * it;
+      const int m = m0 + (c >> 5), n = n0 + (c & 31) * 8;
+      ext[it] = bf16x8{};
+      if (m < p.M && n < p.N) {
+        if constexpr (KIND == EP_BWD_ERF || KIND == EP_BWD_TANH) ext[it] = *(const bf16x8*)(p.actz + (long long)m * p.ldz + n);
+        else ext[it] = *(const bf16x8*)(p.residual + map_row(p.cmap, m) * p.ldr + n);
+      }
+    }
+  }
+  __syncthreads();     // the staged tile is complete
+#pragma unroll 1
+  for (int h = 0; h < 4; ++h)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = tid + 512 * (h * 4 + j);
+    bf16x8 ex = bf16x8{};
+    if constexpr (EXT) ex = h == 0 ? ext[j] : h == 1 ? ext[4 + j] : h == 2 ? ext[8 + j] : ext[12 + j];   // keeps the loop rolled (code size)
     const int row = c >> 5, col = (c & 31) * 8;
     const int m = m0 + row, n = n0 + col;
     if (m < p.M && n < p.N) {
@@ -98,17 +138,15 @@ __device__ __forceinline__ void finish_rows(const GemmArgs& p, const bf16* cb, i
         *(bf16x8*)(p.preact + crow * p.ldc + n) = zb;
         *(bf16x8*)cp = cvt8(apply_act<KIND == EP_ERF_PRE ? MPV_ACT_GELU_ERF : MPV_ACT_GELU_TANH>(cvt8(zb)));
       } else if constexpr (KIND == EP_BWD_ERF || KIND == EP_BWD_TANH) {
-        const f32x8 z = cvt8(*(const bf16x8*)(p.actz + (long long)m * p.ldz + n));
-        *(bf16x8*)cp = cvt8(apply_act_grad<KIND == EP_BWD_ERF ? MPV_ACT_GELU_ERF : MPV_ACT_GELU_TANH>(cvt8(zb), z));
+        *(bf16x8*)cp = cvt8(apply_act_grad<KIND == EP_BWD_ERF ? MPV_ACT_GELU_ERF : MPV_ACT_GELU_TANH>(cvt8(zb), cvt8(ex)));
       } else if constexpr (KIND == EP_RES) {
-        *(bf16x8*)cp = cvt8(cvt8(zb) + cvt8(*(const bf16x8*)(p.residual + crow * p.ldr + n)));
+        *(bf16x8*)cp = cvt8(cvt8(zb) + cvt8(ex));
       } else if constexpr (KIND == EP_DROP_RES) {
-        const f32x8 r = cvt8(*(const bf16x8*)(p.residual + crow * p.ldr + n));
         f32x8 v = cvt8(zb);
         const uint64_t base = p.drop_offset + (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = mpv_keep(p.seed, base + e, p.drop_thr) ? v[e] * p.drop_scale : 0.f;
-        *(bf16x8*)cp = cvt8(v + r);
+        *(bf16x8*)cp = cvt8(v + cvt8(ex));
       } else {
         f32x8 v = cvt8(zb);
         if (p.act) {
@@ -479,7 +517,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
           *(bf16x4*)(cb + row * CPITCH + col) = cvt4(acc[mh][nh][mb][nb] + bv);
         }
       }
-  __syncthreads();
+  // (the barrier that completes the staged tile is inside finish_rows, after its global prefetches are in flight)
   // Row-contiguous finish, specialised at compile time for the epilogue combinations the step uses (a tile is 128
   // elements per thread with the matrix pipe idle: per-element runtime switches on act / act_bwd cost more than the
   // activation itself); anything else takes the generic instance with the switches hoisted to one per 8-element chunk.

@@ -88,41 +88,92 @@ __host__ __device__ __forceinline__ bool mpv_keep(uint64_t seed, uint64_t idx, u
 }
 
 // ---------------------------------------------------------------------------------------
-// Activation math for the GEMM epilogues.  A 256x256 output tile is 128 activations per thread with the matrix pipe idle,
-// so these are built from the hardware transcendentals (v_exp_f32, v_rcp_f32: ~1 ulp) instead of the libm routines
-// (measured: erff/tanhf epilogues cost 10-20 us per tile, more than the K = 768 main loop).  Errors are far below bf16
-// resolution: erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7), tanh(u) = 1 - 2 / (e^{2u} + 1).
+// Activation math for the GEMM epilogues.  A 256x256 output tile is 128 activations per thread with the matrix pipe idle:
+// the epilogue is VALU-bound on this math (measured: libm erff/tanhf 10-20 us per tile; v_exp_f32 + v_rcp_f32 forms
+// 9-11 us, the quarter-rate transcendentals being half of it; the K = 768 main loop is 15.7 us).  Both GELU flavours are
+// therefore evaluated as x * (1/2 + S(x)) with the odd part S(x) = Phi~(x) - 1/2 a clamped odd minimax polynomial
+// x * P(x^2) on |x| <= 4 -- pure FMAs, which the compiler packs two lanes wide (v_pk_fma_f32) when handed f32x2 --
+// and likewise GELU'(x) - 1/2 = x * Q(x^2).  Fitted in tools/probe/fit_gelu_poly.py (Lawson-weighted least squares,
+// verified in fp32 Horner form): max abs error of Phi~ 2.2e-5 (erf) / 2.8e-5 (tanh), of GELU' 7.4e-5 / 1.1e-4 inside
+// the clamp, 5e-4 beyond it (the frozen tail value), all a fraction of a bf16 half-ulp (2e-3 at 1.0).
 __device__ __forceinline__ float mpv_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
-// returns erf(x / sqrt(2)) and hands back e = exp(-x^2 / 2) for the derivative
-__device__ __forceinline__ float mpv_erf_rsqrt2(float x, float& e) {
-  const float u = fabsf(x) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
-  float q = fmaf(1.061405429f, t, -1.453152027f);
-  q = fmaf(q, t, 1.421413741f);
-  q = fmaf(q, t, -0.284496736f);
-  q = fmaf(q, t, 0.254829592f);
-  e = mpv_exp(-u * u);
-  return copysignf(fmaf(-q * t, e, 1.0f), x);
-}
 __device__ __forceinline__ float mpv_tanh(float u) {
   return fmaf(-2.0f, __builtin_amdgcn_rcpf(mpv_exp(2.0f * u) + 1.0f), 1.0f);   // e^{2u} = inf -> 1, = 0 -> -1
 }
-__device__ __forceinline__ float gelu_erf_f(float x) {
-  float e;
-  return 0.5f * x * (1.0f + mpv_erf_rsqrt2(x, e));
+
+#define MPV_GELU_CLAMP 4.0f
+__device__ __forceinline__ float mpv_fma_t(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ f32x2 mpv_fma_t(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float mpv_clamp_t(float x) { return __builtin_amdgcn_fmed3f(x, -MPV_GELU_CLAMP, MPV_GELU_CLAMP); }
+__device__ __forceinline__ f32x2 mpv_clamp_t(f32x2 x) { return f32x2{mpv_clamp_t(x[0]), mpv_clamp_t(x[1])}; }
+template <typename T>
+__device__ __forceinline__ T mpv_splat(float v);
+template <>
+__device__ __forceinline__ float mpv_splat<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ f32x2 mpv_splat<f32x2>(float v) { return f32x2{v, v}; }
+
+// P(w) of S(x) = x * P(x^2): KIND 1 = erf GELU (Phi(x) - 1/2), 2 = tanh GELU (tanh(0.79788456 x (1 + 0.044715 x^2)) / 2)
+template <int KIND, typename T>
+__device__ __forceinline__ T mpv_gelu_cdf_poly(T w) {
+  if constexpr (KIND == 1) {
+    T q = mpv_fma_t(mpv_splat<T>(-1.580771181e-09f), w, mpv_splat<T>(1.217102152e-07f));
+    q = mpv_fma_t(q, w, mpv_splat<T>(-4.100845217e-06f));
+    q = mpv_fma_t(q, w, mpv_splat<T>(8.066713781e-05f));
+    q = mpv_fma_t(q, w, mpv_splat<T>(-1.048202743e-03f));
+    q = mpv_fma_t(q, w, mpv_splat<T>(9.664868936e-03f));
+    q = mpv_fma_t(q, w, mpv_splat<T>(-6.617537141e-02f));
+    return mpv_fma_t(q, w, mpv_splat<T>(3.988475204e-01f));
+  } else {
+    T q = mpv_fma_t(mpv_splat<T>(-1.796823246e-09f), w, mpv_splat<T>(1.362741813e-07f));
+    q = mpv_fma_t(q, w, mpv_splat<T>(-4.502460342e-06f));
+    q = mpv_fma_t(q, w, mpv_splat<T>(8.644891204e-05f));
+    q = mpv_fma_t(q, w, mpv_splat<T>(-1.093709492e-03f));
+    q = mpv_fma_t(q, w, mpv_splat<T>(9.846926667e-03f));
+    q = mpv_fma_t(q, w, mpv_splat<T>(-6.644576788e-02f));
+    return mpv_fma_t(q, w, mpv_splat<T>(3.988276422e-01f));
+  }
 }
-__device__ __forceinline__ float gelu_erf_grad_f(float x) {
-  float e;
-  const float cdf = 0.5f * (1.0f + mpv_erf_rsqrt2(x, e));
-  return fmaf(x * 0.3989422804014327f, e, cdf);
+// Q(w) of GELU'(x) - 1/2 = x * Q(x^2)
+template <int KIND, typename T>
+__device__ __forceinline__ T mpv_gelu_grad_poly(T w) {
+  if constexpr (KIND == 1) {
+    T q = mpv_fma_t(mpv_splat<T>(9.796049527e-10f), w, mpv_splat<T>(-8.218798797e-08f));
+    q = mpv_fma_t(q, w, mpv_splat<T>(3.028347010e-06f));
+    q = mpv_fma_t(q, w, mpv_splat<T>(-6.495756679e-05f));
+    q = mpv_fma_t(q, w, mpv_splat<T>(9.073265246e-04f));
+    q = mpv_fma_t(q, w, mpv_splat<T>(-8.716319688e-03f));
+    q = mpv_fma_t(q, w, mpv_splat<T>(5.845610052e-02f));
+    q = mpv_fma_t(q, w, mpv_splat<T>(-2.648265362e-01f));
+    return mpv_fma_t(q, w, mpv_splat<T>(7.976095676e-01f));
+  } else {
+    T q = mpv_fma_t(mpv_splat<T>(1.172013597e-09f), w, mpv_splat<T>(-9.666642597e-08f));
+    q = mpv_fma_t(q, w, mpv_splat<T>(3.483976570e-06f));
+    q = mpv_fma_t(q, w, mpv_splat<T>(-7.268741319e-05f));
+    q = mpv_fma_t(q, w, mpv_splat<T>(9.829062037e-04f));
+    q = mpv_fma_t(q, w, mpv_splat<T>(-9.133556858e-03f));
+    q = mpv_fma_t(q, w, mpv_splat<T>(5.960476771e-02f));
+    q = mpv_fma_t(q, w, mpv_splat<T>(-2.658853233e-01f));
+    return mpv_fma_t(q, w, mpv_splat<T>(7.975339890e-01f));
+  }
 }
-__device__ __forceinline__ float gelu_tanh_f(float x) {
-  return 0.5f * x * (1.0f + mpv_tanh(0.79788456f * x * fmaf(0.044715f * x, x, 1.0f)));
+// GELU(x) = x * (1/2 + xc * P(xc^2)), xc = clamp(x)
+template <int KIND, typename T>
+__device__ __forceinline__ T mpv_gelu_t(T x) {
+  const T xc = mpv_clamp_t(x);
+  const T s = xc * mpv_gelu_cdf_poly<KIND>(xc * xc);
+  return mpv_fma_t(x, s, x * mpv_splat<T>(0.5f));
 }
-__device__ __forceinline__ float gelu_tanh_grad_f(float x) {
-  const float t = mpv_tanh(0.79788456f * x * fmaf(0.044715f * x, x, 1.0f));
-  return 0.5f * x * ((1.0f - t * t) * fmaf(0.1070322243f * x, x, 0.79788456f)) + 0.5f * (1.0f + t);
+// dy * GELU'(x) = dy * (1/2 + xc * Q(xc^2))
+template <int KIND, typename T>
+__device__ __forceinline__ T mpv_gelu_grad_mul_t(T dy, T x) {
+  const T xc = mpv_clamp_t(x);
+  return mpv_fma_t(dy * xc, mpv_gelu_grad_poly<KIND>(xc * xc), dy * mpv_splat<T>(0.5f));
 }
+__device__ __forceinline__ float gelu_erf_f(float x) { return mpv_gelu_t<1>(x); }
+__device__ __forceinline__ float gelu_erf_grad_f(float x) { return mpv_gelu_grad_mul_t<1>(1.0f, x); }
+__device__ __forceinline__ float gelu_tanh_f(float x) { return mpv_gelu_t<2>(x); }
+__device__ __forceinline__ float gelu_tanh_grad_f(float x) { return mpv_gelu_grad_mul_t<2>(1.0f, x); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
