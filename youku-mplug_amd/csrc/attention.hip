@@ -672,7 +672,10 @@ __device__ __forceinline__ void dma_rows(const __amdgpu_buffer_rsrc_t src, char*
 // bytes of one LDS region of `rows` rows padded to whole tiles (device twin of the host's res_region)
 __device__ __forceinline__ int region_bytes(int rows, int pitch) { return (((rows + 31) / 32 * 32) * pitch + 1023) / 1024 * 1024; }
 
-template <int HD>
+// NTC > 0: non-causal with exactly NTC key tiles for every wave, known at compile time -- the tile loops become
+// straight-line code (no per-tile branch), so the scheduler can hoist the next tile's LDS reads and MFMA chain above the
+// current tile's VALU work.  NTC == 0: tile count per wave decided at run time (causal, other lengths).
+template <int HD, int NTC = 0>
 __global__ __launch_bounds__(512) void attn_fwd_res_kernel(const AttnArgs p) {
   constexpr int NS = HD / 16;
   constexpr int NDT = (HD + 31) / 32;
@@ -704,97 +707,82 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(const AttnArgs p) {
   const int my_last = last_visible_key(p, qrow);
   const int wave_last = last_visible_key(p, min(p.sq - 1, q0 + 31));
   const int wave_first_last = last_visible_key(p, q0);      // tiles entirely <= this need no masking
-  const int nt = wave_last / 32 + 1;
+  const int nt = NTC ? NTC : wave_last / 32 + 1;
   const float c2 = sc * 1.4426950408889634f;               // work in the exp2 domain: p = 2^(s*c2 - m)
   const lds_char* sm = (const lds_char*)rsm;
   const int kbase = (int)(kl - rsm) + rows_lane_base<ROWB>(lane), vbase = cols_lane_base<ROWB>(lane);
-  float m = -INFINITY, l = 0.f;
-  for (int kt = 0; kt < nt; ++kt) {
-    f32x16 s;
+  // One QK^T pass: all (<= 8) 32-key score tiles of the wave's 32 queries stay in registers (128 VGPRs), so the row
+  // maximum is exact before the first exponential, every exponential is evaluated once, and K is read from LDS once
+  // (the earlier form ran QK^T twice: once for the statistics, once for the probabilities).  Probabilities go to the
+  // PV MFMAs unnormalised (<= 1, bf16); 1/l is applied to the 32 x hd output instead of the 32 x sk scores.
+  constexpr int NTM = NTC ? NTC : 8;
+  f32x16 st[NTM];
+  float mx = -INFINITY;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) s[e] = 0.f;
-{   // two interleaved partial sums: a 6-deep dependent MFMA chain waits on its own latency
-  f32x16 s_odd;
+  for (int kt = 0; kt < NTM; ++kt) {
+    if (NTC || kt < nt) {
+      f32x16 s, s_odd;      // two interleaved partial sums: a 6-deep dependent MFMA chain waits on its own latency
 #pragma unroll
-  for (int e = 0; e < 16; ++e) s_odd[e] = 0.f;
+      for (int e = 0; e < 16; ++e) s[e] = s_odd[e] = 0.f;
 #pragma unroll
-  for (int st = 0; st < NS; ++st) {
-    if (st & 1) s_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, kbase + kt * 32 * ROWB, st), qf[st], s_odd, 0, 0, 0);
-    else s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, kbase + kt * 32 * ROWB, st), qf[st], s, 0, 0, 0);
-  }
-  s += s_odd;
-}
-    float mx = -INFINITY;
-    if (kt * 32 + 31 <= wave_first_last) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        s[e] *= c2;
-        mx = fmaxf(mx, s[e]);
+      for (int sx = 0; sx < NS; ++sx) {
+        if (sx & 1) s_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, kbase + kt * 32 * ROWB, sx), qf[sx], s_odd, 0, 0, 0);
+        else s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, kbase + kt * 32 * ROWB, sx), qf[sx], s, 0, 0, 0);
       }
-    } else {
+      s += s_odd;
+      if (NTC ? kt == NTC - 1 : kt * 32 + 31 > wave_first_last) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int key = kt * 32 + acc_row(e, lane);
-        s[e] = key <= my_last ? s[e] * c2 : -INFINITY;
-        mx = fmaxf(mx, s[e]);
+        for (int e = 0; e < 16; ++e) s[e] = kt * 32 + acc_row(e, lane) <= my_last ? s[e] : -INFINITY;
       }
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mn = fmaxf(m, mx);
-    if (mn > -INFINITY) {
-      float sum = 0.f;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) sum += fexp2(s[e] - mn);
-      sum += __shfl_xor(sum, 32, 64);
-      l = l * fexp2(m - mn) + sum;
-      m = mn;
+      for (int e = 0; e < 16; e += 2) mx = fmaxf(fmaxf(mx, s[e]), s[e + 1]);      // v_max3_f32
+      st[kt] = s;
     }
   }
-  const float inv_l = l > 0.f ? 1.0f / l : 0.f;
-  if (qrow < p.sq && lane < 32 && p.lse) p.lse[(long long)bh * p.sq + qrow] = (m + log2f(l)) * 0.6931471805599453f;
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float m = mx > -INFINITY ? mx * c2 : 0.f;          // c2 > 0 (checked on the host): max(s * c2) = c2 * max(s)
+  float l = 0.f;
   f32x16 oacc[NDT];
 #pragma unroll
   for (int d = 0; d < NDT; ++d)
 #pragma unroll
     for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
-  for (int kt = 0; kt < nt; ++kt) {
-    f32x16 s;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) s[e] = 0.f;
-{   // two interleaved partial sums: a 6-deep dependent MFMA chain waits on its own latency
-  f32x16 s_odd;
+  for (int kt = 0; kt < NTM; ++kt) {
+    if (NTC || kt < nt) {
+      f32x16 pr;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) s_odd[e] = 0.f;
+      for (int e = 0; e < 16; e += 2) {        // pairs: v_pk_fma_f32; masked scores are -inf -> 2^-inf = 0
+        const f32x2 t = __builtin_elementwise_fma(f32x2{st[kt][e], st[kt][e + 1]}, f32x2{c2, c2}, f32x2{-m, -m});
+        pr[e] = fexp2(t[0]);
+        pr[e + 1] = fexp2(t[1]);
+      }
+      {
+        f32x2 a2 = {0.f, 0.f};
 #pragma unroll
-  for (int st = 0; st < NS; ++st) {
-    if (st & 1) s_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, kbase + kt * 32 * ROWB, st), qf[st], s_odd, 0, 0, 0);
-    else s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, kbase + kt * 32 * ROWB, st), qf[st], s, 0, 0, 0);
-  }
-  s += s_odd;
-}
-    if (kt * 32 + 31 <= wave_first_last && !p.drop_thr) {
+        for (int e = 0; e < 16; e += 2) a2 += f32x2{pr[e], pr[e + 1]};
+        l += a2[0] + a2[1];
+      }
+      if (NTC == 0 && p.drop_thr) {      // (the NTC instances are launched without dropout)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) s[e] = fexp2(s[e] * c2 - m) * inv_l;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int key = kt * 32 + acc_row(e, lane);
-        float pr = key <= my_last ? fexp2(s[e] * c2 - m) * inv_l : 0.f;
-        if (p.drop_thr) {
+        for (int e = 0; e < 16; ++e) {
+          const int key = kt * 32 + acc_row(e, lane);
           const uint64_t idx = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qrow) * (uint64_t)p.sk + (uint64_t)key;
-          pr = mpv_keep(p.seed, idx, p.drop_thr) ? pr * p.drop_scale : 0.f;
+          pr[e] = mpv_keep(p.seed, idx, p.drop_thr) ? pr[e] * p.drop_scale : 0.f;
         }
-        s[e] = pr;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 pf = acc_to_frag(pr, ks);
+#pragma unroll
+        for (int d = 0; d < NDT; ++d)
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_f<ROWB>(sm, vbase + kt * 32 * ROWB, ks, d), pf, oacc[d], 0, 0, 0);
       }
     }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8 pf = acc_to_frag(s, ks);
-#pragma unroll
-      for (int d = 0; d < NDT; ++d)
-        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_f<ROWB>(sm, vbase + kt * 32 * ROWB, ks, d), pf, oacc[d], 0, 0, 0);
-    }
   }
+  l += __shfl_xor(l, 32, 64);
+  const float inv_l = l > 0.f ? 1.0f / l : 0.f;
+  if (qrow < p.sq && lane < 32 && p.lse) p.lse[(long long)bh * p.sq + qrow] = (m + log2f(l)) * 0.6931471805599453f;
   if (qrow < p.sq) {
     bf16* orow = p.o + b * p.o_bs + h * p.o_hs + (long long)qrow * p.o_rs;
 #pragma unroll
@@ -805,7 +793,7 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(const AttnArgs p) {
         if (col < p.hd) {
           f32x4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = oacc[d][4 * q4 + e];
+          for (int e = 0; e < 4; ++e) v[e] = oacc[d][4 * q4 + e] * inv_l;
           *(bf16x4*)(orow + col) = cvt4(v);
         }
       }
@@ -940,12 +928,17 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_dkv_res_kernel(const AttnArg
   // (hardware returns 0 for out-of-range LDS reads); the fp32 stats sit in front so no bf16 fragment read
   // can ever interpret them as (possibly Inf/NaN) bf16.
   float* sl = (float*)rsm;                                                  // [lse*log2e | delta] x qrows
-  char* dl = rsm + ((2 * qrows * 4 + 1023) / 1024) * 1024;                  // dO [sq][208 B]
+  char* vl = rsm + ((2 * qrows * 4 + 1023) / 1024) * 1024;                  // V  [sk][208 B] (head_dim > 64 only: zero bytes otherwise)
+  char* dl = vl + (HD > 64 ? region_bytes(p.sk, ROWB) : 0);                  // dO [sq][208 B]
   char* ql = dl + region_bytes(p.sq, ROWB);                                  // Q  [sq][208 B]
   const __amdgpu_buffer_rsrc_t qsrc = make_rsrc(p.q + b * p.q_bs + h * p.q_hs, (uint32_t)(((long long)(p.sq - 1) * p.q_rs + p.hd) * 2));
   const __amdgpu_buffer_rsrc_t dosrc = make_rsrc(p.dO + b * p.o_bs + h * p.o_hs, (uint32_t)(((long long)(p.sq - 1) * p.o_rs + p.hd) * 2));
   dma_rows<HD, ROWB>(qsrc, ql, p.sq, p.q_rs, wave, nwaves, lane, p.hd);
   dma_rows<HD, ROWB>(dosrc, dl, p.sq, p.o_rs, wave, nwaves, lane, p.hd);
+  if constexpr (HD > 64) {
+    const __amdgpu_buffer_rsrc_t vsrc = make_rsrc(p.v + b * p.v_bs + h * p.v_hs, (uint32_t)(((long long)(p.sk - 1) * p.v_rs + p.hd) * 2));
+    dma_rows<HD, ROWB>(vsrc, vl, p.sk, p.v_rs, wave, nwaves, lane, p.hd);
+  }
   for (int r = tid; r < qrows; r += blockDim.x) {   // lse pre-multiplied by log2(e): probabilities are 2^(s*c2 - lse2)
     sl[r] = r < p.sq ? p.lse[(long long)bh * p.sq + r] * 1.4426950408889634f : 1e30f;
     sl[qrows + r] = r < p.sq ? p.delta[(long long)bh * p.sq + r] : 0.f;
@@ -975,15 +968,9 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_dkv_res_kernel(const AttnArg
   ASTAMP(3);
   if (k0 >= p.sk) return;
   const int first_q = p.causal ? max(0, k0 - (p.sk - p.sq)) : 0;
-  // Two passes over the q-tiles, dV first and dK second, each with ONE 32 x HD accumulator set: holding both sets plus
-  // K, V, S, dP fragments needs ~330 VGPRs (one wave per SIMD, or scratch traffic inside the loop when capped at 256:
-  // measured 5k clocks per q-tile).  The second pass recomputes S = Q K^T (+25% MFMAs) and the probabilities; both
-  // passes draw identical dropout masks (pure function of the element index).
   const lds_char* sm = (const lds_char*)rsm;
   const int qroff = (int)(ql - rsm) + rows_lane_base<ROWB>(lane), droff = (int)(dl - rsm) + rows_lane_base<ROWB>(lane);
   const int qcoff = (int)(ql - rsm) + cols_lane_base<ROWB>(lane), dcoff = (int)(dl - rsm) + cols_lane_base<ROWB>(lane);
-  bf16* dkrow = p.dk + b * p.k_bs + h * p.k_hs + (long long)krow * p.k_rs;
-  bf16* dvrow = p.dv + b * p.v_bs + h * p.v_hs + (long long)krow * p.v_rs;
   auto store_rows = [&](const f32x16 (&acc)[NDT], bf16* row, float mul) {
     if (kok) {
 #pragma unroll
@@ -1000,185 +987,83 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_dkv_res_kernel(const AttnArg
         }
     }
   };
-  // probability (and, in the dK pass, dS) of one 32 x 32 tile, in place: s -> P (WANT_DS = false) or dS (true)
-  auto softmax_bwd_tile = [&](auto WANT_DS, int qt, f32x16& s, const f32x16& dp) {
-    constexpr bool want_ds = decltype(WANT_DS)::value;
-    // a q-tile is "interior" for this wave when every (q,key) pair is visible and in range
+  // One pass over the q-tiles, S, P, dP and dS computed once, both 32 x HD accumulator sets live.  head_dim <= 64 keeps
+  // the wave's K and V fragments in registers; above that the V fragments (24 more VGPRs at 96) are read from a third LDS
+  // region instead -- with them in registers the kernel needs ~290 VGPRs and the allocator parks fragments in scratch
+  // inside the loop (measured 5k clocks per q-tile); the earlier answer, two passes with one accumulator set each,
+  // recomputed S and the exponentials (+25% MFMAs, 2x exp, +33% LDS reads).
+  constexpr bool V_LDS = HD > 64;
+  bf16x8 vf[V_LDS ? 1 : NS];
+  if constexpr (!V_LDS) load_row_frags<HD>(vf, p.v + b * p.v_bs + h * p.v_hs, p.v_rs, krow, p.sk, lane, p.hd);
+  const int vfoff = (int)(vl - rsm) + rows_lane_base<ROWB>(lane) + k0 * ROWB;
+  f32x16 dkacc[NDT], dvacc[NDT];
+#pragma unroll
+  for (int d = 0; d < NDT; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dkacc[d][e] = dvacc[d][e] = 0.f;
+  for (int qt = first_q / 32; qt < qtiles; ++qt) {
+    f32x16 s, dp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
+    int vo = vfoff;
+    asm volatile("" : "+v"(vo));      // opaque per iteration: otherwise the loop-invariant V fragment reads are hoisted back into registers
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, qroff + qt * 32 * ROWB, st), kf[st], s, 0, 0, 0);
+      if constexpr (V_LDS) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, droff + qt * 32 * ROWB, st), frag_rows_f(sm, vo, st), dp, 0, 0, 0);
+      else dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, droff + qt * 32 * ROWB, st), vf[st], dp, 0, 0, 0);
+    }
+    // P and dS in one sweep (one exponential and one dropout draw per element), half a tile at a time: accumulator
+    // registers 8*ks .. 8*ks+7 are exactly the B operand of reduction step ks, so P never exists as a whole fp32 tile.
+    // A q-tile is "interior" for this wave when every (q,key) pair is visible and in range.
     const bool interior = !p.drop_thr && (k0 + 31 < p.sk) && (qt * 32 + 31 < p.sq) &&
                           (!p.causal || (k0 + 31 <= qt * 32 + (p.sk - p.sq)));
 #pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) {
-      const int qb4 = qt * 32 + 8 * q4 + 4 * (lane >> 5);
-      const f32x4 l4 = *(const f32x4*)(sl + qb4);
-      f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
-      if constexpr (want_ds) d4 = *(const f32x4*)(sl + qrows + qb4);
-      if (interior) {
+    for (int ks = 0; ks < 2; ++ks) {
+      f32x8 pr8, ds8;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int e = 4 * q4 + j;
-          const float pr = fexp2(s[e] * c2 - l4[j]);
-          s[e] = want_ds ? pr * (dp[e] - d4[j]) : pr;
-        }
-      } else {
+      for (int qh = 0; qh < 2; ++qh) {
+        const int q4 = 2 * ks + qh;
+        const int qb4 = qt * 32 + 8 * q4 + 4 * (lane >> 5);
+        const f32x4 l4 = *(const f32x4*)(sl + qb4), d4 = *(const f32x4*)(sl + qrows + qb4);
+        if (interior) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int e = 4 * q4 + j;
-          const int qr = qb4 + j;
-          const int lastk = p.causal ? qr + (p.sk - p.sq) : p.sk - 1;
-          const bool vis = kok && krow <= lastk && qr < p.sq;
-          const float pr = vis ? fexp2(s[e] * c2 - l4[j]) : 0.f;
-          float keep = 1.0f;
-          if (p.drop_thr) {
-            const uint64_t idx = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qr) * (uint64_t)p.sk + (uint64_t)krow;
-            keep = mpv_keep(p.seed, idx, p.drop_thr) ? p.drop_scale : 0.f;
+          for (int j = 0; j < 4; ++j) {
+            const int e = 4 * q4 + j;
+            const float pr = fexp2(s[e] * c2 - l4[j]);
+            pr8[4 * qh + j] = pr;
+            ds8[4 * qh + j] = pr * (dp[e] - d4[j]);
           }
-          if constexpr (want_ds) s[e] = vis ? pr * (dp[e] * keep - d4[j]) : 0.f;
-          else s[e] = vis ? pr * keep : 0.f;
-        }
-      }
-    }
-  };
-  if constexpr (HD <= 64) {
-    // head_dim 64 (GPT): one pass, S and P computed once
-    bf16x8 vf[NS];
-    load_row_frags<HD>(vf, p.v + b * p.v_bs + h * p.v_hs, p.v_rs, krow, p.sk, lane, p.hd);
-    f32x16 dkacc[NDT], dvacc[NDT];
+        } else {
 #pragma unroll
-    for (int d = 0; d < NDT; ++d)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) dkacc[d][e] = dvacc[d][e] = 0.f;
-    for (int qt = first_q / 32; qt < qtiles; ++qt) {
-      f32x16 s, dp, pd;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
-#pragma unroll
-      for (int st = 0; st < NS; ++st) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, qroff + qt * 32 * ROWB, st), kf[st], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, droff + qt * 32 * ROWB, st), vf[st], dp, 0, 0, 0);
-      }
-      {   // P -> pd and dS -> s in one sweep (one exponential and one dropout draw per element)
-        const bool interior = !p.drop_thr && (k0 + 31 < p.sk) && (qt * 32 + 31 < p.sq) &&
-                              (!p.causal || (k0 + 31 <= qt * 32 + (p.sk - p.sq)));
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          const int qb4 = qt * 32 + 8 * q4 + 4 * (lane >> 5);
-          const f32x4 l4 = *(const f32x4*)(sl + qb4), d4 = *(const f32x4*)(sl + qrows + qb4);
-          if (interior) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int e = 4 * q4 + j;
-              const float pr = fexp2(s[e] * c2 - l4[j]);
-              pd[e] = pr;
-              s[e] = pr * (dp[e] - d4[j]);
+          for (int j = 0; j < 4; ++j) {
+            const int e = 4 * q4 + j;
+            const int qr = qb4 + j;
+            const int lastk = p.causal ? qr + (p.sk - p.sq) : p.sk - 1;
+            const bool vis = kok && krow <= lastk && qr < p.sq;
+            const float pr = vis ? fexp2(s[e] * c2 - l4[j]) : 0.f;
+            float keep = 1.0f;
+            if (p.drop_thr) {
+              const uint64_t idx = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qr) * (uint64_t)p.sk + (uint64_t)krow;
+              keep = mpv_keep(p.seed, idx, p.drop_thr) ? p.drop_scale : 0.f;
             }
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int e = 4 * q4 + j;
-              const int qr = qb4 + j;
-              const int lastk = p.causal ? qr + (p.sk - p.sq) : p.sk - 1;
-              const bool vis = kok && krow <= lastk && qr < p.sq;
-              const float pr = vis ? fexp2(s[e] * c2 - l4[j]) : 0.f;
-              float keep = 1.0f;
-              if (p.drop_thr) {
-                const uint64_t idx = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qr) * (uint64_t)p.sk + (uint64_t)krow;
-                keep = mpv_keep(p.seed, idx, p.drop_thr) ? p.drop_scale : 0.f;
-              }
-              pd[e] = vis ? pr * keep : 0.f;
-              s[e] = vis ? pr * (dp[e] * keep - d4[j]) : 0.f;
-            }
+            pr8[4 * qh + j] = vis ? pr * keep : 0.f;
+            ds8[4 * qh + j] = vis ? pr * (dp[e] * keep - d4[j]) : 0.f;
           }
         }
       }
+      const bf16x8 pf = cvt8(pr8), dsf = cvt8(ds8);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 pf = acc_to_frag(pd, ks);
-        const bf16x8 dsf = acc_to_frag(s, ks);
-#pragma unroll
-        for (int d = 0; d < NDT; ++d) {
-          dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_f<ROWB>(sm, dcoff + qt * 32 * ROWB, ks, d), pf, dvacc[d], 0, 0, 0);
-          dkacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_f<ROWB>(sm, qcoff + qt * 32 * ROWB, ks, d), dsf, dkacc[d], 0, 0, 0);
-        }
+      for (int d = 0; d < NDT; ++d) {
+        dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_f<ROWB>(sm, dcoff + qt * 32 * ROWB, ks, d), pf, dvacc[d], 0, 0, 0);
+        dkacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_f<ROWB>(sm, qcoff + qt * 32 * ROWB, ks, d), dsf, dkacc[d], 0, 0, 0);
       }
-    }
-    ASTAMP(4);
-    store_rows(dvacc, dvrow, 1.0f);
-    store_rows(dkacc, dkrow, sc);
-  } else {
-    {   // ---- pass 1: dV = P^T dO
-      f32x16 acc[NDT];
-  #pragma unroll
-      for (int d = 0; d < NDT; ++d)
-  #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[d][e] = 0.f;
-      for (int qt = first_q / 32; qt < qtiles; ++qt) {
-        f32x16 s;
-  #pragma unroll
-        for (int e = 0; e < 16; ++e) s[e] = 0.f;
-  {   // two interleaved partial sums: a 6-deep dependent MFMA chain waits on its own latency
-    f32x16 s_odd;
-  #pragma unroll
-    for (int e = 0; e < 16; ++e) s_odd[e] = 0.f;
-  #pragma unroll
-    for (int st = 0; st < NS; ++st) {
-      if (st & 1) s_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, qroff + qt * 32 * ROWB, st), kf[st], s_odd, 0, 0, 0);
-      else s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, qroff + qt * 32 * ROWB, st), kf[st], s, 0, 0, 0);
-    }
-    s += s_odd;
-  }
-        softmax_bwd_tile(std::false_type{}, qt, s, s);
-  #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const bf16x8 pf = acc_to_frag(s, ks);
-  #pragma unroll
-          for (int d = 0; d < NDT; ++d)
-            acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_f<ROWB>(sm, dcoff + qt * 32 * ROWB, ks, d), pf, acc[d], 0, 0, 0);
-        }
-      }
-      store_rows(acc, dvrow, 1.0f);
-    }
-    {   // ---- pass 2: dK = scale * dS^T Q
-      bf16x8 vf[NS];
-      load_row_frags<HD>(vf, p.v + b * p.v_bs + h * p.v_hs, p.v_rs, krow, p.sk, lane, p.hd);
-      f32x16 acc[NDT];
-  #pragma unroll
-      for (int d = 0; d < NDT; ++d)
-  #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[d][e] = 0.f;
-      for (int qt = first_q / 32; qt < qtiles; ++qt) {
-        f32x16 s, dp;
-  #pragma unroll
-        for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
-  {   // four interleaved partial sums (see above)
-    f32x16 s_odd, dp_odd;
-  #pragma unroll
-    for (int e = 0; e < 16; ++e) s_odd[e] = dp_odd[e] = 0.f;
-  #pragma unroll
-    for (int st = 0; st < NS; ++st) {
-      if (st & 1) {
-        s_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, qroff + qt * 32 * ROWB, st), kf[st], s_odd, 0, 0, 0);
-        dp_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, droff + qt * 32 * ROWB, st), vf[st], dp_odd, 0, 0, 0);
-      } else {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, qroff + qt * 32 * ROWB, st), kf[st], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, droff + qt * 32 * ROWB, st), vf[st], dp, 0, 0, 0);
-      }
-    }
-    s += s_odd;
-    dp += dp_odd;
-  }
-        softmax_bwd_tile(std::true_type{}, qt, s, dp);
-  #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const bf16x8 dsf = acc_to_frag(s, ks);
-  #pragma unroll
-          for (int d = 0; d < NDT; ++d)
-            acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_f<ROWB>(sm, qcoff + qt * 32 * ROWB, ks, d), dsf, acc[d], 0, 0, 0);
-        }
-      }
-      ASTAMP(4);
-      store_rows(acc, dkrow, sc);
     }
   }
+  ASTAMP(4);
+  // (row pointers formed only now: as loop-carried live values they were the first thing the allocator spilled)
+  store_rows(dvacc, p.dv + b * p.v_bs + h * p.v_hs + (long long)krow * p.v_rs, 1.0f);
+  store_rows(dkacc, p.dk + b * p.k_bs + h * p.k_hs + (long long)krow * p.k_rs, sc);
   ASTAMP(5);
 }
 
@@ -1424,6 +1309,7 @@ int check_desc(const mpv_attn_desc* d, const char* who) {
   MPV_REQUIRE((((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v) & 15) == 0 && ((uintptr_t)d->o & 7) == 0, MPV_E_ALIGN,
               "%s: q/k/v must be 16-byte aligned", who);
   MPV_REQUIRE(d->dropout_p >= 0.f && d->dropout_p < 1.f, MPV_E_ARG, "%s: bad dropout_p", who);
+  MPV_REQUIRE(d->scale > 0.f, MPV_E_ARG, "%s: scale must be positive (the row maximum is taken before scaling)", who);
   MPV_REQUIRE(!d->causal || d->sk >= d->sq, MPV_E_SHAPE, "%s: causal needs sk >= sq", who);
   return MPV_OK;
 }
@@ -1444,7 +1330,7 @@ static void allow_lds(K kernel) {
 static void res_attr_once() {
   static bool done = false;
   if (done) return;
-  allow_lds(attn_fwd_res_kernel<64>); allow_lds(attn_fwd_res_kernel<80>); allow_lds(attn_fwd_res_kernel<96>);
+  allow_lds(attn_fwd_res_kernel<64>); allow_lds(attn_fwd_res_kernel<80>); allow_lds(attn_fwd_res_kernel<96>); allow_lds(attn_fwd_res_kernel<96, 7>);
   allow_lds(attn_bwd_dq_res_kernel<64>); allow_lds(attn_bwd_dq_res_kernel<80>); allow_lds(attn_bwd_dq_res_kernel<96>);
   allow_lds(attn_bwd_dkv_res_kernel<64, 512>); allow_lds(attn_bwd_dkv_res_kernel<80, 512>); allow_lds(attn_bwd_dkv_res_kernel<96, 512>);
   done = true;
@@ -1470,7 +1356,10 @@ extern "C" int mpv_attn_fwd(const mpv_attn_desc* d, hipStream_t stream) {
     switch (d->head_dim <= 64 ? 64 : d->head_dim <= 80 ? 80 : 96) {
       case 64: hipLaunchKernelGGL((attn_fwd_res_kernel<64>), grid, block, lds, stream, a); break;
       case 80: hipLaunchKernelGGL((attn_fwd_res_kernel<80>), grid, block, lds, stream, a); break;
-      default: hipLaunchKernelGGL((attn_fwd_res_kernel<96>), grid, block, lds, stream, a); break;
+      default:
+        if (!d->causal && d->dropout_p == 0.f && (d->sk + 31) / 32 == 7) hipLaunchKernelGGL((attn_fwd_res_kernel<96, 7>), grid, block, lds, stream, a);   // ViT-B/16 spatial: 197 keys
+        else hipLaunchKernelGGL((attn_fwd_res_kernel<96>), grid, block, lds, stream, a);
+        break;
     }
     return mpv_check_launch("mpv_attn_fwd");
   }
@@ -1503,7 +1392,7 @@ extern "C" int mpv_attn_bwd(const mpv_attn_desc* d, const void* dO, void* dq, vo
     const int gy = (d->batch + 7) / 8 * 8 * d->heads;
     const int nwk = waves_for(d->sk);
     dim3 gq((d->sq + 32 * nw - 1) / (32 * nw), gy), gk((d->sk + 32 * nwk - 1) / (32 * nwk), gy);
-    const size_t lq = res_lds_bytes(d->sk, false), lk = res_lds_bytes(d->sq, true);
+    const size_t lq = res_lds_bytes(d->sk, false), lk = res_lds_bytes(d->sq, true) + (d->head_dim > 64 ? res_region(d->sk, ROWB) : 0);
     switch (d->head_dim <= 64 ? 64 : d->head_dim <= 80 ? 80 : 96) {
       case 64:
         hipLaunchKernelGGL((attn_bwd_dq_res_kernel<64>), gq, dim3(64 * nw), lq, stream, a);

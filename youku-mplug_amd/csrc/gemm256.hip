@@ -99,26 +99,33 @@ __device__ __forceinline__ f32x8 apply_act_grad(f32x8 v, f32x8 z) {
 
 // second half of the epilogue: the staged bf16 tile (acc * alpha + bias, pitch CPITCH) -> global, 8 columns per thread.
 // Everything the finish reads from global memory (GELU' pre-activation, residual) is fetched for all 16 chunks of the
-// thread BEFORE the staging barrier: interleaved with the stores each load sat behind `s_waitcnt vmcnt(0)` (stores
+// thread right after the main loop, before the accumulators are staged: interleaved with the stores each load sat behind `s_waitcnt vmcnt(0)` (stores
 // count in vmcnt, and the compiler cannot prove C does not alias z / the residual), 16 serial round trips = 14 us per
-// tile at K = 768; up front they cost one latency, hidden behind the barrier.
+// tile at K = 768; up front they cost one latency, hidden behind the staging pass and its barrier.
 template <int KIND>
-__device__ __forceinline__ void finish_rows(const GemmArgs& p, const bf16* cb, int tid, int m0, int n0) {
-  constexpr bool EXT = KIND == EP_BWD_ERF || KIND == EP_BWD_TANH || KIND == EP_RES || KIND == EP_DROP_RES;
-  bf16x8 ext[EXT ? 16 : 1];
-  if constexpr (EXT) {
+struct EpExt {
+  static constexpr bool EXT = KIND == EP_BWD_ERF || KIND == EP_BWD_TANH || KIND == EP_RES || KIND == EP_DROP_RES;
+  bf16x8 v[EXT ? 16 : 1];
+};
+template <int KIND>
+__device__ __forceinline__ void prefetch_rows(const GemmArgs& p, EpExt<KIND>& x, int tid, int m0, int n0) {
+  if constexpr (EpExt<KIND>::EXT) {
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
       const int c = tid + 512 * it;
       const int m = m0 + (c >> 5), n = n0 + (c & 31) * 8;
-      ext[it] = bf16x8{};
+      x.v[it] = bf16x8{};
       if (m < p.M && n < p.N) {
-        if constexpr (KIND == EP_BWD_ERF || KIND == EP_BWD_TANH) ext[it] = *(const bf16x8*)(p.actz + (long long)m * p.ldz + n);
-        else ext[it] = *(const bf16x8*)(p.residual + map_row(p.cmap, m) * p.ldr + n);
+        if constexpr (KIND == EP_BWD_ERF || KIND == EP_BWD_TANH) x.v[it] = *(const bf16x8*)(p.actz + (long long)m * p.ldz + n);
+        else x.v[it] = *(const bf16x8*)(p.residual + map_row(p.cmap, m) * p.ldr + n);
       }
     }
   }
-  __syncthreads();     // the staged tile is complete
+}
+template <int KIND>
+__device__ __forceinline__ void finish_rows(const GemmArgs& p, const EpExt<KIND>& x, const bf16* cb, int tid, int m0, int n0) {
+  constexpr bool EXT = EpExt<KIND>::EXT;
+  const bf16x8* ext = x.v;
 #pragma unroll 1
   for (int h = 0; h < 4; ++h)
 #pragma unroll
@@ -501,36 +508,42 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     return;
   }
 
-  bf16* cb = (bf16*)smem;
-#pragma unroll
-  for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-    for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb) {
-        const int col = wc * 64 + nh * 32 + nb * 16 + lg * 4;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias && n0 + col < p.N) bv = cvt4(*(const bf16x4*)(p.bias + n0 + col));
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-          const int row = wr * 128 + mh * 64 + mb * 16 + l15;
-          *(bf16x4*)(cb + row * CPITCH + col) = cvt4(acc[mh][nh][mb][nb] + bv);
-        }
-      }
-  // (the barrier that completes the staged tile is inside finish_rows, after its global prefetches are in flight)
   // Row-contiguous finish, specialised at compile time for the epilogue combinations the step uses (a tile is 128
   // elements per thread with the matrix pipe idle: per-element runtime switches on act / act_bwd cost more than the
   // activation itself); anything else takes the generic instance with the switches hoisted to one per 8-element chunk.
+  auto epilogue = [&](auto kind) {
+    constexpr int KIND = decltype(kind)::value;
+    EpExt<KIND> ext;
+    prefetch_rows<KIND>(p, ext, tid, m0, n0);      // global reads of the finish go out first
+    bf16* cb = (bf16*)smem;
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const int col = wc * 64 + nh * 32 + nb * 16 + lg * 4;
+          f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+          if (p.bias && n0 + col < p.N) bv = cvt4(*(const bf16x4*)(p.bias + n0 + col));
+#pragma unroll
+          for (int mb = 0; mb < 4; ++mb) {
+            const int row = wr * 128 + mh * 64 + mb * 16 + l15;
+            *(bf16x4*)(cb + row * CPITCH + col) = cvt4(acc[mh][nh][mb][nb] + bv);
+          }
+        }
+    __syncthreads();     // the staged tile is complete
+    finish_rows<KIND>(p, ext, cb, tid, m0, n0);
+  };
   const int cfg = (p.act ? 1 : 0) | (p.act_bwd ? 2 : 0) | (p.drop_thr ? 4 : 0) | (p.residual ? 8 : 0) | (p.accumulate ? 16 : 0) |
                   (p.preact ? 32 : 0);
-  if (cfg == 0) finish_rows<EP_PLAIN>(p, cb, tid, m0, n0);
-  else if (cfg == (1 | 32) && p.act == MPV_ACT_GELU_ERF) finish_rows<EP_ERF_PRE>(p, cb, tid, m0, n0);
-  else if (cfg == (1 | 32) && p.act == MPV_ACT_GELU_TANH) finish_rows<EP_TANH_PRE>(p, cb, tid, m0, n0);
-  else if (cfg == 2 && p.act_bwd == MPV_ACT_GELU_ERF) finish_rows<EP_BWD_ERF>(p, cb, tid, m0, n0);
-  else if (cfg == 2 && p.act_bwd == MPV_ACT_GELU_TANH) finish_rows<EP_BWD_TANH>(p, cb, tid, m0, n0);
-  else if (cfg == 8) finish_rows<EP_RES>(p, cb, tid, m0, n0);
-  else if (cfg == (4 | 8)) finish_rows<EP_DROP_RES>(p, cb, tid, m0, n0);
-  else finish_rows<EP_GENERIC>(p, cb, tid, m0, n0);
+  if (cfg == 0) epilogue(IC<EP_PLAIN>{});
+  else if (cfg == (1 | 32) && p.act == MPV_ACT_GELU_ERF) epilogue(IC<EP_ERF_PRE>{});
+  else if (cfg == (1 | 32) && p.act == MPV_ACT_GELU_TANH) epilogue(IC<EP_TANH_PRE>{});
+  else if (cfg == 2 && p.act_bwd == MPV_ACT_GELU_ERF) epilogue(IC<EP_BWD_ERF>{});
+  else if (cfg == 2 && p.act_bwd == MPV_ACT_GELU_TANH) epilogue(IC<EP_BWD_TANH>{});
+  else if (cfg == 8) epilogue(IC<EP_RES>{});
+  else if (cfg == (4 | 8)) epilogue(IC<EP_DROP_RES>{});
+  else epilogue(IC<EP_GENERIC>{});
 }
 
 }  // namespace
