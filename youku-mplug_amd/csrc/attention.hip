@@ -800,7 +800,8 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(const AttnArgs p) {
   }
 }
 
-template <int HD>
+// NTC as in the forward kernel: compile-time key-tile count (non-causal, no dropout) -> straight-line tile loop.
+template <int HD, int NTC = 0>
 __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const AttnArgs p) {
   constexpr int NS = HD / 16;
   constexpr int NDT = (HD + 31) / 32;
@@ -834,7 +835,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const AttnArgs p) 
   __syncthreads();
   if (q0 >= p.sq) return;
   const int my_last = last_visible_key(p, qrow);
-  const int nt = last_visible_key(p, min(p.sq - 1, q0 + 31)) / 32 + 1;
+  const int nt = NTC ? NTC : last_visible_key(p, min(p.sq - 1, q0 + 31)) / 32 + 1;
   const int wave_first_last = last_visible_key(p, q0);
   const float c2 = sc * 1.4426950408889634f, lse2 = lse * 1.4426950408889634f;
   f32x16 dqacc[NDT];
@@ -845,7 +846,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const AttnArgs p) 
   const lds_char* sm = (const lds_char*)rsm;
   const int kroff = (int)(kl - rsm) + rows_lane_base<ROWB>(lane), vroff = rows_lane_base<ROWB>(lane);
   const int kcoff = (int)(kl - rsm) + cols_lane_base<ROWB>(lane);
-  for (int kt = 0; kt < nt; ++kt) {
+  auto tile = [&](int kt) {
     f32x16 s, dp;
 #pragma unroll
     for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
@@ -866,16 +867,22 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const AttnArgs p) 
   s += s_odd;
   dp += dp_odd;
 }
-    if (kt * 32 + 31 <= wave_first_last && !p.drop_thr) {
+    if (NTC ? kt < NTC - 1 : (kt * 32 + 31 <= wave_first_last && !p.drop_thr)) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) s[e] = fexp2(s[e] * c2 - lse2) * (dp[e] - dl);
+      for (int e = 0; e < 16; e += 2) {      // pairs: v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 around the two exponentials
+        const f32x2 t = __builtin_elementwise_fma(f32x2{s[e], s[e + 1]}, f32x2{c2, c2}, f32x2{-lse2, -lse2});
+        const f32x2 pr = {fexp2(t[0]), fexp2(t[1])};
+        const f32x2 ds = pr * (f32x2{dp[e], dp[e + 1]} - f32x2{dl, dl});
+        s[e] = ds[0];
+        s[e + 1] = ds[1];
+      }
     } else {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int key = kt * 32 + acc_row(e, lane);
         const float pr = key <= my_last ? fexp2(s[e] * c2 - lse2) : 0.f;
         float dpe = dp[e];
-        if (p.drop_thr) {
+        if (NTC == 0 && p.drop_thr) {
           const uint64_t idx = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qrow) * (uint64_t)p.sk + (uint64_t)key;
           dpe = mpv_keep(p.seed, idx, p.drop_thr) ? dpe * p.drop_scale : 0.f;
         }
@@ -889,6 +896,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const AttnArgs p) 
       for (int d = 0; d < NDT; ++d)
         dqacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_f<ROWB>(sm, kcoff + kt * 32 * ROWB, ks, d), dsf, dqacc[d], 0, 0, 0);
     }
+  };
+  if constexpr (NTC > 0) {
+#pragma unroll
+    for (int kt = 0; kt < NTC; ++kt) tile(kt);
+  } else {
+    for (int kt = 0; kt < nt; ++kt) tile(kt);
   }
   if (qok) {
     bf16* row = p.dq + b * p.q_bs + h * p.q_hs + (long long)qrow * p.q_rs;
@@ -1331,7 +1344,7 @@ static void res_attr_once() {
   static bool done = false;
   if (done) return;
   allow_lds(attn_fwd_res_kernel<64>); allow_lds(attn_fwd_res_kernel<80>); allow_lds(attn_fwd_res_kernel<96>); allow_lds(attn_fwd_res_kernel<96, 7>);
-  allow_lds(attn_bwd_dq_res_kernel<64>); allow_lds(attn_bwd_dq_res_kernel<80>); allow_lds(attn_bwd_dq_res_kernel<96>);
+  allow_lds(attn_bwd_dq_res_kernel<64>); allow_lds(attn_bwd_dq_res_kernel<80>); allow_lds(attn_bwd_dq_res_kernel<96>); allow_lds(attn_bwd_dq_res_kernel<96, 7>);
   allow_lds(attn_bwd_dkv_res_kernel<64, 512>); allow_lds(attn_bwd_dkv_res_kernel<80, 512>); allow_lds(attn_bwd_dkv_res_kernel<96, 512>);
   done = true;
 }
@@ -1403,7 +1416,8 @@ extern "C" int mpv_attn_bwd(const mpv_attn_desc* d, const void* dO, void* dq, vo
         hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<80, 512>), gk, dim3(64 * nwk), lk, stream, a);
         break;
       default:
-        hipLaunchKernelGGL((attn_bwd_dq_res_kernel<96>), gq, dim3(64 * nw), lq, stream, a);
+        if (!d->causal && d->dropout_p == 0.f && (d->sk + 31) / 32 == 7) hipLaunchKernelGGL((attn_bwd_dq_res_kernel<96, 7>), gq, dim3(64 * nw), lq, stream, a);
+        else hipLaunchKernelGGL((attn_bwd_dq_res_kernel<96>), gq, dim3(64 * nw), lq, stream, a);
         hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<96, 512>), gk, dim3(64 * nwk), lk, stream, a);
         break;
     }
