@@ -79,6 +79,11 @@ typedef struct mpv_gemm_epilogue {
                              i.e. the bias gradient that goes with dW = dY^T X, fused into the same pass */
   int tile_hint;          /* 0: the library picks the tile kernel per problem; 128 / 256 pin the 128x128 or the
                              256x256 eight-phase kernel where it applies (tests and measurements)              */
+  void* row_tap_out;      /* optional bf16 [ceil(M / row_tap_group)][N]: rows m with m % row_tap_group == 0 ALSO store
+                             bf16(acc * alpha + bias) -- before activation / dropout / residual -- at row m / group.
+                             The ViT block uses it to take the per-frame cls rows of the spatial projection out of the
+                             GEMM whose residual epilogue writes x + proj(.) for all rows (vision_transformer.py:263-270) */
+  int row_tap_group;
 } mpv_gemm_epilogue;
 
 size_t mpv_gemm_workspace_size(int64_t M, int64_t N, int64_t K, int transA, int transB);
@@ -155,6 +160,12 @@ int mpv_vit_embed_assemble_bwd(const void* dx, void* dpatch, void* dcls, void* d
  * m = mean_t a[b,t,0,:];  y[b,t,0,:] = xt[b,t,0,:] + m.  Token rows: y = xt + a (all rows). */
 int mpv_vit_cls_merge_fwd(const void* xt, const void* a, void* y, int B, int T, int N1, int D, mpv_stream_t stream);
 /* backward: dxt = dy (all rows); da[token rows] = dy; da[b,t,0] = (sum_t' dy[b,t',0]) / T. */
+/* The same merge without the full-tensor passes: after a GEMM with residual = xt and a row tap of group N1
+ * (y = xt + a everywhere, tap = a on the cls rows), fix the cls slots in place: y[b,t,0] = xt[b,t,0] + bf16(mean_t' tap[b,t']). */
+int mpv_vit_cls_fix_fwd(const void* xt, const void* tap, void* y, int B, int T, int N1, int D, mpv_stream_t stream);
+/* Backward in place: saved[b,t] = dy[b,t,0] (bf16 [B*T][D], to be copied back with mpv_copy_rows once the projection's
+ * gradients are done), then dy[b,t,0] = bf16(mean_t' dy[b,t',0]); token rows are untouched. */
+int mpv_vit_cls_merge_bwd_inplace(void* dy, void* saved, int B, int T, int N1, int D, mpv_stream_t stream);
 int mpv_vit_cls_merge_bwd(const void* dy, void* da, int B, int T, int N1, int D, mpv_stream_t stream);
 
 /* copy `rows` rows of `cols` bf16 between row-mapped buffers */

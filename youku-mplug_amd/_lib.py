@@ -24,7 +24,7 @@ class GemmEpilogue(C.Structure):
         ("act_bwd_z", c_void_p), ("ldz", c_int64), ("act_bwd", c_int),
         ("dropout_p", c_float), ("seed", c_uint64), ("offset", c_uint64),
         ("alpha_dev", c_void_p), ("alpha", c_float), ("out_f32", c_int), ("accumulate", c_int),
-        ("colsum_out", c_void_p), ("tile_hint", c_int),
+        ("colsum_out", c_void_p), ("tile_hint", c_int), ("row_tap_out", c_void_p), ("row_tap_group", c_int),
     ]
 
 
@@ -64,6 +64,8 @@ _SIGS = {
     "mpv_vit_embed_assemble_bwd": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "mpv_vit_cls_merge_fwd": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
     "mpv_vit_cls_merge_bwd": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
+    "mpv_vit_cls_fix_fwd": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
+    "mpv_vit_cls_merge_bwd_inplace": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
     "mpv_copy_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64] + _RM + _RM + [c_void_p]),
     "mpv_colsum_workspace_size": (c_size_t, [c_int64]),
     "mpv_colsum": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64] + _RM + [c_int, c_void_p, c_size_t, c_void_p]),

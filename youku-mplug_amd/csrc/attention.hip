@@ -42,6 +42,10 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 // v_exp_f32 directly: exp2f() wraps it in a denormal-range rescue (6 VALU instead of 1; measured 38% of the forward
 // kernel's VALU instructions); probabilities below 2^-126 may flush to zero, far below bf16 resolution of the result
 __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// attention-probability dropout: element (row, key) of the score matrix, pairs along the key axis (mpv_common.h)
+__device__ __forceinline__ bool attn_keep(uint64_t seed, uint64_t row_base, int key, uint32_t thr) {
+  return mpv_keep(seed, row_base + (uint64_t)(key & ~1), key & 1, thr);
+}
 
 #ifdef MPV_ATTN_TIMING   // measurement build only (tools/probe/attn_timeline.py)
 __device__ long long mpv_attn_dbg[4096 * 8];
@@ -321,8 +325,8 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs p) {
         const int key = c * CH + kt * 32 + acc_row(e, lane);
         float pr = key <= my_last ? __expf(s[e] * sc - m) * inv_l : 0.f;
         if (p.drop_thr) {
-          const uint64_t idx = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qrow) * (uint64_t)p.sk + (uint64_t)key;
-          pr = mpv_keep(p.seed, idx, p.drop_thr) ? pr * p.drop_scale : 0.f;
+          const uint64_t rb = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qrow) * (uint64_t)p.sk;
+          pr = attn_keep(p.seed, rb, key, p.drop_thr) ? pr * p.drop_scale : 0.f;
         }
         s[e] = pr;
       }
@@ -447,8 +451,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttnArgs p) {
         const float pr = key <= my_last ? __expf(s[e] * sc - lse) : 0.f;
         float dpe = dp[e];
         if (p.drop_thr) {
-          const uint64_t idx = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qrow) * (uint64_t)p.sk + (uint64_t)key;
-          dpe = mpv_keep(p.seed, idx, p.drop_thr) ? dpe * p.drop_scale : 0.f;
+          const uint64_t rb = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qrow) * (uint64_t)p.sk;
+          dpe = attn_keep(p.seed, rb, key, p.drop_thr) ? dpe * p.drop_scale : 0.f;
         }
         s[e] = pr * (dpe - dl);
       }
@@ -579,8 +583,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
         const float pr = vis ? __expf(s[e] * sc - sl[ql_]) : 0.f;
         float keep = 1.0f;
         if (p.drop_thr) {
-          const uint64_t idx = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qr) * (uint64_t)p.sk + (uint64_t)krow;
-          keep = mpv_keep(p.seed, idx, p.drop_thr) ? p.drop_scale : 0.f;
+          const uint64_t rb = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qr) * (uint64_t)p.sk;
+          keep = attn_keep(p.seed, rb, krow, p.drop_thr) ? p.drop_scale : 0.f;
         }
         pd[e] = pr * keep;
         s[e] = pr * (dp[e] * keep - sl[CH + ql_]);
@@ -764,11 +768,12 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(const AttnArgs p) {
         l += a2[0] + a2[1];
       }
       if (NTC == 0 && p.drop_thr) {      // (the NTC instances are launched without dropout)
+        const uint64_t rb = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qrow) * (uint64_t)p.sk;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int key = kt * 32 + acc_row(e, lane);
-          const uint64_t idx = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qrow) * (uint64_t)p.sk + (uint64_t)key;
-          pr[e] = mpv_keep(p.seed, idx, p.drop_thr) ? pr[e] * p.drop_scale : 0.f;
+        for (int e = 0; e < 16; e += 2) {      // registers e, e+1 hold keys k, k+1 with k even: one hash per pair
+          const uint32_t r = mpv_rand_pair(p.seed, rb + (uint64_t)(kt * 32 + acc_row(e, lane)));
+          pr[e] = (r & 0xffffu) >= p.drop_thr ? pr[e] * p.drop_scale : 0.f;
+          pr[e + 1] = (r >> 16) >= p.drop_thr ? pr[e + 1] * p.drop_scale : 0.f;
         }
       }
 #pragma unroll
@@ -883,8 +888,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const AttnArgs p) 
         const float pr = key <= my_last ? fexp2(s[e] * c2 - lse2) : 0.f;
         float dpe = dp[e];
         if (NTC == 0 && p.drop_thr) {
-          const uint64_t idx = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qrow) * (uint64_t)p.sk + (uint64_t)key;
-          dpe = mpv_keep(p.seed, idx, p.drop_thr) ? dpe * p.drop_scale : 0.f;
+          const uint64_t rb = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qrow) * (uint64_t)p.sk;
+          dpe = attn_keep(p.seed, rb, key, p.drop_thr) ? dpe * p.drop_scale : 0.f;
         }
         s[e] = key <= my_last ? pr * (dpe - dl) : 0.f;
       }
@@ -1057,8 +1062,8 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_dkv_res_kernel(const AttnArg
             const float pr = vis ? fexp2(s[e] * c2 - l4[j]) : 0.f;
             float keep = 1.0f;
             if (p.drop_thr) {
-              const uint64_t idx = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qr) * (uint64_t)p.sk + (uint64_t)krow;
-              keep = mpv_keep(p.seed, idx, p.drop_thr) ? p.drop_scale : 0.f;
+              const uint64_t rb = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qr) * (uint64_t)p.sk;
+              keep = attn_keep(p.seed, rb, krow, p.drop_thr) ? p.drop_scale : 0.f;
             }
             pr8[4 * qh + j] = vis ? pr * keep : 0.f;
             ds8[4 * qh + j] = vis ? pr * (dp[e] * keep - d4[j]) : 0.f;

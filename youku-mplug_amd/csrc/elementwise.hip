@@ -153,6 +153,38 @@ __global__ void cls_merge_bwd_kernel(const bf16* __restrict__ dy, bf16* __restri
   }
 }
 
+// The merge without full-tensor passes (one thread per (b, 8 columns)).  Forward: y already holds xt + a on every row
+// (residual epilogue of the projection GEMM), tap holds a on the cls rows; only the B*T cls slots are rewritten.
+__global__ void cls_fix_fwd_kernel(const bf16* __restrict__ xt, const bf16* __restrict__ tap, bf16* __restrict__ y, int B, int T,
+                                   int N1, int D) {
+  const int D8 = D / 8;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * D8) return;
+  const int b = idx / D8, c = (idx - b * D8) * 8;
+  f32x8 m = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < T; ++t) m += cvt8(*(const bf16x8*)(tap + (long long)(b * T + t) * D + c));
+  const f32x8 mb = cvt8(cvt8(m * (1.0f / (float)T)));      // torch.mean rounds to bf16 before the residual add (:265,270)
+  for (int t = 0; t < T; ++t) {
+    const long long off = (long long)(b * T + t) * N1 * D + c;
+    *(bf16x8*)(y + off) = cvt8(cvt8(*(const bf16x8*)(xt + off)) + mb);
+  }
+}
+// Backward: the cls rows of dy are saved, then replaced by their mean over t (what the projection's gradients see).
+__global__ void cls_merge_bwd_inplace_kernel(bf16* __restrict__ dy, bf16* __restrict__ saved, int B, int T, int N1, int D) {
+  const int D8 = D / 8;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * D8) return;
+  const int b = idx / D8, c = (idx - b * D8) * 8;
+  f32x8 m = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < T; ++t) {
+    const bf16x8 v = *(const bf16x8*)(dy + (long long)(b * T + t) * N1 * D + c);
+    *(bf16x8*)(saved + (long long)(b * T + t) * D + c) = v;
+    m += cvt8(v);
+  }
+  const bf16x8 o = cvt8(m * (1.0f / (float)T));
+  for (int t = 0; t < T; ++t) *(bf16x8*)(dy + (long long)(b * T + t) * N1 * D + c) = o;
+}
+
 // ---------------------------------------------------------------- row copy / add / colsum
 __global__ void copy_rows_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, long long rows, int cols, long long lds_,
                                  long long ldd, RowMap sm, RowMap dm) {
@@ -232,8 +264,7 @@ __global__ void gpt_embed_fwd_kernel(const bf16* __restrict__ query, const int64
     if (thr) {
       v = cvt8(cvt8(v));
       const uint64_t base = offset + (uint64_t)row * (uint64_t)H + (uint64_t)(c8 * 8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = mpv_keep(seed, base + e, thr) ? v[e] * drop_scale : 0.f;
+      v = mpv_dropout_vec<f32x8, 8>(v, seed, base, thr, drop_scale);
     }
     *(bf16x8*)(h + row * H + c8 * 8) = cvt8(v);
   }
@@ -251,8 +282,7 @@ __global__ void gpt_embed_bwd_kernel(const bf16* __restrict__ dh, bf16* __restri
     f32x8 v = cvt8(*(const bf16x8*)(dh + row * H + c8 * 8));
     if (thr) {
       const uint64_t base = offset + (uint64_t)row * (uint64_t)H + (uint64_t)(c8 * 8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = mpv_keep(seed, base + e, thr) ? v[e] * drop_scale : 0.f;
+      v = mpv_dropout_vec<f32x8, 8>(v, seed, base, thr, drop_scale);
     }
     *(bf16x8*)(dquery + qrow * H + c8 * 8) = cvt8(v);
   }
@@ -663,6 +693,22 @@ extern "C" int mpv_vit_cls_merge_fwd(const void* xt, const void* a, void* y, int
   hipLaunchKernelGGL(cls_merge_fwd_kernel, dim3(ew_grid((long long)B * T * N1 * (D / 4))), dim3(256), 0, stream, (const bf16*)xt,
                      (const bf16*)a, (bf16*)y, B, T, N1, D);
   return mpv_check_launch("mpv_vit_cls_merge_fwd");
+}
+
+extern "C" int mpv_vit_cls_fix_fwd(const void* xt, const void* tap, void* y, int B, int T, int N1, int D, hipStream_t stream) {
+  MPV_REQUIRE(xt && tap && y, MPV_E_ARG, "mpv_vit_cls_fix_fwd: null pointer");
+  MPV_REQUIRE(D % 8 == 0 && B > 0 && T > 0 && N1 > 1, MPV_E_SHAPE, "mpv_vit_cls_fix_fwd: bad shape");
+  hipLaunchKernelGGL(cls_fix_fwd_kernel, dim3((unsigned)((B * (D / 8) + 255) / 256)), dim3(256), 0, stream, (const bf16*)xt,
+                     (const bf16*)tap, (bf16*)y, B, T, N1, D);
+  return mpv_check_launch("mpv_vit_cls_fix_fwd");
+}
+
+extern "C" int mpv_vit_cls_merge_bwd_inplace(void* dy, void* saved, int B, int T, int N1, int D, hipStream_t stream) {
+  MPV_REQUIRE(dy && saved, MPV_E_ARG, "mpv_vit_cls_merge_bwd_inplace: null pointer");
+  MPV_REQUIRE(D % 8 == 0 && B > 0 && T > 0 && N1 > 1, MPV_E_SHAPE, "mpv_vit_cls_merge_bwd_inplace: bad shape");
+  hipLaunchKernelGGL(cls_merge_bwd_inplace_kernel, dim3((unsigned)((B * (D / 8) + 255) / 256)), dim3(256), 0, stream, (bf16*)dy,
+                     (bf16*)saved, B, T, N1, D);
+  return mpv_check_launch("mpv_vit_cls_merge_bwd_inplace");
 }
 
 extern "C" int mpv_vit_cls_merge_bwd(const void* dy, void* da, int B, int T, int N1, int D, hipStream_t stream) {

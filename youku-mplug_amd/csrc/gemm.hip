@@ -426,6 +426,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
           continue;
         }
         if (p.bias) v += cvt8(*(const bf16x8*)(p.bias + n));
+        // the product rounds to bf16 before anything else is applied to it (as the unfused reference ops do, and as the
+        // 256x256 kernel's staged tile does): results do not depend on which tile kernel took the problem
+        if (p.act_bwd || p.drop_thr || p.residual || p.accumulate || p.tap_out) v = cvt8(cvt8(v));
+        if (p.tap_out && m % p.tap_group == 0) *(bf16x8*)(p.tap_out + (long long)(m / p.tap_group) * p.N + n) = cvt8(v);
         if (p.act) {
           const bf16x8 zb = cvt8(v);
           if (p.preact) *(bf16x8*)(p.preact + crow * p.ldc + n) = zb;
@@ -440,8 +444,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
         }
         if (p.drop_thr) {
           const uint64_t base = p.drop_offset + (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = mpv_keep(p.seed, base + e, p.drop_thr) ? v[e] * p.drop_scale : 0.f;
+          v = mpv_dropout_vec<f32x8, 8>(v, p.seed, base, p.drop_thr, p.drop_scale);
         }
         if (p.residual) v += cvt8(*(const bf16x8*)(p.residual + crow * p.ldr + n));
         bf16* cp = (bf16*)p.C + crow * p.ldc + n;
@@ -683,11 +686,17 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
     if (ep->alpha != 0.f) g.alpha = ep->alpha;
     g.out_f32 = ep->out_f32;
     g.accumulate = ep->accumulate;
+    if (ep->row_tap_out) {
+      MPV_REQUIRE(ep->row_tap_group > 0 && !ep->out_f32 && !(transA && transB), MPV_E_ARG,
+                  "mpv_gemm_bf16: row_tap_out needs row_tap_group > 0 and a bf16 forward/dgrad product");
+      g.tap_out = (bf16*)ep->row_tap_out;
+      g.tap_group = ep->row_tap_group;
+    }
   }
   void* colsum_out = ep ? ep->colsum_out : nullptr;
   MPV_REQUIRE(!colsum_out || (transA && transB && !g.out_f32), MPV_E_ARG, "mpv_gemm_bf16: colsum_out is a wgrad (transA=transB=1) option");
   // decode regime: a handful of rows against a k-contiguous weight -> the weight-streaming kernel
-  if (!transA && !transB && M <= 16 && !g.out_f32 && !g.accumulate && !g.drop_thr && !g.act_bwd && !g.preact && !g.alpha_dev &&
+  if (!transA && !transB && M <= 16 && !g.out_f32 && !g.accumulate && !g.drop_thr && !g.act_bwd && !g.preact && !g.alpha_dev && !g.tap_out &&
       g.alpha == 1.0f && g.amap.group == 0 && !colsum_out) {
     SmallMArgs sm = {};
     sm.A = g.A; sm.W = g.B; sm.C = (bf16*)C;

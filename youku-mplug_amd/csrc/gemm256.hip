@@ -147,15 +147,15 @@ __device__ __forceinline__ void finish_rows(const GemmArgs& p, const EpExt<KIND>
       } else if constexpr (KIND == EP_BWD_ERF || KIND == EP_BWD_TANH) {
         *(bf16x8*)cp = cvt8(apply_act_grad<KIND == EP_BWD_ERF ? MPV_ACT_GELU_ERF : MPV_ACT_GELU_TANH>(cvt8(zb), cvt8(ex)));
       } else if constexpr (KIND == EP_RES) {
+        if (p.tap_out && m % p.tap_group == 0) *(bf16x8*)(p.tap_out + (long long)(m / p.tap_group) * p.N + n) = zb;
         *(bf16x8*)cp = cvt8(cvt8(zb) + cvt8(ex));
       } else if constexpr (KIND == EP_DROP_RES) {
-        f32x8 v = cvt8(zb);
         const uint64_t base = p.drop_offset + (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = mpv_keep(p.seed, base + e, p.drop_thr) ? v[e] * p.drop_scale : 0.f;
+        const f32x8 v = mpv_dropout_vec<f32x8, 8>(cvt8(zb), p.seed, base, p.drop_thr, p.drop_scale);
         *(bf16x8*)cp = cvt8(v + cvt8(ex));
       } else {
         f32x8 v = cvt8(zb);
+        if (p.tap_out && m % p.tap_group == 0) *(bf16x8*)(p.tap_out + (long long)(m / p.tap_group) * p.N + n) = zb;
         if (p.act) {
           if (p.preact) *(bf16x8*)(p.preact + crow * p.ldc + n) = zb;
           v = p.act == MPV_ACT_GELU_ERF ? apply_act<MPV_ACT_GELU_ERF>(v) : p.act == MPV_ACT_GELU_TANH ? apply_act<MPV_ACT_GELU_TANH>(v) : apply_act<MPV_ACT_RELU>(v);
@@ -167,8 +167,7 @@ __device__ __forceinline__ void finish_rows(const GemmArgs& p, const EpExt<KIND>
         }
         if (p.drop_thr) {
           const uint64_t base = p.drop_offset + (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = mpv_keep(p.seed, base + e, p.drop_thr) ? v[e] * p.drop_scale : 0.f;
+          v = mpv_dropout_vec<f32x8, 8>(v, p.seed, base, p.drop_thr, p.drop_scale);
         }
         if (p.residual) v += cvt8(*(const bf16x8*)(p.residual + crow * p.ldr + n));
         if (p.accumulate) v += cvt8(*(const bf16x8*)cp);
@@ -535,7 +534,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     finish_rows<KIND>(p, ext, cb, tid, m0, n0);
   };
   const int cfg = (p.act ? 1 : 0) | (p.act_bwd ? 2 : 0) | (p.drop_thr ? 4 : 0) | (p.residual ? 8 : 0) | (p.accumulate ? 16 : 0) |
-                  (p.preact ? 32 : 0);
+                  (p.preact ? 32 : 0) | (p.tap_out && !(p.residual && !p.act && !p.act_bwd && !p.drop_thr && !p.accumulate && !p.preact) ? 64 : 0);
   if (cfg == 0) epilogue(IC<EP_PLAIN>{});
   else if (cfg == (1 | 32) && p.act == MPV_ACT_GELU_ERF) epilogue(IC<EP_ERF_PRE>{});
   else if (cfg == (1 | 32) && p.act == MPV_ACT_GELU_TANH) epilogue(IC<EP_TANH_PRE>{});

@@ -30,6 +30,8 @@ struct GemmArgs {
   int tiles_n, tiles_m;
   int nwg, splits;
   int gm;               // gemm256: m-tiles per n-tile in an XCD's tile walk (0 -> default)
+  bf16* tap_out;        // rows m % tap_group == 0 also store bf16(acc * alpha + bias) at tap_out[(m / tap_group) * N + n]
+  int tap_group;
   float* colsum_part;   // wgrad only: [splits][M] fp32 partial column sums of the A operand (bias gradient)
   // tail split: the last `tiles % 512` tiles (a mostly empty final round of the 512 resident slots) are cut
   // tail_g ways along K; partial tiles meet in tail_ws and the last workgroup to arrive finishes the tile

@@ -59,8 +59,8 @@ __device__ __forceinline__ f32x8 cvt8(bf16x8 v) { return __builtin_convertvector
 __device__ __forceinline__ bf16x8 cvt8(f32x8 v) { return __builtin_convertvector(v, bf16x8); }
 
 // ---------------------------------------------------------------------------------------
-// Counter-based dropout RNG: two rounds of a 32-bit avalanche mix keyed by a 64-bit seed.
-// keep(idx) is a pure function of (seed, idx) so forward and backward regenerate the same
+// Counter-based dropout RNG: a 32-bit avalanche mix keyed by a 64-bit seed.
+// keep is a pure function of (seed, element index) so forward and backward regenerate the same
 // mask without storing it.  (The reference uses torch's Philox stream; masks cannot be
 // bit-compatible with it, parity is tested with dropout off and statistically with it on.)
 __host__ __device__ __forceinline__ uint32_t mpv_mix32(uint32_t x) {
@@ -71,20 +71,36 @@ __host__ __device__ __forceinline__ uint32_t mpv_mix32(uint32_t x) {
   x ^= x >> 16;
   return x;
 }
-// The seed halves go through the hash themselves before they meet the counter (an XOR of the raw seed into the counter
-// would make the streams of two seeds index-permutations of each other); both seed hashes are loop-invariant.
-__host__ __device__ __forceinline__ uint32_t mpv_rand32(uint64_t seed, uint64_t idx) {
-  uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
-  uint32_t x = mpv_mix32(lo + mpv_mix32((uint32_t)seed));
-  x = mpv_mix32(x + mpv_mix32((uint32_t)(seed >> 32) ^ 0x85ebca6bu) + hi * 0x9e3779b9u);
-  return x;
+// One hash serves TWO adjacent elements (16 random bits each): the 32-bit integer multiply is quarter rate on CDNA, so a
+// hash per element (two rounds, 4 multiplies) cost ~35 issue slots per element -- 10 us per 256x256 tile in a GEMM
+// epilogue.  `ctr` is the 64-bit index of the pair's FIRST element; every site pairs along its fastest dimension with
+// the even coordinate first (hidden states: columns n, n+1 with n even; attention: keys k, k+1 with k even), and the
+// forward and backward kernels of a site use the same rule, so masks are reproduced exactly.  The seed halves go through
+// the hash themselves (wave-uniform, hoisted) before they meet the counter; the high counter word only matters beyond
+// 2^32 elements and is folded in by XOR.  Drop probability is quantised to 1/65536 (0.1 -> 0.100006).
+__host__ __device__ __forceinline__ uint32_t mpv_rand_pair(uint64_t seed, uint64_t ctr) {
+  const uint32_t ka = mpv_mix32((uint32_t)seed), kb = mpv_mix32((uint32_t)(seed >> 32) ^ 0x85ebca6bu);
+  return mpv_mix32(((uint32_t)ctr + ka) ^ ((uint32_t)(ctr >> 32) + kb));
 }
-// keep-threshold on the top 24 bits: keep iff r24 >= p * 2^24
+// keep-threshold on 16 bits: keep iff r16 >= p * 2^16
 __host__ __device__ __forceinline__ uint32_t mpv_drop_threshold(float p) {
-  return (uint32_t)(p * 16777216.0f);
+  return (uint32_t)(p * 65536.0f + 0.5f);
 }
-__host__ __device__ __forceinline__ bool mpv_keep(uint64_t seed, uint64_t idx, uint32_t thr) {
-  return (mpv_rand32(seed, idx) >> 8) >= thr;
+// element `half` (0/1) of the pair whose first element has index ctr
+__host__ __device__ __forceinline__ bool mpv_keep(uint64_t seed, uint64_t ctr, int half, uint32_t thr) {
+  const uint32_t r = mpv_rand_pair(seed, ctr);
+  return (half ? r >> 16 : r & 0xffffu) >= thr;
+}
+// dropout on N (4 or 8) consecutive elements starting at index `base` (an even coordinate of the fastest dimension)
+template <typename V, int N>
+__device__ __forceinline__ V mpv_dropout_vec(V v, uint64_t seed, uint64_t base, uint32_t thr, float scale) {
+#pragma unroll
+  for (int e = 0; e < N; e += 2) {
+    const uint32_t r = mpv_rand_pair(seed, base + e);
+    v[e] = (r & 0xffffu) >= thr ? v[e] * scale : 0.f;
+    v[e + 1] = (r >> 16) >= thr ? v[e + 1] * scale : 0.f;
+  }
+  return v;
 }
 
 // ---------------------------------------------------------------------------------------

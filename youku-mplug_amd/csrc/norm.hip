@@ -154,10 +154,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p) {
         *(bf16x4*)(dxr + c * 4) = ob;
         if (ddr) {
           const f32x4 of = cvt4(ob);
-          f32x4 od;
           const uint64_t base = p.offset + (uint64_t)r * (uint64_t)p.cols + (uint64_t)(c * 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) od[e] = (p.drop_thr == 0 || mpv_keep(p.seed, base + e, p.drop_thr)) ? of[e] * p.drop_scale : 0.f;
+          const f32x4 od = p.drop_thr ? mpv_dropout_vec<f32x4, 4>(of, p.seed, base, p.drop_thr, p.drop_scale) : of * p.drop_scale;
           *(bf16x4*)(ddr + c * 4) = cvt4(od);
         }
       }
@@ -314,10 +312,8 @@ __global__ __launch_bounds__(256) void ln_bwd8_kernel(const LnBwdArgs p) {
         *(bf16x8*)(dxr + c * 8) = ob;
         if (ddr) {
           const f32x8 of = cvt8(ob);
-          f32x8 od;
           const uint64_t base = p.offset + (uint64_t)r * (uint64_t)p.cols + (uint64_t)(c * 8);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) od[e] = (p.drop_thr == 0 || mpv_keep(p.seed, base + e, p.drop_thr)) ? of[e] * p.drop_scale : 0.f;
+          const f32x8 od = p.drop_thr ? mpv_dropout_vec<f32x8, 8>(of, p.seed, base, p.drop_thr, p.drop_scale) : of * p.drop_scale;
           *(bf16x8*)(ddr + c * 8) = cvt8(od);
         }
       }

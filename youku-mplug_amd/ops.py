@@ -50,7 +50,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: Optio
          act_bwd_z=None, act_bwd: int = 0, ldz: int = 0, dropout_p: float = 0.0, seed: int = 0, offset: int = 0,
          alpha_dev=None, alpha: float = 0.0, amap: RowMap = IDENT, cmap: RowMap = IDENT, kmap: RowMap = IDENT,
          out_rows: Optional[int] = None, accumulate: bool = False, out_f32: bool = False, colsum_out=None,
-         tile_hint: int = 0) -> torch.Tensor:
+         tile_hint: int = 0, row_tap_out=None, row_tap_group: int = 0) -> torch.Tensor:
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)).  See include/mpv.h:mpv_gemm_bf16."""
     _need_cuda(a, b)
     lda = lda if lda is not None else (M if trans_a else K)
@@ -80,6 +80,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: Optio
     ep.accumulate = int(accumulate)
     ep.colsum_out = _p(colsum_out)
     ep.tile_hint = tile_hint
+    ep.row_tap_out = _p(row_tap_out)
+    ep.row_tap_group = row_tap_group
     ws, wsn = None, 0
     if not out_f32:
         wsn = _lib.lib().mpv_gemm_workspace_size(M, N, K, int(trans_a), int(trans_b))
@@ -205,6 +207,20 @@ def vit_cls_merge_fwd(xt, a, B, T, N1, D, out=None):
     check(_lib.lib().mpv_vit_cls_merge_fwd(xt.data_ptr(), a.data_ptr(), y.data_ptr(), B, T, N1, D, _stream()),
           "mpv_vit_cls_merge_fwd")
     return y
+
+
+def vit_cls_fix_fwd(xt, tap, y, B, T, N1, D):
+    """y (= xt + a on all rows) gets its cls slots rewritten: xt_cls + bf16(mean_t tap)."""
+    check(_lib.lib().mpv_vit_cls_fix_fwd(xt.data_ptr(), tap.data_ptr(), y.data_ptr(), B, T, N1, D, _stream()), "mpv_vit_cls_fix_fwd")
+    return y
+
+
+def vit_cls_merge_bwd_inplace(dy, B, T, N1, D):
+    """dy's cls rows <- their mean over t, in place; returns the saved originals [B*T, D] (restore with copy_rows)."""
+    saved = torch.empty((B * T, D), dtype=torch.bfloat16, device=dy.device)
+    check(_lib.lib().mpv_vit_cls_merge_bwd_inplace(dy.data_ptr(), saved.data_ptr(), B, T, N1, D, _stream()),
+          "mpv_vit_cls_merge_bwd_inplace")
+    return saved
 
 
 def vit_cls_merge_bwd(dy, B, T, N1, D, out=None):

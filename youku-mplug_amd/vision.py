@@ -237,8 +237,11 @@ class TimeSformer(nn.Module):
             lay = ops.AttnLayout(st3, st3, st3, (N1 * D, hd, D))
             lse = ops.attn_fwd(qkv_s, qkv_s[:, D:], qkv_s[:, 2 * D:], a_s, lay, B * T, heads, N1, N1, hd,
                                scale=blk.attn.scale, scale_q_bf16=True)
-            ps = ops.gemm(a_s, blk.attn.proj.weight, R, D, D, bias=blk.attn.proj.bias)
-            y = ops.vit_cls_merge_fwd(xt, ps, B, T, N1, D)                               # :263-270
+            # y = xt + proj(a_s) straight from the GEMM's residual epilogue; the projection's cls rows are tapped out of the
+            # same launch and only the B*T cls slots are rewritten as xt_cls + mean_t(proj cls)              (:263-270)
+            tap = torch.empty((B * T, D), dtype=torch.bfloat16, device=x.device)
+            y = ops.gemm(a_s, blk.attn.proj.weight, R, D, D, bias=blk.attn.proj.bias, residual=xt, row_tap_out=tap, row_tap_group=N1)
+            ops.vit_cls_fix_fwd(xt, tap, y, B, T, N1, D)
             # ---- MLP (:271)
             l2, s["m2"], s["r2"] = ops.layernorm_fwd(y, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, R, D)
             hid = blk.mlp.fc1.out_features
@@ -287,9 +290,12 @@ class TimeSformer(nn.Module):
             dy = ops.layernorm_bwd(dl2, s["y"], blk.norm2.weight, s["m2"], s["r2"], R, D, dres=dout,
                                    dgamma=grad_of(blk.norm2.weight), dbeta=grad_of(blk.norm2.bias))
             # ---- cls merge + spatial attention
-            dps = ops.vit_cls_merge_bwd(dy, B, T, N1, D)
-            ops.gemm(dps, s["a_s"], D, D, R, trans_a=True, trans_b=True, out=grad_of(blk.attn.proj.weight), colsum_out=grad_of(blk.attn.proj.bias))
-            das = ops.gemm(dps, blk.attn.proj.weight, R, D, D, trans_b=True)
+            # the projection sees dy with every cls row replaced by the mean over t: done in place on the B*T cls rows,
+            # which are put back before dy is used as the residual gradient
+            cls_saved = ops.vit_cls_merge_bwd_inplace(dy, B, T, N1, D)
+            ops.gemm(dy, s["a_s"], D, D, R, trans_a=True, trans_b=True, out=grad_of(blk.attn.proj.weight), colsum_out=grad_of(blk.attn.proj.bias))
+            das = ops.gemm(dy, blk.attn.proj.weight, R, D, D, trans_b=True)
+            ops.copy_rows(cls_saved, dy, B * T, D, dmap=(1, N1, 0))
             qkv_s = s["qkv_s"]
             dqkv = torch.empty_like(qkv_s)
             ops.attn_bwd(qkv_s, qkv_s[:, D:], qkv_s[:, 2 * D:], s["a_s"], s["lse"], das, dqkv, dqkv[:, D:], dqkv[:, 2 * D:],
