@@ -300,10 +300,19 @@ def main():
     roof = None
     if rank == 0 and not args.no_roofline:
         nroof = min(args.steps, 3)
+        # per-launch durations are taken with the weight-gradient lane off (vision._WgradLane: in the timed region the
+        # ViT wgrad GEMMs run on a second stream and share the chip with the dgrad launches, which stretches both
+        # kernels' start-to-end times); tools/profile_round.sh traces the same serial mode (MPV_WGRAD_STREAM=0)
+        lane = getattr(model.visual_encoder, "_wgrad_lane", None)
+        lane_on = lane.on if lane is not None else False
+        if lane is not None:
+            lane.on = False
         with GemmTimer() as gt:
             for i in range(nroof):
                 step(total + i)
         tot = gt.summary()
+        if lane is not None:
+            lane.on = lane_on
         fl = sum(v[0] for v in tot.values())
         tt = sum(v[1] for v in tot.values())
         n = sum(v[2] for v in tot.values())
@@ -313,6 +322,7 @@ def main():
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / tt / 1e12 / PEAK_BF16_TFLOPS, 4),
                 "traffic": traffic, "traffic_unit": "bytes per launch (L2-miss side: 2*FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": round(by / n, 0),
+                "measured": "HIP events around every mpv_gemm_bf16 launch in %d extra steps after the timed region, weight-gradient lane off (kernels do not overlap)" % nroof,
                 "launches_per_step": n // nroof, "avg_launch_us": round(tt / n * 1e6, 1), "avg_launch_gflop": round(fl / n / 1e9, 2),
                 "gemm_ms_per_step": round(tt / nroof * 1e3, 2),
                 "by_kernel": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / nroof * 1e3, 2), "launches": v[2] // nroof}

@@ -173,3 +173,32 @@ def test_gemm256_row_maps_and_fused_bias_grad(dev):
     dw2 = ops.gemm(dy2, x2, 768, 512, K, trans_a=True, trans_b=True, colsum_out=bs2, tile_hint=256)
     close(dw2, dy2.float().t() @ x2.float(), 1e-2, "dW split-K")
     close(bs2, dy2.float().sum(0), 1e-2, "fused bias grad split-K")
+
+
+@pytest.mark.parametrize("rows", [192, 160])
+@pytest.mark.parametrize("M,N,K", [(160, 256, 64), (192, 256, 128), (5120, 2048, 256), (1000, 520, 192), (333, 264, 320), (2560, 768, 2048)])
+def test_gemm256_short_tile_rows(dev, rows, M, N, K):
+    """The 192- and 160-row tile variants of the eight-phase kernel (same ring, the second A unit of a wave row partly
+    dead): every element against fp32, bit-identical to the 256-row tile (same K order per element), ragged M / N,
+    and the fused epilogues the GPT shapes use (tanh-GELU + pre-activation, GELU', dropout + residual)."""
+    from youku_mplug_amd import ops
+    from youku_mplug_amd.ops import ACT_GELU_TANH
+    a, w = rn(M, K, dev=dev, seed=71), rn(N, K, dev=dev, seed=72, scale=0.2)
+    bias, res = rn(N, dev=dev, seed=73), rn(M, N, dev=dev, seed=74)
+    out = ops.gemm(a, w, M, N, K, tile_hint=rows)
+    close(out, a.float() @ w.float().t(), 1e-2, f"{rows}-row tile")
+    assert torch.equal(out, ops.gemm(a, w, M, N, K, tile_hint=256))
+    for _ in range(10):
+        assert torch.equal(out, ops.gemm(a, w, M, N, K, tile_hint=rows))
+    z1, z2 = torch.empty_like(out), torch.empty_like(out)
+    h1 = ops.gemm(a, w, M, N, K, bias=bias, act=ACT_GELU_TANH, preact_out=z1, tile_hint=rows)
+    h2 = ops.gemm(a, w, M, N, K, bias=bias, act=ACT_GELU_TANH, preact_out=z2, tile_hint=256)
+    assert torch.equal(h1, h2) and torch.equal(z1, z2)
+    g1 = ops.gemm(a, w, M, N, K, act_bwd_z=res, act_bwd=ACT_GELU_TANH, tile_hint=rows)
+    g2 = ops.gemm(a, w, M, N, K, act_bwd_z=res, act_bwd=ACT_GELU_TANH, tile_hint=256)
+    assert torch.equal(g1, g2)
+    d1 = ops.gemm(a, w, M, N, K, bias=bias, residual=res, dropout_p=0.1, seed=11, offset=5, tile_hint=rows)
+    d2 = ops.gemm(a, w, M, N, K, bias=bias, residual=res, dropout_p=0.1, seed=11, offset=5, tile_hint=256)
+    assert torch.equal(d1, d2)
+    r1 = ops.gemm(a, w, M, N, K, bias=bias, residual=res, tile_hint=rows)
+    assert torch.equal(r1, ops.gemm(a, w, M, N, K, bias=bias, residual=res, tile_hint=256))

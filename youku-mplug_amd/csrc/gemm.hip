@@ -734,13 +734,14 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
 
   // ---- 256x256 eight-phase kernel (gemm256.hip) for the problems that fill the chip with 256-tiles
   const int variant = (ep && ep->tile_hint) ? ep->tile_hint : gemm_variant();
-  if (variant != 128 && K % 64 == 0 && M >= 256 && N >= 256) {
+  if (variant != 128 && K % 64 == 0 && (M >= 256 || variant == 160 || variant == 192) && N >= 256) {
     const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
     int s256 = 1;
     if (transA && transB && !g.out_f32) s256 = choose_splitk256(t256, K, M, N, workspace ? workspace_bytes : 0);
     {   // measured on MI355X (tools/gemm_ab.py): the 256x256 kernel wins on every eligible shape of the path, also when
         // its tiles fill only 5/8 of the CUs (M = 5120, N = 2048: 959 vs 764 TFLOP/s)
       GemmArgs h = g;
+      h.tile_rows = (variant == 160 || variant == 192 || variant == 256) ? variant : 0;
       h.splits = s256;
       h.k_per_split = (int)K;
       if (s256 > 1) {

@@ -102,16 +102,17 @@ __device__ __forceinline__ f32x8 apply_act_grad(f32x8 v, f32x8 z) {
 // thread right after the main loop, before the accumulators are staged: interleaved with the stores each load sat behind `s_waitcnt vmcnt(0)` (stores
 // count in vmcnt, and the compiler cannot prove C does not alias z / the residual), 16 serial round trips = 14 us per
 // tile at K = 768; up front they cost one latency, hidden behind the staging pass and its barrier.
-template <int KIND>
+// NIT = 16-byte chunks per thread = tile rows / 16 (16 for the 256-row tile, 12 / 10 for the 192 / 160-row variants)
+template <int KIND, int NIT>
 struct EpExt {
   static constexpr bool EXT = KIND == EP_BWD_ERF || KIND == EP_BWD_TANH || KIND == EP_RES || KIND == EP_DROP_RES;
-  bf16x8 v[EXT ? 16 : 1];
+  bf16x8 v[EXT ? NIT : 1];
 };
-template <int KIND>
-__device__ __forceinline__ void prefetch_rows(const GemmArgs& p, EpExt<KIND>& x, int tid, int m0, int n0) {
-  if constexpr (EpExt<KIND>::EXT) {
+template <int KIND, int NIT>
+__device__ __forceinline__ void prefetch_rows(const GemmArgs& p, EpExt<KIND, NIT>& x, int tid, int m0, int n0) {
+  if constexpr (EpExt<KIND, NIT>::EXT) {
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
+    for (int it = 0; it < NIT; ++it) {
       const int c = tid + 512 * it;
       const int m = m0 + (c >> 5), n = n0 + (c & 31) * 8;
       x.v[it] = bf16x8{};
@@ -122,17 +123,24 @@ __device__ __forceinline__ void prefetch_rows(const GemmArgs& p, EpExt<KIND>& x,
     }
   }
 }
-template <int KIND>
-__device__ __forceinline__ void finish_rows(const GemmArgs& p, const EpExt<KIND>& x, const bf16* cb, int tid, int m0, int n0) {
-  constexpr bool EXT = EpExt<KIND>::EXT;
+template <int KIND, int NIT>
+__device__ __forceinline__ void finish_rows(const GemmArgs& p, const EpExt<KIND, NIT>& x, const bf16* cb, int tid, int m0, int n0) {
+  constexpr bool EXT = EpExt<KIND, NIT>::EXT;
+  constexpr int JW = NIT % 4 == 0 ? 4 : 2, HN = NIT / JW;      // rolled outer loop x unrolled inner loop (code size)
+  static_assert(HN >= 3 && HN <= 5, "nested selects below");
   const bf16x8* ext = x.v;
 #pragma unroll 1
-  for (int h = 0; h < 4; ++h)
+  for (int h = 0; h < HN; ++h)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int c = tid + 512 * (h * 4 + j);
+  for (int j = 0; j < JW; ++j) {
+    const int c = tid + 512 * (h * JW + j);
     bf16x8 ex = bf16x8{};
-    if constexpr (EXT) ex = h == 0 ? ext[j] : h == 1 ? ext[4 + j] : h == 2 ? ext[8 + j] : ext[12 + j];   // keeps the loop rolled (code size)
+    if constexpr (EXT) {     // nested register selects keep the loop rolled (written as one nested ?: on purpose: a chain of
+                             // separate selects gets folded back into an indexed load from a scratch copy of the array)
+      if constexpr (HN == 3) ex = h == 0 ? ext[j] : h == 1 ? ext[JW + j] : ext[2 * JW + j];
+      else if constexpr (HN == 4) ex = h == 0 ? ext[j] : h == 1 ? ext[JW + j] : h == 2 ? ext[2 * JW + j] : ext[3 * JW + j];
+      else ex = h == 0 ? ext[j] : h == 1 ? ext[JW + j] : h == 2 ? ext[2 * JW + j] : h == 3 ? ext[3 * JW + j] : ext[4 * JW + j];
+    }
     const int row = c >> 5, col = (c & 31) * 8;
     const int m = m0 + row, n = n0 + col;
     if (m < p.M && n < p.N) {
@@ -192,8 +200,16 @@ __device__ __forceinline__ i32x4 raw_rsrc(const void* ptr, uint32_t bytes) {
   return i32x4{(int)(uint32_t)a, (int)((uint32_t)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
 }
 
-template <bool TA, bool TB, bool KMAP>
+// MB1 = 16-row blocks in the SECOND 64-row half of a wave row (4: the 256-row tile).  MB1 = 2 / 1 give 192 / 160-row tiles
+// on the same ring, DMA schedule and barriers: a wave row then owns 64 + 16*MB1 tile rows, the unused rows of the second
+// A unit are out-of-range DMA lanes (zero fill, no traffic) and their LDS reads / MFMAs are not issued.  For problems
+// whose 256-row tiling leaves CUs idle (M = 5120, N = 2048: 160 tiles on 256 CUs; 160-row tiles: exactly 256).
+template <bool TA, bool TB, bool KMAP, int MB1 = 4>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
+  static_assert(MB1 == 4 || (!TA && !TB), "short tiles exist for the k-contiguous forward form only");
+  constexpr int WROWS = 64 + 16 * MB1;          // tile rows of one wave row
+  constexpr int TME = 2 * WROWS;                // tile rows
+  constexpr int NIT = TME / 16;
   __shared__ __attribute__((aligned(1024))) char smem[SMEM_BYTES];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -214,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   const int grp = pid / gsz, rem = pid - grp * gsz;
   const int gm = min(GM, p.tiles_m - grp * GM);
   const int tile_n = rem / gm, tile_m = grp * GM + (rem - tile_n * gm);
-  const int m0 = tile_m * TM, n0 = tile_n * TN;
+  const int m0 = tile_m * TME, n0 = tile_n * TN;
 
   const int kbeg = split * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
@@ -233,9 +249,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     if constexpr (!TA) {   // [128 rows][64 k] image: instruction (wave, j) covers unit rows 16*wave + 8*j + lane/8
       const int ur = wave * 16 + j * 8 + (lane >> 3);
       const int kc = (lane & 7) ^ (j * 4 + (lane >> 4));          // = chunk slot ^ ((ur >> 1) & 7)
-      const int mA = m0 + (ur >> 6) * 128 + (ur & 63);
+      const int mA = m0 + (ur >> 6) * WROWS + (ur & 63);
       vo[0][j] = mA < p.M ? (uint32_t)((map_row(p.amap, mA) * p.lda + kc * 8) * 2) : OOB;
-      vo[3][j] = mA + 64 < p.M ? (uint32_t)((map_row(p.amap, mA + 64) * p.lda + kc * 8) * 2) : OOB;
+      vo[3][j] = (ur & 63) < 16 * MB1 && mA + 64 < p.M ? (uint32_t)((map_row(p.amap, mA + 64) * p.lda + kc * 8) * 2) : OOB;
     } else {               // [64 k][128 cols] image: instruction (wave, j) covers k rows 8*wave + 4*j + lane/16
       const int f8 = (lane >> 4) | ((wave & 1) << 2);
       const int c = ((((lane & 15) >> 1) ^ f8) << 4) + (lane & 1) * 8;     // unit column of this lane's 8 elements
@@ -322,7 +338,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   auto read_a = [&](auto BUF, auto X) {     // unit X (0 or 3) of ring buffer BUF
     constexpr int bf = decltype(BUF)::value, x = decltype(X)::value;
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
+    for (int mb = 0; mb < (x == 3 ? MB1 : 4); ++mb)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         if constexpr (!TA) fa[mb][kk] = *(const bf16x8*)(smem + a_off[bf][kk] + x * UNIT + mb * 2048);
@@ -357,15 +373,52 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
 
-  auto mma = [&](auto MH, auto NH) {
-    constexpr int mh = decltype(MH)::value, nh = decltype(NH)::value;
+  // 4 MFMAs: row block mb of half mh against the 32-column half nh (both 16-column blocks, both k-steps)
+  auto mma_blk = [&](auto MH, auto MB, auto NH) {
+    constexpr int mh = decltype(MH)::value, mb = decltype(MB)::value, nh = decltype(NH)::value;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-          acc[mh][nh][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nh][nb][kk], fa[mb][kk], acc[mh][nh][mb][nb], 0, 0, 0);
+      for (int nb = 0; nb < 2; ++nb)
+        acc[mh][nh][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nh][nb][kk], fa[mb][kk], acc[mh][nh][mb][nb], 0, 0, 0);
+  };
+  auto mma = [&](auto MH, auto NH) {
+    mma_blk(MH, IC<0>{}, NH);
+    mma_blk(MH, IC<1>{}, NH);
+    mma_blk(MH, IC<2>{}, NH);
+    mma_blk(MH, IC<3>{}, NH);
+  };
+  // MFMA segment of phase j.  256-row tile: one 64 x 32 quadrant per phase, order (0,0) (0,1) (1,1) (1,0).  Short tiles:
+  // the second half has only MB1 row blocks, so whole quadrants would give 16/16/4/4 (8/8) MFMAs over phases that cost the
+  // same barriers and LDS latency; fragments stay in registers once read (A half 0: fa[0..3] from phase 0, fa[0..MB1-1]
+  // replaced by half 1 in phase 2; B nh0 from phase 0, nh1 from phase 1), so row block 3 of half 0 is deferred to phases
+  // 2 and 3: 12/12/8/8 (MB1 = 1) and 12/12/12/12 (MB1 = 2).
+  auto mma_phase = [&](auto J) {
+    constexpr int j = decltype(J)::value;
+    if constexpr (MB1 == 4) {
+      if constexpr (j == 0) mma(IC<0>{}, IC<0>{});
+      else if constexpr (j == 1) mma(IC<0>{}, IC<1>{});
+      else if constexpr (j == 2) mma(IC<1>{}, IC<1>{});
+      else mma(IC<1>{}, IC<0>{});
+    } else {
+      if constexpr (j == 0) {
+        mma_blk(IC<0>{}, IC<0>{}, IC<0>{});
+        mma_blk(IC<0>{}, IC<1>{}, IC<0>{});
+        mma_blk(IC<0>{}, IC<2>{}, IC<0>{});
+      } else if constexpr (j == 1) {
+        mma_blk(IC<0>{}, IC<0>{}, IC<1>{});
+        mma_blk(IC<0>{}, IC<1>{}, IC<1>{});
+        mma_blk(IC<0>{}, IC<2>{}, IC<1>{});
+      } else if constexpr (j == 2) {
+        mma_blk(IC<0>{}, IC<3>{}, IC<1>{});
+        mma_blk(IC<1>{}, IC<0>{}, IC<1>{});
+        if constexpr (MB1 == 2) mma_blk(IC<1>{}, IC<1>{}, IC<1>{});
+      } else {
+        mma_blk(IC<0>{}, IC<3>{}, IC<0>{});
+        mma_blk(IC<1>{}, IC<0>{}, IC<0>{});
+        if constexpr (MB1 == 2) mma_blk(IC<1>{}, IC<1>{}, IC<0>{});
+      }
+    }
   };
   auto colsum_mma = [&](auto MH) {
     constexpr int mh = decltype(MH)::value;
@@ -404,10 +457,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     SCHED_FENCE();
     // ---- MFMA segment: quadrant order (0,0) (0,1) (1,1) (1,0)
     __builtin_amdgcn_s_setprio(1);
-    if constexpr (j == 0) { mma(IC<0>{}, IC<0>{}); colsum_mma(IC<0>{}); }
-    else if constexpr (j == 1) mma(IC<0>{}, IC<1>{});
-    else if constexpr (j == 2) { mma(IC<1>{}, IC<1>{}); colsum_mma(IC<1>{}); }
-    else mma(IC<1>{}, IC<0>{});
+    mma_phase(J);
+    if constexpr (j == 0) colsum_mma(IC<0>{});
+    else if constexpr (j == 2) colsum_mma(IC<1>{});
     __builtin_amdgcn_s_setprio(0);
     SCHED_FENCE();
     __builtin_amdgcn_s_barrier();
@@ -456,7 +508,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < (a == 1 ? MB1 : 4); ++c)
 #pragma unroll
           for (int d = 0; d < 2; ++d) acc[a][b][c][d] *= alpha;
   }
@@ -512,8 +564,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   // activation itself); anything else takes the generic instance with the switches hoisted to one per 8-element chunk.
   auto epilogue = [&](auto kind) {
     constexpr int KIND = decltype(kind)::value;
-    EpExt<KIND> ext;
-    prefetch_rows<KIND>(p, ext, tid, m0, n0);      // global reads of the finish go out first
+    EpExt<KIND, NIT> ext;
+    prefetch_rows<KIND, NIT>(p, ext, tid, m0, n0);      // global reads of the finish go out first
     bf16* cb = (bf16*)smem;
 #pragma unroll
     for (int mh = 0; mh < 2; ++mh)
@@ -525,13 +577,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
           f32x4 bv = {0.f, 0.f, 0.f, 0.f};
           if (p.bias && n0 + col < p.N) bv = cvt4(*(const bf16x4*)(p.bias + n0 + col));
 #pragma unroll
-          for (int mb = 0; mb < 4; ++mb) {
-            const int row = wr * 128 + mh * 64 + mb * 16 + l15;
+          for (int mb = 0; mb < (mh == 1 ? MB1 : 4); ++mb) {
+            const int row = wr * WROWS + mh * 64 + mb * 16 + l15;
             *(bf16x4*)(cb + row * CPITCH + col) = cvt4(acc[mh][nh][mb][nb] + bv);
           }
         }
     __syncthreads();     // the staged tile is complete
-    finish_rows<KIND>(p, ext, cb, tid, m0, n0);
+    finish_rows<KIND, NIT>(p, ext, cb, tid, m0, n0);
   };
   const int cfg = (p.act ? 1 : 0) | (p.act_bwd ? 2 : 0) | (p.drop_thr ? 4 : 0) | (p.residual ? 8 : 0) | (p.accumulate ? 16 : 0) |
                   (p.preact ? 32 : 0) | (p.tap_out && !(p.residual && !p.act && !p.act_bwd && !p.drop_thr && !p.accumulate && !p.preact) ? 64 : 0);
@@ -553,15 +605,37 @@ bool mpv_gemm256_try_launch(const GemmArgs& g0, int transA, int transB, hipStrea
   GemmArgs g = g0;
   if (g.K % TK != 0 || g.k_per_split % TK != 0) return false;
   if (g.tail_g > 1) return false;
-  g.tiles_m = (g.M + TM - 1) / TM;
   g.tiles_n = (g.N + TN - 1) / TN;
-  g.nwg = g.tiles_m * g.tiles_n;
   g.gm = g.gm > 0 ? g.gm : 4;
-  const dim3 grid((unsigned)(g.nwg * g.splits)), block(512);
   const bool km = (transA || transB) && g.kmap.group != 0;
-  if (!transA && !transB)
-    hipLaunchKernelGGL((gemm256_kernel<false, false, false>), grid, block, 0, stream, g);
-  else if (!transA && transB && !km)
+  // tile rows: 256, or 192 / 160 (forward form, bf16 output, no split-K) when that tiling fills the chip better.  Cost =
+  // rounds of one workgroup per CU x relative time of a tile (measured main-loop time per K-tile: 1.0 / 0.80 / 0.73 --
+  // the short variants keep the barrier structure and shed MFMAs only in two of the four phases).
+  int rows = 256;
+  if (!transA && !transB && !g.out_f32 && g.splits == 1) {
+    if (g.tile_rows == 192 || g.tile_rows == 160) {
+      rows = g.tile_rows;
+    } else if (g.tile_rows == 0) {
+      static int ncu = 0;
+      if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+      }
+      auto cost = [&](int r, float rel) { return (float)(((long long)((g.M + r - 1) / r) * g.tiles_n + ncu - 1) / ncu) * rel; };
+      const float c256 = cost(256, 1.0f), c192 = cost(192, 0.80f), c160 = cost(160, 0.73f);
+      if (c160 < 0.95f * c256 && c160 <= c192) rows = 160;
+      else if (c192 < 0.95f * c256) rows = 192;
+    }
+  }
+  g.tiles_m = (g.M + rows - 1) / rows;
+  g.nwg = g.tiles_m * g.tiles_n;
+  const dim3 grid((unsigned)(g.nwg * g.splits)), block(512);
+  if (!transA && !transB) {
+    if (rows == 160) hipLaunchKernelGGL((gemm256_kernel<false, false, false, 1>), grid, block, 0, stream, g);
+    else if (rows == 192) hipLaunchKernelGGL((gemm256_kernel<false, false, false, 2>), grid, block, 0, stream, g);
+    else hipLaunchKernelGGL((gemm256_kernel<false, false, false>), grid, block, 0, stream, g);
+  } else if (!transA && transB && !km)
     hipLaunchKernelGGL((gemm256_kernel<false, true, false>), grid, block, 0, stream, g);
   else if (!transA && transB)
     hipLaunchKernelGGL((gemm256_kernel<false, true, true>), grid, block, 0, stream, g);
