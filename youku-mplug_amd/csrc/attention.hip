@@ -679,8 +679,11 @@ __device__ __forceinline__ int region_bytes(int rows, int pitch) { return (((row
 // NTC > 0: non-causal with exactly NTC key tiles for every wave, known at compile time -- the tile loops become
 // straight-line code (no per-tile branch), so the scheduler can hoist the next tile's LDS reads and MFMA chain above the
 // current tile's VALU work.  NTC == 0: tile count per wave decided at run time (causal, other lengths).
-template <int HD, int NTC = 0>
-__global__ __launch_bounds__(512) void attn_fwd_res_kernel(const AttnArgs p) {
+// NTMAX / THREADS / WPE: an instance for short sequences (<= 32 * NTMAX keys) keeps only NTMAX score tiles and is compiled
+// for WPE waves per SIMD, so that two workgroups share a CU (GPT: 160 keys, 5 waves, head_dim 64 -- one workgroup per CU
+// left the kernel latency-bound: MFMA pipe 4 % busy).
+template <int HD, int NTC = 0, int NTMAX = 8, int THREADS = 512, int WPE = 1>
+__global__ __launch_bounds__(THREADS, WPE) void attn_fwd_res_kernel(const AttnArgs p) {
   constexpr int NS = HD / 16;
   constexpr int NDT = (HD + 31) / 32;
   extern __shared__ __attribute__((aligned(1024))) char rsm[];
@@ -719,7 +722,7 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(const AttnArgs p) {
   // maximum is exact before the first exponential, every exponential is evaluated once, and K is read from LDS once
   // (the earlier form ran QK^T twice: once for the statistics, once for the probabilities).  Probabilities go to the
   // PV MFMAs unnormalised (<= 1, bf16); 1/l is applied to the 32 x hd output instead of the 32 x sk scores.
-  constexpr int NTM = NTC ? NTC : 8;
+  constexpr int NTM = NTC ? NTC : NTMAX;
   f32x16 st[NTM];
   float mx = -INFINITY;
 #pragma unroll
@@ -806,8 +809,8 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(const AttnArgs p) {
 }
 
 // NTC as in the forward kernel: compile-time key-tile count (non-causal, no dropout) -> straight-line tile loop.
-template <int HD, int NTC = 0>
-__global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const AttnArgs p) {
+template <int HD, int NTC = 0, int THREADS = 512, int WPE = 1>
+__global__ __launch_bounds__(THREADS, WPE) void attn_bwd_dq_res_kernel(const AttnArgs p) {
   constexpr int NS = HD / 16;
   constexpr int NDT = (HD + 31) / 32;
   extern __shared__ __attribute__((aligned(1024))) char rsm[];
@@ -930,8 +933,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const AttnArgs p) 
 // allocated 336 VGPRs: one 4-wave workgroup per CU, two workgroups per (batch, head) each re-loading Q and dO.)
 // (head_dim 64 fits both accumulator sets in 256 VGPRs and keeps one pass: measured 80 us against 106 us for the two-pass
 // form on the GPT shape)
-template <int HD, int THREADS>
-__global__ __launch_bounds__(THREADS) void attn_bwd_dkv_res_kernel(const AttnArgs p) {
+template <int HD, int THREADS, int WPE = 1>
+__global__ __launch_bounds__(THREADS, WPE) void attn_bwd_dkv_res_kernel(const AttnArgs p) {
   constexpr int NS = HD / 16;
   constexpr int NDT = (HD + 31) / 32;
   extern __shared__ __attribute__((aligned(1024))) char rsm[];
@@ -1023,8 +1026,8 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_dkv_res_kernel(const AttnArg
     f32x16 s, dp;
 #pragma unroll
     for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
-    int vo = vfoff;
-    asm volatile("" : "+v"(vo));      // opaque per iteration: otherwise the loop-invariant V fragment reads are hoisted back into registers
+    int vo = vfoff, lane_t = lane;      // lane_t: the per-element row indices / dropout counters derived from it are loop-invariant
+    asm volatile("" : "+v"(vo), "+v"(lane_t));      // opaque per iteration: otherwise the loop-invariant V fragment reads are hoisted back into registers
 #pragma unroll
     for (int st = 0; st < NS; ++st) {
       s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, qroff + qt * 32 * ROWB, st), kf[st], s, 0, 0, 0);
@@ -1042,7 +1045,7 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_dkv_res_kernel(const AttnArg
 #pragma unroll
       for (int qh = 0; qh < 2; ++qh) {
         const int q4 = 2 * ks + qh;
-        const int qb4 = qt * 32 + 8 * q4 + 4 * (lane >> 5);
+        const int qb4 = qt * 32 + 8 * q4 + 4 * (lane_t >> 5);
         const f32x4 l4 = *(const f32x4*)(sl + qb4), d4 = *(const f32x4*)(sl + qrows + qb4);
         if (interior) {
 #pragma unroll
@@ -1348,9 +1351,9 @@ static void allow_lds(K kernel) {
 static void res_attr_once() {
   static bool done = false;
   if (done) return;
-  allow_lds(attn_fwd_res_kernel<64>); allow_lds(attn_fwd_res_kernel<80>); allow_lds(attn_fwd_res_kernel<96>); allow_lds(attn_fwd_res_kernel<96, 7>);
-  allow_lds(attn_bwd_dq_res_kernel<64>); allow_lds(attn_bwd_dq_res_kernel<80>); allow_lds(attn_bwd_dq_res_kernel<96>); allow_lds(attn_bwd_dq_res_kernel<96, 7>);
-  allow_lds(attn_bwd_dkv_res_kernel<64, 512>); allow_lds(attn_bwd_dkv_res_kernel<80, 512>); allow_lds(attn_bwd_dkv_res_kernel<96, 512>);
+  allow_lds(attn_fwd_res_kernel<64>); allow_lds(attn_fwd_res_kernel<64, 0, 5, 320, 3>); allow_lds(attn_fwd_res_kernel<80>); allow_lds(attn_fwd_res_kernel<96>); allow_lds(attn_fwd_res_kernel<96, 7>);
+  allow_lds(attn_bwd_dq_res_kernel<64>); allow_lds(attn_bwd_dq_res_kernel<64, 0, 320, 3>); allow_lds(attn_bwd_dq_res_kernel<80>); allow_lds(attn_bwd_dq_res_kernel<96>); allow_lds(attn_bwd_dq_res_kernel<96, 7>);
+  allow_lds(attn_bwd_dkv_res_kernel<64, 512>); allow_lds(attn_bwd_dkv_res_kernel<64, 320, 3>); allow_lds(attn_bwd_dkv_res_kernel<80, 512>); allow_lds(attn_bwd_dkv_res_kernel<96, 512>);
   done = true;
 }
 
@@ -1372,7 +1375,10 @@ extern "C" int mpv_attn_fwd(const mpv_attn_desc* d, hipStream_t stream) {
     dim3 grid((d->sq + 32 * nw - 1) / (32 * nw), gy), block(64 * nw);
     const size_t lds = res_lds_bytes(d->sk, false);
     switch (d->head_dim <= 64 ? 64 : d->head_dim <= 80 ? 80 : 96) {
-      case 64: hipLaunchKernelGGL((attn_fwd_res_kernel<64>), grid, block, lds, stream, a); break;
+      case 64:
+        if (d->sk <= 160 && nw <= 5) hipLaunchKernelGGL((attn_fwd_res_kernel<64, 0, 5, 320, 3>), grid, block, lds, stream, a);
+        else hipLaunchKernelGGL((attn_fwd_res_kernel<64>), grid, block, lds, stream, a);
+        break;
       case 80: hipLaunchKernelGGL((attn_fwd_res_kernel<80>), grid, block, lds, stream, a); break;
       default:
         if (!d->causal && d->dropout_p == 0.f && (d->sk + 31) / 32 == 7) hipLaunchKernelGGL((attn_fwd_res_kernel<96, 7>), grid, block, lds, stream, a);   // ViT-B/16 spatial: 197 keys
@@ -1413,8 +1419,13 @@ extern "C" int mpv_attn_bwd(const mpv_attn_desc* d, const void* dO, void* dq, vo
     const size_t lq = res_lds_bytes(d->sk, false), lk = res_lds_bytes(d->sq, true) + (d->head_dim > 64 ? res_region(d->sk, ROWB) : 0);
     switch (d->head_dim <= 64 ? 64 : d->head_dim <= 80 ? 80 : 96) {
       case 64:
-        hipLaunchKernelGGL((attn_bwd_dq_res_kernel<64>), gq, dim3(64 * nw), lq, stream, a);
-        hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<64, 512>), gk, dim3(64 * nwk), lk, stream, a);
+        if (d->sk <= 160 && d->sq <= 160 && nw <= 5 && nwk <= 5) {     // two workgroups per CU (see attn_fwd_res_kernel)
+          hipLaunchKernelGGL((attn_bwd_dq_res_kernel<64, 0, 320, 3>), gq, dim3(64 * nw), lq, stream, a);
+          hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<64, 320, 3>), gk, dim3(64 * nwk), lk, stream, a);
+        } else {
+          hipLaunchKernelGGL((attn_bwd_dq_res_kernel<64>), gq, dim3(64 * nw), lq, stream, a);
+          hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<64, 512>), gk, dim3(64 * nwk), lk, stream, a);
+        }
         break;
       case 80:
         hipLaunchKernelGGL((attn_bwd_dq_res_kernel<80>), gq, dim3(64 * nw), lq, stream, a);
