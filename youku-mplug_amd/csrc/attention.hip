@@ -1103,11 +1103,14 @@ struct TempArgs {
 // one wave per (sequence, head); T <= 16, hd <= 96 (multiple of 4).  Rows live in LDS as fp32 with a pitch of
 // hd+4 floats so every inner product runs on 16-byte ds_read_b128 operands (conflict-free across rows).
 // LDS floats per wave: (3|4)*T*(hd+4) + (1|2)*T*(T+1).
-template <bool BWD>
+// TC / HDC > 0: T and head_dim known at compile time (the ViT-B/16 instance: 8 frames, head_dim 96).  With run-time trip
+// counts none of the inner loops unrolls, every iteration waits on its own LDS reads (~130 clocks each: measured 15k
+// clocks per problem for ~450 instructions); unrolled, the reads of 8 iterations are in flight together.
+template <bool BWD, int TC = 0, int HDC = 0>
 __global__ __launch_bounds__(256) void temporal_attn_kernel(const TempArgs p) {
   extern __shared__ __attribute__((aligned(16))) float tsm[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int T = p.T, hd = p.hd, ld = hd + 4, D = p.heads * hd, H4 = hd / 4;
+  const int T = TC ? TC : p.T, hd = HDC ? HDC : p.hd, ld = hd + 4, D = p.heads * hd, H4 = hd / 4;
   const int per_wave = (BWD ? 4 : 3) * T * ld + (BWD ? 2 : 1) * T * (T + 1);
   float* qs = tsm + wave * ((per_wave + 3) & ~3);
   float* ks = qs + T * ld;
@@ -1121,6 +1124,7 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TempArgs p) {
     const long long seq = pr / p.heads;
     const long long o = seq / p.n_inner, i = seq % p.n_inner;
     const long long row0 = o * p.outer_stride + p.inner_offset + i;
+#pragma unroll
     for (int x = lane; x < T * H4; x += 64) {
       const int t = x / H4, c4 = x - t * H4;
       const bf16* src = p.qkv + (row0 + t * p.t_stride) * (3LL * D) + h * hd + c4 * 4;
@@ -1133,9 +1137,11 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TempArgs p) {
         *(f32x4*)(dos + t * ld + c4 * 4) = cvt4(*(const bf16x4*)(p.dout + (row0 + t * p.t_stride) * (long long)D + h * hd + c4 * 4));
     }
     WAVE_SYNC();
+#pragma unroll
     for (int x = lane; x < T * T; x += 64) {
       const int a = x / T, bb = x - a * T;
       f32x4 acc4 = {0.f, 0.f, 0.f, 0.f}, dp4 = acc4;
+#pragma unroll 8
       for (int c4 = 0; c4 < H4; ++c4) {
         const f32x4 kv = *(const f32x4*)(ks + bb * ld + c4 * 4);
         acc4 += *(const f32x4*)(qs + a * ld + c4 * 4) * kv;
@@ -1147,28 +1153,35 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TempArgs p) {
     WAVE_SYNC();
     if (lane < T) {
       float mx = -INFINITY;
+#pragma unroll
       for (int j = 0; j < T; ++j) mx = fmaxf(mx, ps[lane * (T + 1) + j]);
       float sum = 0.f;
+#pragma unroll
       for (int j = 0; j < T; ++j) sum += __expf(ps[lane * (T + 1) + j] - mx);
       const float inv = 1.0f / sum;
       float dl = 0.f;
+#pragma unroll
       for (int j = 0; j < T; ++j) {
         const float pv = __expf(ps[lane * (T + 1) + j] - mx) * inv;
         ps[lane * (T + 1) + j] = BWD ? pv : bf2f(f2bf(pv));      // forward: probs cast to bf16 (:201)
         if constexpr (BWD) dl += pv * dss[lane * (T + 1) + j];
       }
       if constexpr (BWD)                                           // dS = P * (dP - rowsum(P*dP))
+#pragma unroll
         for (int j = 0; j < T; ++j) dss[lane * (T + 1) + j] = ps[lane * (T + 1) + j] * (dss[lane * (T + 1) + j] - dl);
     }
     WAVE_SYNC();
+#pragma unroll
     for (int x = lane; x < T * H4; x += 64) {
       const int a = x / H4, c4 = x - a * H4;
       if constexpr (!BWD) {
         f32x4 o4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
         for (int j = 0; j < T; ++j) o4 += *(const f32x4*)(vs + j * ld + c4 * 4) * ps[a * (T + 1) + j];
         *(bf16x4*)(p.out + (row0 + a * p.t_stride) * (long long)D + h * hd + c4 * 4) = cvt4(o4);
       } else {
         f32x4 dq = {0.f, 0.f, 0.f, 0.f}, dk = dq, dv = dq;
+#pragma unroll
         for (int j = 0; j < T; ++j) {
           dq += *(const f32x4*)(ks + j * ld + c4 * 4) * dss[a * (T + 1) + j];
           dk += *(const f32x4*)(qs + j * ld + c4 * 4) * dss[j * (T + 1) + a];
@@ -1494,9 +1507,12 @@ extern "C" int mpv_temporal_attn_fwd(const void* qkv, void* out, int n_outer, in
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)temporal_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void*)temporal_attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)temporal_attn_kernel<false, 8, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)temporal_attn_kernel<true, 8, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL((temporal_attn_kernel<false>), dim3(grid), dim3(64 * nwv), lds, stream, t);
+  if (T == 8 && head_dim == 96) hipLaunchKernelGGL((temporal_attn_kernel<false, 8, 96>), dim3(grid), dim3(64 * nwv), lds, stream, t);
+  else hipLaunchKernelGGL((temporal_attn_kernel<false>), dim3(grid), dim3(64 * nwv), lds, stream, t);
   return mpv_check_launch("mpv_temporal_attn_fwd");
 }
 
@@ -1519,9 +1535,12 @@ extern "C" int mpv_temporal_attn_bwd(const void* qkv, const void* dout, void* dq
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)temporal_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void*)temporal_attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)temporal_attn_kernel<false, 8, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)temporal_attn_kernel<true, 8, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL((temporal_attn_kernel<true>), dim3(grid), dim3(64 * nwv), lds, stream, t);
+  if (T == 8 && head_dim == 96) hipLaunchKernelGGL((temporal_attn_kernel<true, 8, 96>), dim3(grid), dim3(64 * nwv), lds, stream, t);
+  else hipLaunchKernelGGL((temporal_attn_kernel<true>), dim3(grid), dim3(64 * nwv), lds, stream, t);
   return mpv_check_launch("mpv_temporal_attn_bwd");
 }
 
