@@ -62,7 +62,9 @@ def algorithmic_train_flops(B, T, L, s=Shapes):
     Sk = 1 + T * N
     pool = 2 * B * Q * D * D + 2 * B * Sk * D * 2 * D + 4 * B * Q * (Sk + 1) * D + 2 * B * Q * D * D + 4 * B * Q * D * 4 * D
     fc = 2 * B * Q * D * H
-    gpt = Lyr * 2 * B * S * H * (3 * H + H + 2 * s.ffn) + Lyr * 4 * B * S * S * H + 2 * B * S * H * V
+    # LM head on the L text positions only: the Q query slots are always masked (distributed_gpt3.py:142-159), their logits
+    # feed nothing (the reference evaluates them anyway: 2*B*S*H*V); counted as executed here, so step_frac is not inflated
+    gpt = Lyr * 2 * B * S * H * (3 * H + H + 2 * s.ffn) + Lyr * 4 * B * S * S * H + 2 * B * L * H * V
     return 3.0 * (vit + pool + fc) + 2.0 * gpt
 
 

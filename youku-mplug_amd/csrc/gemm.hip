@@ -587,7 +587,13 @@ constexpr size_t TAIL_WS_BYTES = (size_t)SLOTS * BM * BN * sizeof(float);   // 3
 constexpr size_t TAIL_CNT_BYTES = SLOTS * sizeof(unsigned);                  // + their arrival counters, in the caller's workspace
 
 extern "C" size_t mpv_gemm_workspace_size(int64_t M, int64_t N, int64_t K, int transA, int transB) {
-  if (!(transA && transB)) return TAIL_WS_BYTES + TAIL_CNT_BYTES;
+  if (!(transA && transB)) {
+    // forward / dgrad products with few output tiles and a long reduction (the LM head's dgrad on the loss window:
+    // 1024 x 2048 x 51200) are split along K like a wgrad: fp32 partials of up to 16 splits
+    const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
+    const size_t part = (t256 * 2 <= 256 && K >= 4096) ? (size_t)M * N * sizeof(float) * 16 : 0;
+    return (part > TAIL_WS_BYTES ? part : TAIL_WS_BYTES) + TAIL_CNT_BYTES;
+  }
   // wgrad: split the (long) reduction so that >= ~2 workgroups per CU exist (+ the per-split column sums of the fused
   // bias gradient)
   const size_t w = (size_t)M * N * sizeof(float) * 32 + (size_t)M * sizeof(float) * 64;
@@ -738,6 +744,12 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
     const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
     int s256 = 1;
     if (transA && transB && !g.out_f32) s256 = choose_splitk256(t256, K, M, N, workspace ? workspace_bytes : 0);
+    else if (!g.out_f32 && t256 * 2 <= 256 && K >= 4096 && !g.bias && !g.act && !g.residual && !g.act_bwd && !g.drop_thr && !g.tap_out &&
+             !g.preact && g.cmap.group == 0 && ldc == N) {
+      // few tiles, long reduction, plain epilogue: split-K over the idle CUs (at most the 16 splits the workspace size allows for)
+      s256 = choose_splitk256(t256, K, M, N, workspace ? workspace_bytes : 0);
+      if (s256 > 16) s256 = 16;
+    }
     {   // measured on MI355X (tools/gemm_ab.py): the 256x256 kernel wins on every eligible shape of the path, also when
         // its tiles fill only 5/8 of the CUs (M = 5120, N = 2048: 959 vs 764 TFLOP/s)
       GemmArgs h = g;

@@ -171,9 +171,14 @@ class DistributedGPT3(nn.Module):
     # -------------------------------------------------------------- explicit forward / backward
     def forward_lm(self, query_features: Optional[torch.Tensor], ids: torch.Tensor, labels: Optional[torch.Tensor],
                    loss_mask: Optional[torch.Tensor], tape: dict, want_logits: bool = False, hidden_only: bool = False,
-                   pass_index: int = 0):
+                   pass_index: int = 0, loss_window: Optional[tuple] = None):
         """query_features [B*Q, H] (or None), ids [B,L] int64, labels [B,S] int64, loss_mask [B,S-1].
-        Returns dict(loss fp32 scalar, losses [B,S-1] fp32, logits?, last_hidden_state [B,S,H])."""
+        Returns dict(loss fp32 scalar, losses [B,S-1] fp32, logits?, last_hidden_state [B,S,H]).
+        loss_window = (start, length): the caller's promise that loss_mask is zero outside positions
+        [start, start + length) of every sequence (pre-training: the Q query slots in front are always masked,
+        models/distributed_gpt3.py:142-159).  The tied LM head, the CE and the LM head's dgrad then run on those
+        B * length rows only -- the reference evaluates all B * S rows of [S, V] logits and multiplies 80 % of the
+        per-token losses by zero; the loss and every gradient are unchanged (those rows' dlogits are exactly 0)."""
         cfg = self.config
         lm = self.dist_model.language_model
         B, L = ids.shape
@@ -214,19 +219,34 @@ class DistributedGPT3(nn.Module):
         fl = lm.encoder.final_layernorm
         xf, mf, rf = ops.layernorm_fwd(h, fl.weight, fl.bias, fl.eps, R, H)
         if hidden_only:     # only last_hidden_state is consumed (models/distributed_gpt3.py:958, 583-584, 1149-1150)
-            tape.update(B=B, Q=Q, L=L, S=S, layers=layers, h_last=h, sf=(mf, rf), dlogits=None, lay=lay, scale=scale, seed=seed,
-                        p_h=p_h, p_a=p_a)
+            tape.update(B=B, Q=Q, L=L, S=S, layers=layers, h_last=h, sf=(mf, rf), dlogits=None, lm_window=None, lay=lay, scale=scale,
+                        seed=seed, p_h=p_h, p_a=p_a)
             return dict(last_hidden_state=xf.view(B, S, H))
-        logits = ops.gemm(xf, lm.embedding.word_embeddings.weight, R, V, H)          # tied LM head (:1348-1350)
         # masked mean of per-token CE over positions 0..S-2 (:1615-1617)
         lmf = loss_mask.to(torch.float32)
         denom = lmf.sum()
         w = torch.zeros((B, S), dtype=torch.float32, device=h.device)
         w[:, :S - 1] = lmf / denom
-        keep_logits = logits.clone() if want_logits else None
-        losses, loss = ops.cross_entropy(logits, labels.contiguous().view(-1), w.view(-1), R, V, dlogits=logits)
-        tape.update(B=B, Q=Q, L=L, S=S, layers=layers, h_last=h, sf=(mf, rf), dlogits=logits, lay=lay, scale=scale, seed=seed,
-                    p_h=p_h, p_a=p_a)
+        window = None
+        if loss_window is not None and not want_logits:
+            w0, wl = int(loss_window[0]), int(loss_window[1])
+            if 0 <= w0 and w0 + wl <= S and 0 < wl < S:
+                window = (w0, wl)
+        if window is not None:
+            w0, wl = window
+            Rw = B * wl
+            logits = ops.gemm(xf, lm.embedding.word_embeddings.weight, Rw, V, H, amap=(wl, S, w0))      # rows b*S + w0 + j
+            losses_w, loss = ops.cross_entropy(logits, labels[:, w0:w0 + wl].contiguous().view(-1),
+                                               w[:, w0:w0 + wl].contiguous().view(-1), Rw, V, dlogits=logits)
+            losses = torch.zeros((B, S), dtype=torch.float32, device=h.device)
+            losses[:, w0:w0 + wl] = losses_w.view(B, wl)
+            keep_logits = None
+        else:
+            logits = ops.gemm(xf, lm.embedding.word_embeddings.weight, R, V, H)          # tied LM head (:1348-1350)
+            keep_logits = logits.clone() if want_logits else None
+            losses, loss = ops.cross_entropy(logits, labels.contiguous().view(-1), w.view(-1), R, V, dlogits=logits)
+        tape.update(B=B, Q=Q, L=L, S=S, layers=layers, h_last=h, sf=(mf, rf), dlogits=logits, lm_window=window, lay=lay, scale=scale,
+                    seed=seed, p_h=p_h, p_a=p_a)
         out = dict(loss=loss, losses=losses.view(B, S)[:, :S - 1], last_hidden_state=xf.view(B, S, H))
         if want_logits:
             out["logits"] = keep_logits.view(B, S, V)
@@ -257,7 +277,18 @@ class DistributedGPT3(nn.Module):
         p_h, p_a, seed, lay, scale = tape["p_h"], tape["p_a"], tape["seed"], tape["lay"], tape["scale"]
         nl = len(lm.encoder.layers)
         fl = lm.encoder.final_layernorm
-        if tape["dlogits"] is not None:
+        if tape["dlogits"] is not None and tape.get("lm_window") is not None:
+            # LM head dgrad on the loss window only (few output tiles, K = V: split along K inside mpv_gemm_bf16), scattered
+            # into a zero d(final-LN output); rows outside the window carry no loss gradient
+            w0, wl = tape["lm_window"]
+            dxw = self._dgrad(tape["dlogits"], lm.embedding.word_embeddings.weight, B * wl, H, V, alpha_dev=grad_loss)
+            dxf = torch.zeros((R, H), dtype=torch.bfloat16, device=dxw.device) if d_last_hidden is None else d_last_hidden.clone()
+            if d_last_hidden is None:
+                ops.copy_rows(dxw, dxf, B * wl, H, dmap=(wl, S, w0))
+            else:
+                dxf.view(B, S, H)[:, w0:w0 + wl] += dxw.view(B, wl, H)
+            tape["dlogits"] = None
+        elif tape["dlogits"] is not None:
             dxf = self._dgrad(tape["dlogits"], lm.embedding.word_embeddings.weight, R, H, V, alpha_dev=grad_loss,
                               residual=d_last_hidden)
             tape["dlogits"] = None

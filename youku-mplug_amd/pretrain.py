@@ -129,7 +129,9 @@ class DistributedGPT3_Pretrain(nn.Module):
             tla = tla.clone()
             tla[torch.arange(tla.shape[1], device=ids.device)[None] < pl] = 0
         loss_mask = torch.cat([torch.zeros((B, Q), dtype=torch.long, device=ids.device), tla], dim=1)
-        out = self.text_decoder.forward_lm(qf, ids, targets, loss_mask, tape["gpt"], want_logits=want_logits)
+        # the Q query slots in front never carry loss (zeros above): LM head + CE on the L text positions only
+        out = self.text_decoder.forward_lm(qf, ids, targets, loss_mask, tape["gpt"], want_logits=want_logits,
+                                           loss_window=(Q, ids.shape[1]))
         tape["out"] = out
         return out["loss"], tape
 
