@@ -92,6 +92,13 @@ int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, int64_t N, i
                   int64_t ldc, int transA, int transB, const mpv_gemm_epilogue* ep, void* workspace,
                   size_t workspace_bytes, mpv_stream_t stream);
 
+/* Test / measurement hook: the row-band plan mpv_gemm_bf16 uses for an M x N x K forward or dgrad product on a chip of
+ * `ncu` compute units (csrc/gemm256.hip: rows are cut into up to three bands of 256-, 192- and 160-row tiles, one launch
+ * each, so that no launch ends in a mostly empty round of workgroups).  preact / ext_rows: the epilogue also writes the
+ * pre-activation / reads residual or GELU' rows.  out6[2i] = tile rows, out6[2i+1] = m-tiles of band i (row order);
+ * returns the number of bands.  Host-only, launches nothing. */
+int mpv_gemm_plan_bands(int64_t M, int64_t N, int64_t K, int ncu, int preact, int ext_rows, int* out6);
+
 /* ------------------------------------------------------------------------------------------
  * LayerNorm, fp32 statistics, bf16 in/out.  Replaces LayerNormWithForceFP32
  * (models/vision_transformer.py:69-71) and megatron MixedFusedLayerNorm

@@ -202,3 +202,74 @@ def test_gemm256_short_tile_rows(dev, rows, M, N, K):
     assert torch.equal(d1, d2)
     r1 = ops.gemm(a, w, M, N, K, bias=bias, residual=res, tile_hint=rows)
     assert torch.equal(r1, ops.gemm(a, w, M, N, K, bias=bias, residual=res, tile_hint=256))
+
+
+@pytest.mark.parametrize("M,N,K,tb", [(50432, 768, 768, 0), (50176, 768, 768, 0), (50432, 768, 2304, 1), (50432, 3072, 768, 0), (5120, 8192, 2048, 0),
+                                       (5120, 8192, 2048, 1), (12352, 768, 192, 1), (40000, 520, 128, 0)])
+def test_gemm256_row_bands(dev, M, N, K, tb):
+    """Auto tile choice cuts the rows into bands of 256- / 192- / 160-row tiles, one launch each (csrc/gemm256.hip,
+    plan_bands).  Every element keeps its K order, so each epilogue must be bit-identical to the pinned 256-row launch;
+    fp32 check on top, and the plan the library reports must be a multi-band one for the ViT / GPT shapes it exists for."""
+    from youku_mplug_amd import _lib, ops
+    from youku_mplug_amd.ops import ACT_GELU_ERF
+    import ctypes
+    out6 = (ctypes.c_int * 6)()
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    nb = _lib.lib().mpv_gemm_plan_bands(M, N, K, ncu, 0, 0, out6)
+    if (M, N) in ((50432, 768), (5120, 8192)):
+        assert nb >= 2, f"expected a multi-band plan for {M}x{N}x{K}: {list(out6)}"
+    a = rn(M, K, dev=dev, seed=81)
+    w = rn(K, N, dev=dev, seed=82, scale=0.1) if tb else rn(N, K, dev=dev, seed=82, scale=0.1)
+    bias, res = rn(N, dev=dev, seed=83), rn(M, N, dev=dev, seed=84)
+    kw = dict(trans_b=bool(tb))
+    o0 = ops.gemm(a, w, M, N, K, **kw)
+    o256 = ops.gemm(a, w, M, N, K, tile_hint=256, **kw)
+    assert torch.equal(o0, o256), "plain"
+    close(o0, a.float() @ (w.float() if tb else w.float().t()), 1e-2, "bands vs fp32")
+    assert torch.equal(ops.gemm(a, w, M, N, K, bias=bias, residual=res, **kw), ops.gemm(a, w, M, N, K, bias=bias, residual=res, tile_hint=256, **kw))
+    d0 = ops.gemm(a, w, M, N, K, bias=bias, residual=res, dropout_p=0.1, seed=5, offset=9, **kw)
+    assert torch.equal(d0, ops.gemm(a, w, M, N, K, bias=bias, residual=res, dropout_p=0.1, seed=5, offset=9, tile_hint=256, **kw))
+    assert torch.equal(ops.gemm(a, w, M, N, K, act_bwd_z=res, act_bwd=ACT_GELU_ERF, **kw),
+                       ops.gemm(a, w, M, N, K, act_bwd_z=res, act_bwd=ACT_GELU_ERF, tile_hint=256, **kw))
+    z0, z1 = torch.empty_like(o0), torch.empty_like(o0)
+    h0 = ops.gemm(a, w, M, N, K, bias=bias, act=ACT_GELU_ERF, preact_out=z0, **kw)
+    h1 = ops.gemm(a, w, M, N, K, bias=bias, act=ACT_GELU_ERF, preact_out=z1, tile_hint=256, **kw)
+    assert torch.equal(h0, h1) and torch.equal(z0, z1)
+    for _ in range(5):
+        assert torch.equal(o0, ops.gemm(a, w, M, N, K, **kw))
+
+
+def test_gemm256_row_bands_mapped_rows_and_tap(dev):
+    """Bands with gathered A rows / scattered C rows (token rows around the per-frame cls slot) and the row tap of the
+    spatial projection: band boundaries are logical rows, the maps apply per row as in a single launch."""
+    from youku_mplug_amd import ops
+    BT, N1, D, Nout = 256, 197, 256, 768
+    n = N1 - 1
+    rows = BT * n                                   # 50176 logical rows in a 50432-row stream
+    tok = (n, N1, 1)
+    x, w = rn(BT * N1, D, dev=dev, seed=85), rn(Nout, D, dev=dev, seed=86, scale=0.1)
+    res = rn(BT * N1, Nout, dev=dev, seed=87)
+    o0 = torch.zeros(BT * N1, Nout, dtype=torch.bfloat16, device=dev)
+    o1 = torch.zeros_like(o0)
+    ops.gemm(x, w, rows, Nout, D, out=o0, amap=tok, cmap=tok, residual=res)
+    ops.gemm(x, w, rows, Nout, D, out=o1, amap=tok, cmap=tok, residual=res, tile_hint=256)
+    assert torch.equal(o0, o1)
+    assert o0[::N1].abs().max().item() == 0.0, "cls slots must be untouched"
+    M = BT * N1
+    t0 = torch.zeros(BT, Nout, dtype=torch.bfloat16, device=dev)
+    t1 = torch.zeros_like(t0)
+    p0 = ops.gemm(x, w, M, Nout, D, residual=res, row_tap_out=t0, row_tap_group=N1)
+    p1 = ops.gemm(x, w, M, Nout, D, residual=res, row_tap_out=t1, row_tap_group=N1, tile_hint=256)
+    assert torch.equal(p0, p1) and torch.equal(t0, t1)
+    close(t0, (x.float() @ w.float().t())[::N1], 1e-2, "row tap")
+
+
+@pytest.mark.parametrize("rows", [192, 160])
+def test_gemm256_short_tile_rows_dgrad(dev, rows):
+    """192- / 160-row tiles with the reduction-slow B operand (dgrad form), bit-identical to the 256-row tile."""
+    from youku_mplug_amd import ops
+    for (M, N, K) in [(160, 256, 64), (1000, 520, 192), (2560, 768, 2304)]:
+        dy, w = rn(M, K, dev=dev, seed=75), rn(K, N, dev=dev, seed=76, scale=0.2)
+        out = ops.gemm(dy, w, M, N, K, trans_b=True, tile_hint=rows)
+        close(out, dy.float() @ w.float(), 1e-2, f"{rows}-row dgrad tile")
+        assert torch.equal(out, ops.gemm(dy, w, M, N, K, trans_b=True, tile_hint=256))

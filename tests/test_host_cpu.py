@@ -433,3 +433,34 @@ def test_video_transform_restatement_and_draws_vs_golden():
             box, flip = (0, 0, H, W), False
         out = restate_video_transform(clip, box, (res, res), tf.interpolation, flip, CLIP_MEAN, CLIP_STD)
         assert out.shape == ref.shape and torch.equal(out, ref), (T, H, W, res, train, seed, (out - ref).abs().max().item())
+
+
+def test_gemm_row_band_plans():
+    """Host-side planner of the 256x256 GEMM (csrc/gemm256.hip plan_bands): bands tile the rows exactly once in order,
+    every band but the last is made of whole tiles, band tile rows are 256 / 192 / 160, and the shapes the planner exists
+    for (a mostly empty last round of workgroups) come out with fewer modelled tile-rounds than the single launch."""
+    import youku_mplug_amd  # noqa: F401
+    from youku_mplug_amd import _lib
+    f = _lib.lib().mpv_gemm_plan_bands
+    out = (ctypes.c_int * 6)()
+    rel = {256: 1.0, 192: 0.8, 160: 0.73}
+    ncu = 256
+    cases = [(50432, 768, 768), (50176, 768, 768), (50432, 768, 3072), (50432, 2304, 768), (50432, 3072, 768), (5120, 2048, 2048),
+             (5120, 6144, 2048), (5120, 8192, 2048), (1024, 51200, 2048), (256, 256, 64), (300, 264, 320), (1, 256, 64), (70000, 1024, 64)]
+    for (M, N, K) in cases:
+        for pre, ext in ((0, 0), (1, 0), (0, 1)):
+            n = f(M, N, K, ncu, pre, ext, out)
+            bands = [(out[2 * i], out[2 * i + 1]) for i in range(n)]
+            assert 1 <= n <= 3 and all(r in rel and t > 0 for r, t in bands), (M, N, K, bands)
+            covered = 0
+            for i, (r, t) in enumerate(bands):
+                if i + 1 < n:
+                    covered += r * t
+                    assert covered < M
+                else:
+                    assert covered + r * (t - 1) < M <= covered + r * t, (M, N, K, bands)
+            tn = (N + 255) // 256
+            rounds = lambda r, t: -(-t * tn // ncu) * rel[r]
+            assert sum(rounds(r, t) for r, t in bands) <= rounds(256, -(-M // 256)) + 1e-6, (M, N, K, bands)
+    n = f(50432, 768, 3072, ncu, 0, 0, out)
+    assert n == 3 and [out[0], out[2], out[4]] == [256, 192, 160]

@@ -47,6 +47,7 @@ _SIGS = {
     "mpv_last_error": (C.c_char_p, []),
     "mpv_check_device": (c_int, []),
     "mpv_gemm_workspace_size": (c_size_t, [c_int64, c_int64, c_int64, c_int, c_int]),
+    "mpv_gemm_plan_bands": (c_int, [c_int64, c_int64, c_int64, c_int, c_int, c_int, C.POINTER(c_int)]),
     "mpv_gemm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64,
                               c_int, c_int, C.POINTER(GemmEpilogue), c_void_p, c_size_t, c_void_p]),
     "mpv_layernorm_fwd": (c_int, [c_void_p] * 6 + [c_int64] * 4 + [c_float] + _RM + _RM + [c_void_p]),

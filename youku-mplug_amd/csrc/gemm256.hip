@@ -29,6 +29,7 @@
 //    dropout, residual, accumulate, C row map).  fp32 outputs (split-K partials) are staged in four 64-row passes.
 //  * wgrad: the fused bias gradient (column sums of the A operand) is one extra MFMA per A fragment against a
 //    constant ones operand, spread over the four wave columns.
+#include <algorithm>
 #include <type_traits>
 
 #include "mpv_common.h"
@@ -206,7 +207,7 @@ __device__ __forceinline__ i32x4 raw_rsrc(const void* ptr, uint32_t bytes) {
 // whose 256-row tiling leaves CUs idle (M = 5120, N = 2048: 160 tiles on 256 CUs; 160-row tiles: exactly 256).
 template <bool TA, bool TB, bool KMAP, int MB1 = 4>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
-  static_assert(MB1 == 4 || (!TA && !TB), "short tiles exist for the k-contiguous forward form only");
+  static_assert(MB1 == 4 || !TA, "short tiles exist for a k-contiguous A operand (forward / dgrad forms) only");
   constexpr int WROWS = 64 + 16 * MB1;          // tile rows of one wave row
   constexpr int TME = 2 * WROWS;                // tile rows
   constexpr int NIT = TME / 16;
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   const int grp = pid / gsz, rem = pid - grp * gsz;
   const int gm = min(GM, p.tiles_m - grp * GM);
   const int tile_n = rem / gm, tile_m = grp * GM + (rem - tile_n * gm);
-  const int m0 = tile_m * TME, n0 = tile_n * TN;
+  const int m0 = p.m_base + tile_m * TME, n0 = tile_n * TN;
 
   const int kbeg = split * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
@@ -597,7 +598,75 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   else epilogue(IC<EP_GENERIC>{});
 }
 
+struct Band { int rows, m_tiles; };
+// Row-band plan of one product (see mpv_gemm256_try_launch): fills plan[0..n) with (tile rows, m-tiles) in row order.
+int plan_bands(int M, int tn, int K, float epi_tiles, int ncu, Band plan[3]) {
+  const float nk = (float)(K / TK);
+  const float epi = 4.9f * epi_tiles;
+  auto tile_us = [&](int r) { return 2.2f + 1.31f * nk * (r == 256 ? 1.0f : r == 192 ? 0.80f : 0.73f) + epi * (float)r * (1.0f / 256.0f); };
+  auto band_us = [&](int r, int mt) { return mt > 0 ? (float)(((long long)mt * tn + ncu - 1) / ncu) * tile_us(r) + 2.5f : 0.f; };
+  const int all256 = (M + 255) / 256;
+  int nband = 1;
+  plan[0] = Band{256, all256};
+  const float single256 = band_us(256, all256);
+  float best = single256;
+  // candidates: n256 m-tiles of 256 rows filling whole rounds, then n192 m-tiles of 192 rows likewise, the rest at 160 / 192 / 256
+  for (int r1 = 0;; ++r1) {
+    int n256 = (int)((long long)r1 * ncu / tn);
+    const bool last1 = n256 >= M / 256;
+    if (last1) n256 = M / 256;                              // whole tiles only: what is left goes to the next band
+    const int m1 = M - n256 * 256;
+    const float c1 = band_us(256, n256);
+    for (int r2 = 0;; ++r2) {
+      int n192 = (int)((long long)r2 * ncu / tn);
+      const bool last2 = n192 >= m1 / 192;
+      if (last2) n192 = m1 / 192;
+      const int m2 = m1 - n192 * 192;
+      const float c2 = c1 + band_us(192, n192);
+      for (int rr : {160, 192, 256}) {
+        const int nr = (m2 + rr - 1) / rr;
+        const float c = c2 + band_us(rr, nr);
+        if (c < best - 0.01f) {
+          best = c;
+          nband = 0;
+          if (n256) plan[nband++] = Band{256, n256};
+          if (n192) plan[nband++] = Band{192, n192};
+          if (nr) plan[nband++] = Band{rr, nr};
+        }
+      }
+      if (last2) break;
+    }
+    if (last1) break;
+  }
+  if (best > 0.97f * single256) {                           // not worth the extra launches
+    nband = 1;
+    plan[0] = Band{256, all256};
+  }
+  for (int i = 0; i + 1 < nband;) {                         // adjacent bands of equal tile rows are one launch
+    if (plan[i].rows == plan[i + 1].rows) {
+      plan[i].m_tiles += plan[i + 1].m_tiles;
+      for (int j = i + 1; j + 1 < nband; ++j) plan[j] = plan[j + 1];
+      --nband;
+    } else {
+      ++i;
+    }
+  }
+  return nband;
+}
+
 }  // namespace
+
+// test hook: the row-band plan of an M x N x K product on `ncu` compute units; out[2 * i] = tile rows, out[2 * i + 1] = m-tiles
+extern "C" int mpv_gemm_plan_bands(int64_t M, int64_t N, int64_t K, int ncu, int preact, int ext_rows, int* out6) {
+  MPV_REQUIRE(M > 0 && N > 0 && K > 0 && ncu > 0 && out6, MPV_E_ARG, "mpv_gemm_plan_bands: bad argument");
+  Band plan[3] = {};
+  const int n = plan_bands((int)M, (int)((N + TN - 1) / TN), (int)K, 1.0f + (preact ? 1.0f : 0.f) + (ext_rows ? 0.5f : 0.f), ncu, plan);
+  for (int i = 0; i < 3; ++i) {
+    out6[2 * i] = i < n ? plan[i].rows : 0;
+    out6[2 * i + 1] = i < n ? plan[i].m_tiles : 0;
+  }
+  return n;
+}
 
 // Takes the problem if the 256x256 kernel is expected to beat the 128x128 one on it.  g is fully populated by
 // mpv_gemm_bf16 (epilogue, maps, byte extents, split-K fields for wgrad: splits / k_per_split / C = fp32 workspace).
@@ -608,40 +677,52 @@ bool mpv_gemm256_try_launch(const GemmArgs& g0, int transA, int transB, hipStrea
   g.tiles_n = (g.N + TN - 1) / TN;
   g.gm = g.gm > 0 ? g.gm : 4;
   const bool km = (transA || transB) && g.kmap.group != 0;
-  // tile rows: 256, or 192 / 160 (forward form, bf16 output, no split-K) when that tiling fills the chip better.  Cost =
-  // rounds of one workgroup per CU x relative time of a tile (measured main-loop time per K-tile: 1.0 / 0.80 / 0.73 --
-  // the short variants keep the barrier structure and shed MFMAs only in two of the four phases).
-  int rows = 256;
-  if (!transA && !transB && !g.out_f32 && g.splits == 1) {
-    if (g.tile_rows == 192 || g.tile_rows == 160) {
-      rows = g.tile_rows;
-    } else if (g.tile_rows == 0) {
-      static int ncu = 0;
-      if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-      }
-      auto cost = [&](int r, float rel) { return (float)(((long long)((g.M + r - 1) / r) * g.tiles_n + ncu - 1) / ncu) * rel; };
-      const float c256 = cost(256, 1.0f), c192 = cost(192, 0.80f), c160 = cost(160, 0.73f);
-      if (c160 < 0.95f * c256 && c160 <= c192) rows = 160;
-      else if (c192 < 0.95f * c256) rows = 192;
+  // Tile rows.  A launch runs in rounds of one workgroup per CU, and a partly filled last round costs a whole tile time
+  // (M = 50432, N = 768: 591 tiles = 2.31 rounds on 256 CUs, paid as 3).  With a k-contiguous A operand (forward and
+  // dgrad forms, bf16 output, no split-K) the rows are therefore cut into up to three BANDS, each its own launch of the
+  // same kernel at 256, 192 or 160 tile rows (same ring, barriers and epilogue; m_base / M delimit the band), sized so that
+  // the 256- and 192-row bands are whole rounds and the short tiles take the remainder: 1 + 1 + 1 rounds at relative
+  // tile times 1.0 / 0.8 / 0.73 instead of 3 x 1.0.  Cost model = measured tile anatomy (tools/probe/gemm256_timeline.py):
+  // prologue 2.2 us + 1.31 us per K-tile x {1.0, 0.80, 0.73} + store-bound epilogue 4.9 us x rows / 256 x (tiles written
+  // or read besides C), and 2.5 us per extra launch.
+  const bool bandable = !transA && !g.out_f32 && g.splits == 1 && !(transB && km);
+  Band plan[3] = {{256, (g.M + 255) / 256}, {0, 0}, {0, 0}};
+  int nband = 1;
+  if (bandable && (g.tile_rows == 192 || g.tile_rows == 160)) {
+    plan[0] = Band{g.tile_rows, (g.M + g.tile_rows - 1) / g.tile_rows};
+  } else if (bandable && g.tile_rows == 0) {
+    static int ncu = 0;
+    if (!ncu) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     }
+    nband = plan_bands(g.M, g.tiles_n, g.K, 1.0f + (g.preact ? 1.0f : 0.f) + ((g.residual || g.act_bwd) ? 0.5f : 0.f), ncu, plan);
   }
-  g.tiles_m = (g.M + rows - 1) / rows;
-  g.nwg = g.tiles_m * g.tiles_n;
-  const dim3 grid((unsigned)(g.nwg * g.splits)), block(512);
-  if (!transA && !transB) {
-    if (rows == 160) hipLaunchKernelGGL((gemm256_kernel<false, false, false, 1>), grid, block, 0, stream, g);
-    else if (rows == 192) hipLaunchKernelGGL((gemm256_kernel<false, false, false, 2>), grid, block, 0, stream, g);
-    else hipLaunchKernelGGL((gemm256_kernel<false, false, false>), grid, block, 0, stream, g);
-  } else if (!transA && transB && !km)
-    hipLaunchKernelGGL((gemm256_kernel<false, true, false>), grid, block, 0, stream, g);
-  else if (!transA && transB)
-    hipLaunchKernelGGL((gemm256_kernel<false, true, true>), grid, block, 0, stream, g);
-  else if (!km)
-    hipLaunchKernelGGL((gemm256_kernel<true, true, false>), grid, block, 0, stream, g);
-  else
-    hipLaunchKernelGGL((gemm256_kernel<true, true, true>), grid, block, 0, stream, g);
+  const int M_all = g.M;
+  int m_base = 0;
+  for (int b = 0; b < nband; ++b) {
+    const int rows = plan[b].rows;
+    g.m_base = m_base;
+    g.M = std::min(M_all, m_base + plan[b].m_tiles * rows);
+    g.tiles_m = plan[b].m_tiles;
+    g.nwg = g.tiles_m * g.tiles_n;
+    m_base = g.M;
+    const dim3 grid((unsigned)(g.nwg * g.splits)), block(512);
+    if (!transA && !transB) {
+      if (rows == 160) hipLaunchKernelGGL((gemm256_kernel<false, false, false, 1>), grid, block, 0, stream, g);
+      else if (rows == 192) hipLaunchKernelGGL((gemm256_kernel<false, false, false, 2>), grid, block, 0, stream, g);
+      else hipLaunchKernelGGL((gemm256_kernel<false, false, false>), grid, block, 0, stream, g);
+    } else if (!transA && transB && !km) {
+      if (rows == 160) hipLaunchKernelGGL((gemm256_kernel<false, true, false, 1>), grid, block, 0, stream, g);
+      else if (rows == 192) hipLaunchKernelGGL((gemm256_kernel<false, true, false, 2>), grid, block, 0, stream, g);
+      else hipLaunchKernelGGL((gemm256_kernel<false, true, false>), grid, block, 0, stream, g);
+    } else if (!transA && transB)
+      hipLaunchKernelGGL((gemm256_kernel<false, true, true>), grid, block, 0, stream, g);
+    else if (!km)
+      hipLaunchKernelGGL((gemm256_kernel<true, true, false>), grid, block, 0, stream, g);
+    else
+      hipLaunchKernelGGL((gemm256_kernel<true, true, true>), grid, block, 0, stream, g);
+  }
   return true;
 }

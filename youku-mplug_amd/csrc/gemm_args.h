@@ -29,6 +29,7 @@ struct GemmArgs {
   int k_per_split;
   int tiles_n, tiles_m;
   int nwg, splits;
+  int m_base;           // gemm256: first row of the row band this launch covers (M = one past its last row)
   int tile_rows;        // gemm256: 0 = pick 256 / 192 / 160 tile rows per problem, else pinned (tile_hint 192 / 160 / 256)
   int gm;               // gemm256: m-tiles per n-tile in an XCD's tile walk (0 -> default)
   bf16* tap_out;        // rows m % tap_group == 0 also store bf16(acc * alpha + bias) at tap_out[(m / tap_group) * N + n]
