@@ -85,6 +85,8 @@ typedef struct mpv_gemm_epilogue {
                              The ViT block uses it to take the per-frame cls rows of the spatial projection out of the
                              GEMM whose residual epilogue writes x + proj(.) for all rows (vision_transformer.py:263-270) */
   int row_tap_group;
+  int split_hint;         /* measurements: > 0 pins the split-K count of a wgrad product (0: the library picks)              */
+  int gm_hint;            /* measurements: > 0 pins the m-tiles per n-tile of an XCD's tile walk in the 256x256 kernel       */
 } mpv_gemm_epilogue;
 
 size_t mpv_gemm_workspace_size(int64_t M, int64_t N, int64_t K, int transA, int transB);

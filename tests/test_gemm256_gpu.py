@@ -204,7 +204,7 @@ def test_gemm256_short_tile_rows(dev, rows, M, N, K):
     assert torch.equal(r1, ops.gemm(a, w, M, N, K, bias=bias, residual=res, tile_hint=256))
 
 
-@pytest.mark.parametrize("M,N,K,tb", [(50432, 768, 768, 0), (50176, 768, 768, 0), (50432, 768, 2304, 1), (50432, 3072, 768, 0), (5120, 8192, 2048, 0),
+@pytest.mark.parametrize("M,N,K,tb", [(50432, 768, 768, 0), (50176, 768, 768, 0), (50432, 768, 2304, 1), (5120, 8192, 2048, 0),
                                        (5120, 8192, 2048, 1), (12352, 768, 192, 1), (40000, 520, 128, 0)])
 def test_gemm256_row_bands(dev, M, N, K, tb):
     """Auto tile choice cuts the rows into bands of 256- / 192- / 160-row tiles, one launch each (csrc/gemm256.hip,

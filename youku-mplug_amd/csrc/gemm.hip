@@ -627,16 +627,23 @@ static int gemm_variant() {
   return v;
 }
 
-// wgrad split for the 256x256 kernel: fill whole rounds of the 256 CUs, at least 8 K-tiles per split
+// wgrad split for the 256x256 kernel.  Filling whole rounds of the CUs is not enough of a criterion: every split writes
+// an fp32 partial of the whole output and the reduce pass reads it back, so 27 tiles x 28 splits (98 % of three rounds)
+// lost to 27 x 9 (95 % of one round) by 25 % (tools/probe/wgrad_splits.py: 217.7 vs 177.6 us at M = 2304, N = 768,
+// K = 50432).  Modelled time (us), constants fitted to that sweep on MI355X: rounds x (12 for prologue + fp32 epilogue
+// + 1.5 per K-tile of a split) + partial bytes read back at 3.5 TB/s + 6 for the reduce launch.
 static int choose_splitk256(int64_t tiles, int64_t K, int64_t M, int64_t N, size_t ws_bytes) {
   int best = 1;
-  double best_eff = 0.0;
+  double best_us = 0.0;
+  const int64_t nk = K / 64;
   for (int s = 1; s <= 64; ++s) {
     if (s > 1 && (K / s < 8 * 64 || (size_t)M * N * sizeof(float) * s + (size_t)s * M * sizeof(float) > ws_bytes)) break;
     const int64_t blocks = tiles * s;
-    const double eff = (double)blocks / (double)(((blocks + 255) / 256) * 256);
-    if (eff > best_eff + 0.02) {
-      best_eff = eff;
+    const double rounds = (double)((blocks + 255) / 256);
+    const double kt = (double)((nk + s - 1) / s);
+    const double us = rounds * (12.0 + 1.5 * kt) + (s > 1 ? (double)s * (double)M * (double)N * 4.0 / 3.5e6 + 6.0 : 0.0);
+    if (s == 1 || us < best_us) {
+      best_us = us;
       best = s;
     }
   }
@@ -743,8 +750,12 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
   if (variant != 128 && K % 64 == 0 && (M >= 256 || variant == 160 || variant == 192) && N >= 256) {
     const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
     int s256 = 1;
-    if (transA && transB && !g.out_f32) s256 = choose_splitk256(t256, K, M, N, workspace ? workspace_bytes : 0);
-    else if (!g.out_f32 && t256 * 2 <= 256 && K >= 4096 && !g.bias && !g.act && !g.residual && !g.act_bwd && !g.drop_thr && !g.tap_out &&
+    if (transA && transB && !g.out_f32) {
+      s256 = choose_splitk256(t256, K, M, N, workspace ? workspace_bytes : 0);
+      if (ep && ep->split_hint > 0 && K / ep->split_hint >= 64 &&
+          (size_t)M * N * sizeof(float) * ep->split_hint + (size_t)ep->split_hint * M * sizeof(float) <= (workspace ? workspace_bytes : 0))
+        s256 = ep->split_hint;
+    } else if (!g.out_f32 && t256 * 2 <= 256 && K >= 4096 && !g.bias && !g.act && !g.residual && !g.act_bwd && !g.drop_thr && !g.tap_out &&
              !g.preact && g.cmap.group == 0 && ldc == N) {
       // few tiles, long reduction, plain epilogue: split-K over the idle CUs (at most the 16 splits the workspace size allows for)
       s256 = choose_splitk256(t256, K, M, N, workspace ? workspace_bytes : 0);
@@ -754,6 +765,7 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
         // its tiles fill only 5/8 of the CUs (M = 5120, N = 2048: 959 vs 764 TFLOP/s)
       GemmArgs h = g;
       h.tile_rows = (variant == 160 || variant == 192 || variant == 256) ? variant : 0;
+      h.gm = (ep && ep->gm_hint > 0) ? ep->gm_hint : 0;
       h.splits = s256;
       h.k_per_split = (int)K;
       if (s256 > 1) {

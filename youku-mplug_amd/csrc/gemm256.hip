@@ -610,6 +610,10 @@ int plan_bands(int M, int tn, int K, float epi_tiles, int ncu, Band plan[3]) {
   plan[0] = Band{256, all256};
   const float single256 = band_us(256, all256);
   float best = single256;
+  // measured (tools/gemm_ab.py, 256 CUs): launches of a few rounds gain 2-5 % (N = 768 ViT shapes at 2.31 rounds, the GPT
+  // N = 8192 shapes at 2.5); at ~9 rounds (N = 3072) the workgroups have drifted apart, the last round is no longer
+  // paid in full and cutting the launch only adds tails (-2..-4 %): single launch from 5 rounds on
+  if (((long long)all256 * tn + ncu - 1) / ncu > 4) return 1;
   // candidates: n256 m-tiles of 256 rows filling whole rounds, then n192 m-tiles of 192 rows likewise, the rest at 160 / 192 / 256
   for (int r1 = 0;; ++r1) {
     int n256 = (int)((long long)r1 * ncu / tn);

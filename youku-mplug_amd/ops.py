@@ -50,7 +50,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: Optio
          act_bwd_z=None, act_bwd: int = 0, ldz: int = 0, dropout_p: float = 0.0, seed: int = 0, offset: int = 0,
          alpha_dev=None, alpha: float = 0.0, amap: RowMap = IDENT, cmap: RowMap = IDENT, kmap: RowMap = IDENT,
          out_rows: Optional[int] = None, accumulate: bool = False, out_f32: bool = False, colsum_out=None,
-         tile_hint: int = 0, row_tap_out=None, row_tap_group: int = 0) -> torch.Tensor:
+         tile_hint: int = 0, row_tap_out=None, row_tap_group: int = 0, split_hint: int = 0, gm_hint: int = 0) -> torch.Tensor:
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)).  See include/mpv.h:mpv_gemm_bf16."""
     _need_cuda(a, b)
     lda = lda if lda is not None else (M if trans_a else K)
@@ -82,6 +82,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: Optio
     ep.tile_hint = tile_hint
     ep.row_tap_out = _p(row_tap_out)
     ep.row_tap_group = row_tap_group
+    ep.split_hint = split_hint
+    ep.gm_hint = gm_hint
     ws, wsn = None, 0
     if not out_f32:
         wsn = _lib.lib().mpv_gemm_workspace_size(M, N, K, int(trans_a), int(trans_b))
