@@ -73,6 +73,7 @@ class GemmTimer:
 
     def __init__(self):
         self.records = []
+        self.shapes = []
         self.orig = None
 
     def __enter__(self):
@@ -88,6 +89,9 @@ class GemmTimer:
             # copies), <0,1> dgrad against trainable weights, <1,1> wgrad
             kind = "gemm<1,1> wgrad" if kw.get("trans_a") else ("gemm<0,1> dgrad" if kw.get("trans_b") else "gemm<0,0> fwd + frozen-weight dgrad")
             self.records.append((kind, 2.0 * M * N * K, s, e, 2.0 * (M * K + N * K + M * N)))
+            epi = "+".join(k for k in ("bias", "act", "preact_out", "residual", "act_bwd_z", "dropout_p", "colsum_out", "row_tap_out", "kmap", "amap")
+                           if (torch.is_tensor(kw.get(k)) or kw.get(k) not in (None, 0, 0.0, False, (0, 0, 0))))
+            self.shapes.append((kind.split()[0], M, N, K, epi))
             return r
         ops.gemm = timed
         import youku_mplug_amd.vision as v, youku_mplug_amd.gpt3 as g, youku_mplug_amd.pretrain as p
@@ -95,6 +99,19 @@ class GemmTimer:
 
     def __exit__(self, *exc):
         self.ops.gemm = self.orig
+
+    def by_shape(self, path, steps):
+        """MPV_BENCH_BY_SHAPE=<file>: per (form, M, N, K, epilogue) launches per step, mean us and TFLOP/s inside the step."""
+        torch.cuda.synchronize()
+        agg = {}
+        for (kind, fl, s, e, _), key in zip(self.records, self.shapes):
+            a = agg.setdefault(key, [0, 0.0, fl])
+            a[0] += 1
+            a[1] += s.elapsed_time(e) * 1e3
+        with open(path, "w") as f:
+            f.write("| form | M | N | K | epilogue | launches/step | mean us | TFLOP/s | ms/step |\n|---|---|---|---|---|---|---|---|---|\n")
+            for key, (n, us, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                f.write(f"| {key[0]} | {key[1]} | {key[2]} | {key[3]} | {key[4] or 'plain'} | {n / steps:g} | {us / n:.1f} | {fl / (us / n) / 1e6:.0f} | {us / steps / 1e3:.2f} |\n")
 
     def summary(self):
         torch.cuda.synchronize()
@@ -313,6 +330,8 @@ def main():
             for i in range(nroof):
                 step(total + i)
         tot = gt.summary()
+        if os.environ.get("MPV_BENCH_BY_SHAPE"):
+            gt.by_shape(os.environ["MPV_BENCH_BY_SHAPE"], nroof)
         if lane is not None:
             lane.on = lane_on
         fl = sum(v[0] for v in tot.values())

@@ -1,4 +1,4 @@
-"""A/B of the two tile kernels on the epilogue-heavy GEMMs of the step (GELU + pre-activation copy, GELU-backward multiply,
+"""A/B of the pinned 256-row launch, the pinned 192- / 160-row launches and the library's own choice (row bands) on the epilogue-heavy GEMMs of the step (GELU + pre-activation copy, GELU-backward multiply,
 dropout + residual), random data.  Usage (GPU box): python tools/gemm_ab_epi.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -29,7 +29,8 @@ CASES = [  # name, M, N, K, tb, kind
     ("vit proj fwd +res", 50432, 768, 768, 0, "res"), ("vit fc2 fwd +res", 50432, 768, 3072, 0, "res"),
     ("gpt h4h fwd gelu+pre", 5120, 8192, 2048, 0, "gelu_tanh"), ("gpt 4hh dgradT gelu'", 5120, 8192, 2048, 0, "bwd_tanh"),
     ("gpt dense drop+res", 5120, 2048, 2048, 0, "dropres"), ("gpt 4hh fwd drop+res", 5120, 2048, 8192, 0, "dropres"),
-    ("plain fc1 shape", 50432, 3072, 768, 0, "plain"),
+    ("plain fc1 shape", 50432, 3072, 768, 0, "plain"), ("vit proj dgrad plain", 50432, 768, 768, 1, "plain"),
+    ("vit qkv dgrad plain", 50432, 768, 2304, 1, "plain"), ("vit fc1 dgrad plain", 50432, 768, 3072, 1, "plain"),
 ]
 for name, M, N, K, tb, kind in CASES:
     a = rnd(M, K)
@@ -50,8 +51,9 @@ for name, M, N, K, tb, kind in CASES:
     elif kind == "dropres":
         kw.update(bias=bias, residual=res, dropout_p=0.1, seed=1, offset=7)
     t = {}
-    for r in range(3):
-        for h in (128, 256):
+    arms = (256, 192, 160, 0)
+    for r in range(4):
+        for h in arms:
             t[h] = min(t.get(h, 1e9), timeit(lambda: ops.gemm(a, b, M, N, K, tile_hint=h, **kw)))
     fl = 2.0 * M * N * K
-    print(f"{name:24s} {M:6d} {N:5d} {K:5d} | 128: {t[128]*1e6:7.1f} us {fl/t[128]/1e12:7.1f} TF/s | 256: {t[256]*1e6:7.1f} us {fl/t[256]/1e12:7.1f} TF/s", flush=True)
+    print(f"{name:24s} {M:6d} {N:5d} {K:5d} | " + " | ".join(f"{'auto' if h == 0 else h}: {t[h]*1e6:7.1f} us {fl/t[h]/1e12:7.1f}" for h in arms), flush=True)
