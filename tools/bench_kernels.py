@@ -79,6 +79,11 @@ def bench_ln():
         tb = timeit(lambda: ops.layernorm_bwd(dy, x, g, mean, rstd, rows, cols, dx=dx, dgamma=dg, dbeta=db))
         by = rows * cols * 2
         print(f"LN {rows}x{cols}: fwd {tf*1e6:7.1f} us ({2*by/tf/1e9:6.0f} GB/s)  bwd {tb*1e6:7.1f} us ({3*by/tb/1e9:6.0f} GB/s)", flush=True)
+        # the forms the step runs: ViT = residual gradient + dgamma/dbeta; GPT (frozen) = residual gradient + dropout-masked copy
+        dres, dxd = rnd(rows, cols), torch.empty_like(x)
+        t1 = timeit(lambda: ops.layernorm_bwd(dy, x, g, mean, rstd, rows, cols, dres=dres, dx=dx, dgamma=dg, dbeta=db))
+        t2 = timeit(lambda: ops.layernorm_bwd(dy, x, g, mean, rstd, rows, cols, dres=dres, dx=dx, dx_drop=dxd, dropout_p=0.1, seed=3, offset=11))
+        print(f"   bwd + dres + dparams {t1*1e6:7.1f} us ({4*by/t1/1e9:6.0f} GB/s)   bwd + dres + dropped copy {t2*1e6:7.1f} us ({5*by/t2/1e9:6.0f} GB/s)", flush=True)
     n = 130_000_000 // 256 * 256
     p16, master, m, v, g = (torch.zeros(n, dtype=torch.bfloat16, device=dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev),
                             torch.zeros(n, device=dev), rnd(n))

@@ -198,49 +198,71 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p) {
 template <int MAXC>
 __global__ __launch_bounds__(256) void ln_fwd8_kernel(const LnFwdArgs p) {
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: row pointers live in SGPRs
   const int nchunk = p.cols >> 3;
   const float inv_n = 1.0f / (float)p.cols;
-  for (long long r = (long long)blockIdx.x * 4 + wave; r < p.rows; r += (long long)gridDim.x * 4) {
+  // gamma / beta stay in registers as bf16 (they were re-read from cache after the reductions of every row), and the next
+  // row of the wave is requested before the current one is reduced: its HBM latency runs under the two wave reductions
+  // and the stores instead of after them.
+  bf16x8 gmb[MAXC], btb[MAXC], nx[MAXC];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    gmb[i] = c < nchunk ? *(const bf16x8*)(p.gamma + c * 8) : bf16x8{};
+    btb[i] = c < nchunk ? *(const bf16x8*)(p.beta + c * 8) : bf16x8{};
+  }
+  const long long stride = (long long)gridDim.x * 4;
+  long long r = (long long)blockIdx.x * 4 + wave;
+  if (r < p.rows) {
     const bf16* xr = p.x + map_row(p.xmap, r) * p.ldx;
-    f32x8 v[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) nx[i] = lane + 64 * i < nchunk ? *(const bf16x8*)(xr + (lane + 64 * i) * 8) : bf16x8{};
+  }
+  for (; r < p.rows; r += stride) {
+    bf16x8 cur[MAXC];      // the row as raw bf16 (4 VGPRs per chunk); converted again for each sweep instead of 8 fp32 VGPRs kept live
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
-      const int c = lane + 64 * i;
-      if (c < nchunk) {
-        v[i] = cvt8(*(const bf16x8*)(xr + c * 8));
+      cur[i] = nx[i];
+      const f32x8 v = cvt8(cur[i]);          // chunks past the row are zeros: they add nothing to the sums
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s += v[i][e];
-      } else {
+      for (int e = 0; e < 8; ++e) s += v[e];
+    }
+    if (r + stride < p.rows) {
+      const bf16* xn = p.x + map_row(p.xmap, r + stride) * p.ldx;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
-      }
+      for (int i = 0; i < MAXC; ++i) nx[i] = lane + 64 * i < nchunk ? *(const bf16x8*)(xn + (lane + 64 * i) * 8) : bf16x8{};
     }
     const float mu = wave_sum(s) * inv_n;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) asm volatile("" : "+v"(cur[i]));
     float s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
       const int c = lane + 64 * i;
       if (c < nchunk) {
+        const f32x8 v = cvt8(cur[i]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float d = v[i][e] - mu;
+          const float d = v[e] - mu;
           s2 += d * d;
         }
       }
     }
     const float rs = rsqrtf(wave_sum(s2) * inv_n + p.eps);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) asm volatile("" : "+v"(cur[i]));
     bf16* yr = p.y + map_row(p.ymap, r) * p.ldy;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
       const int c = lane + 64 * i;
       if (c < nchunk) {
-        const f32x8 g = cvt8(*(const bf16x8*)(p.gamma + c * 8));
-        const f32x8 b = cvt8(*(const bf16x8*)(p.beta + c * 8));
+        const f32x8 v = cvt8(cur[i]);
+        const f32x8 g = cvt8(gmb[i]);
+        const f32x8 b = cvt8(btb[i]);
         f32x8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mu) * rs * g[e] + b[e];
+        for (int e = 0; e < 8; ++e) o[e] = (v[e] - mu) * rs * g[e] + b[e];
         *(bf16x8*)(yr + c * 8) = cvt8(o);
       }
     }
@@ -251,8 +273,12 @@ __global__ __launch_bounds__(256) void ln_fwd8_kernel(const LnFwdArgs p) {
   }
 }
 
-template <int MAXC, bool DPARAM>
-__global__ __launch_bounds__(256) void ln_bwd8_kernel(const LnBwdArgs p) {
+// No parameter gradients (the frozen decoder's LayerNorms, one row per wave at 5120 x 2048): the residual gradient is read after
+// the reductions, interleaved with the stores -- measured 19.9 us against 23.0 us for the single-round-trip form below on that
+// shape (5.3 TB/s: reads and writes alternating suit the HBM better than a read burst followed by a write burst).
+template <int MAXC>
+__global__ __launch_bounds__(256) void ln_bwd8_plain_kernel(const LnBwdArgs p) {
+  constexpr bool DPARAM = false;
   __shared__ float red[DPARAM ? 2 * MAXC * 512 : 1];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -348,6 +374,128 @@ __global__ __launch_bounds__(256) void ln_bwd8_kernel(const LnBwdArgs p) {
   }
 }
 
+
+// waves per SIMD the register allocation is held to: 4 (128 VGPRs) where that fits without scratch
+template <int MAXC, bool DPARAM>
+__global__ __launch_bounds__(256, MAXC <= 2 ? 4 : MAXC <= 3 ? 2 : 1) void ln_bwd8_kernel(const LnBwdArgs p) {
+  __shared__ float red[DPARAM ? 2 * MAXC * 512 : 1];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: row pointers and statistics live in SGPRs
+  const int nchunk = p.cols >> 3;
+  const float inv_n = 1.0f / (float)p.cols;
+  f32x8 gacc[DPARAM ? MAXC : 1], bacc[DPARAM ? MAXC : 1];
+  if constexpr (DPARAM) {
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gacc[i][e] = bacc[i][e] = 0.f;
+  }
+  // gamma stays in registers as bf16 for the whole kernel (it was re-read from cache for every row)
+  bf16x8 gmb[MAXC];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    gmb[i] = c < nchunk ? *(const bf16x8*)(p.gamma + c * 8) : bf16x8{};
+  }
+  // A row is one round trip to memory: x, dy and the residual gradient are all requested before anything is reduced (the
+  // residual gradient used to be read after the two wave reductions -- a second, serial HBM latency per row), and they are
+  // held as raw bf16 (12 VGPRs per chunk instead of 16 of fp32 x-hat / g), x-hat and g being recomputed for the output
+  // sweep: identical arithmetic, fewer registers, more resident waves.
+  for (long long r = (long long)blockIdx.x * 4 + wave; r < p.rows; r += (long long)gridDim.x * 4) {
+    const long long xrow = map_row(p.xmap, r);
+    const bf16* xr = p.x + xrow * p.ldx;
+    const bf16* dyr = p.dy + map_row(p.ymap, r) * p.ldy;
+    const bf16* drr = p.dres ? p.dres + xrow * p.ldx : nullptr;
+    bf16x8 xb[MAXC], db[MAXC], rb[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      const bool ok = c < nchunk;
+      xb[i] = ok ? *(const bf16x8*)(xr + c * 8) : bf16x8{};
+      db[i] = ok ? *(const bf16x8*)(dyr + c * 8) : bf16x8{};
+      rb[i] = ok && drr ? *(const bf16x8*)(drr + c * 8) : bf16x8{};
+    }
+    const float mu = p.mean[r], rs = p.rstd[r];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        const f32x8 xv = cvt8(xb[i]), dv = cvt8(db[i]), gm = cvt8(gmb[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (xv[e] - mu) * rs;
+          const float g = dv[e] * gm[e];
+          c1 += g;
+          c2 += g * xh;
+          if constexpr (DPARAM) {
+            gacc[i][e] += dv[e] * xh;
+            bacc[i][e] += dv[e];
+          }
+        }
+      }
+    }
+    c1 = wave_sum(c1) * inv_n;
+    c2 = wave_sum(c2) * inv_n;
+    bf16* dxr = p.dx + xrow * p.ldx;
+    bf16* ddr = p.dx_drop ? p.dx_drop + xrow * p.ldx : nullptr;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {      // opaque: without this the fp32 conversions of the first sweep are kept live across the reductions
+      asm volatile("" : "+v"(xb[i]), "+v"(db[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        const f32x8 xv = cvt8(xb[i]), dv = cvt8(db[i]), gm = cvt8(gmb[i]);
+        f32x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (xv[e] - mu) * rs;
+          const float g = dv[e] * gm[e];
+          o[e] = rs * (g - c1 - xh * c2);
+        }
+        if (drr) o += cvt8(rb[i]);
+        const bf16x8 ob = cvt8(o);
+        *(bf16x8*)(dxr + c * 8) = ob;
+        if (ddr) {
+          const f32x8 of = cvt8(ob);
+          const uint64_t base = p.offset + (uint64_t)r * (uint64_t)p.cols + (uint64_t)(c * 8);
+          const f32x8 od = p.drop_thr ? mpv_dropout_vec<f32x8, 8>(of, p.seed, base, p.drop_thr, p.drop_scale) : of * p.drop_scale;
+          *(bf16x8*)(ddr + c * 8) = cvt8(od);
+        }
+      }
+    }
+  }
+  if constexpr (DPARAM) {
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+      if (wave == w) {
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+          const int c = lane + 64 * i;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            if (w == 0) {
+              red[c * 8 + e] = gacc[i][e];
+              red[MAXC * 512 + c * 8 + e] = bacc[i][e];
+            } else {
+              red[c * 8 + e] += gacc[i][e];
+              red[MAXC * 512 + c * 8 + e] += bacc[i][e];
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    float* out = p.part + (long long)blockIdx.x * 2 * p.cols;
+    for (int c = threadIdx.x; c < p.cols; c += 256) {
+      out[c] = red[c];
+      out[p.cols + c] = red[MAXC * 512 + c];
+    }
+  }
+}
+
 // Two-level deterministic reduction of the per-workgroup partials [nblk][2][cols]:
 // level 1: grid (cols/64, nblk/64): each workgroup (64 columns x 4 lanes) folds 64 partial rows;
 // level 2 (final): grid (cols/64): folds the <= 32 level-1 rows and writes bf16 (optionally accumulating).
@@ -383,7 +531,7 @@ __global__ __launch_bounds__(256) void ln_dparam_reduce(const float* __restrict_
   }
 }
 
-constexpr int LN_BWD_MAX_BLOCKS = 2048;
+constexpr int LN_BWD_MAX_BLOCKS = 1024;   // measured at 50432 x 768 with dgamma/dbeta: 2048 blocks 82 us, 1024 blocks 73 us, 512 blocks 95 us
 constexpr int LN_L1_ROWS = (LN_BWD_MAX_BLOCKS + 63) / 64;
 
 template <int MAXC>
@@ -399,7 +547,7 @@ void launch_bwd8(const LnBwdArgs& a, bool dparam, int grid, hipStream_t s) {
   if (dparam)
     hipLaunchKernelGGL((ln_bwd8_kernel<MAXC, true>), dim3(grid), dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL((ln_bwd8_kernel<MAXC, false>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((ln_bwd8_plain_kernel<MAXC>), dim3(grid), dim3(256), 0, s, a);
 }
 template <int MAXC>
 void launch_bwd(const LnBwdArgs& a, bool dparam, int grid, hipStream_t s) {
