@@ -470,8 +470,19 @@ __global__ void splitk_reduce_kernel(const float* part, bf16* out, long long MN,
   }
   const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= MN) return;
+  // four partials requested per round trip (a rolled loop waits for every load before the next address is even formed: 9 - 28
+  // serial HBM latencies per thread); the summation order z = 0, 1, 2, ... is unchanged
   f32x4 s = *(const f32x4*)(part + i);
-  for (int z = 1; z < splits; ++z) s += *(const f32x4*)(part + (long long)z * MN + i);
+  int z = 1;
+  for (; z + 4 <= splits; z += 4) {
+    const f32x4 a = *(const f32x4*)(part + (long long)z * MN + i), b = *(const f32x4*)(part + (long long)(z + 1) * MN + i);
+    const f32x4 c = *(const f32x4*)(part + (long long)(z + 2) * MN + i), d = *(const f32x4*)(part + (long long)(z + 3) * MN + i);
+    s += a;
+    s += b;
+    s += c;
+    s += d;
+  }
+  for (; z < splits; ++z) s += *(const f32x4*)(part + (long long)z * MN + i);
   if (accumulate) s += cvt4(*(const bf16x4*)(out + i));
   *(bf16x4*)(out + i) = cvt4(s);
 }
