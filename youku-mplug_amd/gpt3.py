@@ -196,6 +196,12 @@ class DistributedGPT3(nn.Module):
         st3 = (S * 3 * H, 3 * hn, 3 * H)
         lay = ops.AttnLayout(st3, st3, st3, (S * H, hn, H))
         scale = 1.0 / math.sqrt(hn)       # alpha=1/(sqrt(hn)*l) then *l inside the softmax (:718-727,757-762): net 1/sqrt(hn)
+        window = None
+        if loss_window is not None and not want_logits and not hidden_only:
+            w0, wl = int(loss_window[0]), int(loss_window[1])
+            if 0 <= w0 and w0 + wl <= S and 0 < wl < S:
+                window = (w0, wl)
+        nl = len(lm.encoder.layers)
         layers = []
         for li, layer in enumerate(lm.encoder.layers):
             ln = li + 1
@@ -205,6 +211,29 @@ class DistributedGPT3(nn.Module):
             ctx = torch.empty((R, H), dtype=torch.bfloat16, device=h.device)
             lse = ops.attn_fwd(qkv, qkv[:, hn:], qkv[:, 2 * hn:], ctx, lay, B, np_, S, S, hn, causal=True, scale=scale,
                                dropout_p=p_a, seed=seed, offset=_offset(ln, _SITE_ATTN))
+            if window is not None and li == nl - 1:
+                # Top layer under a loss window: nothing downstream reads its hidden states outside the window (they feed only
+                # the LM head, which runs on the window), and everything after the attention is row-wise -- the projection,
+                # LN2, the MLP and their residual adds run on the B * wl window rows (a row map on the [B*S, H] stream; the
+                # MLP's own tensors are compact).  K/V of all rows are still needed by the window's queries, so LN1, qkv and
+                # the attention stay whole.  The reference evaluates all S rows and discards them (models/
+                # modeling_distributed_gpt3.py:1340-1366 + distributed_gpt3.py:142-159); loss and gradients are unchanged.
+                tm = (window[1], S, window[0])
+                Rw = B * window[1]
+                h1 = torch.empty((R, H), dtype=torch.bfloat16, device=h.device)
+                ops.gemm(ctx, att.dense.weight, Rw, H, H, bias=att.dense.bias, residual=h, dropout_p=p_h, seed=seed,
+                         offset=_offset(ln, _SITE_DROP1), amap=tm, cmap=tm, out=h1)
+                x2, m2, r2 = ops.layernorm_fwd(h1, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.bias,
+                                               layer.post_attention_layernorm.eps, Rw, H, xmap=tm)
+                F4 = mlp.dense_h_to_4h.out_features
+                z = torch.empty((Rw, F4), dtype=torch.bfloat16, device=h.device)
+                g = ops.gemm(x2, mlp.dense_h_to_4h.weight, Rw, F4, H, bias=mlp.dense_h_to_4h.bias, act=ACT_GELU_TANH, preact_out=z)
+                h2 = torch.empty((R, H), dtype=torch.bfloat16, device=h.device)
+                ops.gemm(g, mlp.dense_4h_to_h.weight, Rw, H, F4, bias=mlp.dense_4h_to_h.bias, residual=h1, dropout_p=p_h,
+                         seed=seed, offset=_offset(ln, _SITE_DROP2), cmap=tm, out=h2)
+                layers.append(dict(h=h, s1=(m1, r1), qkv=qkv, ctx=ctx, lse=lse, h1=h1, s2=(m2, r2), z=z, rows=tm))
+                h = h2
+                continue
             h1 = ops.gemm(ctx, att.dense.weight, R, H, H, bias=att.dense.bias, residual=h, dropout_p=p_h, seed=seed,
                           offset=_offset(ln, _SITE_DROP1))
             x2, m2, r2 = ops.layernorm_fwd(h1, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.bias,
@@ -217,7 +246,10 @@ class DistributedGPT3(nn.Module):
             layers.append(dict(h=h, s1=(m1, r1), qkv=qkv, ctx=ctx, lse=lse, h1=h1, s2=(m2, r2), z=z))
             h = h2
         fl = lm.encoder.final_layernorm
-        xf, mf, rf = ops.layernorm_fwd(h, fl.weight, fl.bias, fl.eps, R, H)
+        if window is not None:       # final LayerNorm on the window rows of the stream -> compact [B * wl, H]
+            xf, mf, rf = ops.layernorm_fwd(h, fl.weight, fl.bias, fl.eps, B * window[1], H, xmap=(window[1], S, window[0]))
+        else:
+            xf, mf, rf = ops.layernorm_fwd(h, fl.weight, fl.bias, fl.eps, R, H)
         if hidden_only:     # only last_hidden_state is consumed (models/distributed_gpt3.py:958, 583-584, 1149-1150)
             tape.update(B=B, Q=Q, L=L, S=S, layers=layers, h_last=h, sf=(mf, rf), dlogits=None, lm_window=None, lay=lay, scale=scale,
                         seed=seed, p_h=p_h, p_a=p_a)
@@ -227,15 +259,10 @@ class DistributedGPT3(nn.Module):
         denom = lmf.sum()
         w = torch.zeros((B, S), dtype=torch.float32, device=h.device)
         w[:, :S - 1] = lmf / denom
-        window = None
-        if loss_window is not None and not want_logits:
-            w0, wl = int(loss_window[0]), int(loss_window[1])
-            if 0 <= w0 and w0 + wl <= S and 0 < wl < S:
-                window = (w0, wl)
         if window is not None:
             w0, wl = window
             Rw = B * wl
-            logits = ops.gemm(xf, lm.embedding.word_embeddings.weight, Rw, V, H, amap=(wl, S, w0))      # rows b*S + w0 + j
+            logits = ops.gemm(xf, lm.embedding.word_embeddings.weight, Rw, V, H)       # xf is already the window's rows
             losses_w, loss = ops.cross_entropy(logits, labels[:, w0:w0 + wl].contiguous().view(-1),
                                                w[:, w0:w0 + wl].contiguous().view(-1), Rw, V, dlogits=logits)
             losses = torch.zeros((B, S), dtype=torch.float32, device=h.device)
@@ -247,7 +274,8 @@ class DistributedGPT3(nn.Module):
             losses, loss = ops.cross_entropy(logits, labels.contiguous().view(-1), w.view(-1), R, V, dlogits=logits)
         tape.update(B=B, Q=Q, L=L, S=S, layers=layers, h_last=h, sf=(mf, rf), dlogits=logits, lm_window=window, lay=lay, scale=scale,
                     seed=seed, p_h=p_h, p_a=p_a)
-        out = dict(loss=loss, losses=losses.view(B, S)[:, :S - 1], last_hidden_state=xf.view(B, S, H))
+        # under a loss window the top layer and the final LayerNorm exist on the window rows only: no full last_hidden_state
+        out = dict(loss=loss, losses=losses.view(B, S)[:, :S - 1], last_hidden_state=xf.view(B, S, H) if window is None else None)
         if want_logits:
             out["logits"] = keep_logits.view(B, S, V)
         return out
@@ -277,16 +305,15 @@ class DistributedGPT3(nn.Module):
         p_h, p_a, seed, lay, scale = tape["p_h"], tape["p_a"], tape["seed"], tape["lay"], tape["scale"]
         nl = len(lm.encoder.layers)
         fl = lm.encoder.final_layernorm
+        tm = None
         if tape["dlogits"] is not None and tape.get("lm_window") is not None:
-            # LM head dgrad on the loss window only (few output tiles, K = V: split along K inside mpv_gemm_bf16), scattered
-            # into a zero d(final-LN output); rows outside the window carry no loss gradient
+            # LM head dgrad on the loss window only (few output tiles, K = V: split along K inside mpv_gemm_bf16): dxf is the
+            # compact [B * wl, H] gradient of the final LayerNorm's window rows; the final LayerNorm and the top layer's
+            # row-wise part run backward on those rows through the row map tm (forward_lm)
+            assert d_last_hidden is None, "a loss window leaves no full last_hidden_state to receive a gradient"
             w0, wl = tape["lm_window"]
-            dxw = self._dgrad(tape["dlogits"], lm.embedding.word_embeddings.weight, B * wl, H, V, alpha_dev=grad_loss)
-            dxf = torch.zeros((R, H), dtype=torch.bfloat16, device=dxw.device) if d_last_hidden is None else d_last_hidden.clone()
-            if d_last_hidden is None:
-                ops.copy_rows(dxw, dxf, B * wl, H, dmap=(wl, S, w0))
-            else:
-                dxf.view(B, S, H)[:, w0:w0 + wl] += dxw.view(B, wl, H)
+            tm = (wl, S, w0)
+            dxf = self._dgrad(tape["dlogits"], lm.embedding.word_embeddings.weight, B * wl, H, V, alpha_dev=grad_loss)
             tape["dlogits"] = None
         elif tape["dlogits"] is not None:
             dxf = self._dgrad(tape["dlogits"], lm.embedding.word_embeddings.weight, R, H, V, alpha_dev=grad_loss,
@@ -296,21 +323,41 @@ class DistributedGPT3(nn.Module):
             dxf = d_last_hidden
         drop = p_h > 0.0
         dh_m = torch.empty((R, H), dtype=torch.bfloat16, device=dxf.device) if drop else None
-        dh = ops.layernorm_bwd(dxf, tape["h_last"], fl.weight, *tape["sf"], R, H, dx_drop=dh_m, dropout_p=p_h, seed=seed,
-                               offset=_offset(nl, _SITE_DROP2))
+        if tm is not None:      # window rows of the [B*S, H] stream (the other rows of dh / dh_m are never read)
+            dh = torch.empty((R, H), dtype=torch.bfloat16, device=dxf.device)
+            ops.layernorm_bwd(dxf, tape["h_last"], fl.weight, *tape["sf"], B * tm[0], H, dx=dh, dx_drop=dh_m, dropout_p=p_h, seed=seed,
+                              offset=_offset(nl, _SITE_DROP2), xmap=tm)
+        else:
+            dh = ops.layernorm_bwd(dxf, tape["h_last"], fl.weight, *tape["sf"], R, H, dx_drop=dh_m, dropout_p=p_h, seed=seed,
+                                   offset=_offset(nl, _SITE_DROP2))
         for li in range(nl - 1, -1, -1):
             layer, s = lm.encoder.layers[li], tape["layers"][li]
             ln = li + 1
             att, mlp = layer.self_attention, layer.mlp
             F4 = mlp.dense_h_to_4h.out_features
             do = dh_m if drop else dh
-            dz = self._dgrad(do, mlp.dense_4h_to_h.weight, R, F4, H, act_bwd_z=s["z"], act_bwd=ACT_GELU_TANH)
-            dx2 = self._dgrad(dz, mlp.dense_h_to_4h.weight, R, H, F4)
-            dh1_m = torch.empty((R, H), dtype=torch.bfloat16, device=dh.device) if drop else None
-            dh1 = ops.layernorm_bwd(dx2, s["h1"], layer.post_attention_layernorm.weight, *s["s2"], R, H, dres=dh, dx_drop=dh1_m,
-                                    dropout_p=p_h, seed=seed, offset=_offset(ln, _SITE_DROP1))
-            da = dh1_m if drop else dh1
-            dctx = self._dgrad(da, att.dense.weight, R, H, H)
+            if s.get("rows") is not None:
+                # top layer under a loss window (forward_lm): MLP, LN2 and the projection backward on the window rows; the
+                # gradients of the other rows are exact zeros (dh1 feeds LN1's residual gradient, dctx the attention backward)
+                rm = s["rows"]
+                Rw = B * rm[0]
+                dz = self._dgrad(do, mlp.dense_4h_to_h.weight, Rw, F4, H, act_bwd_z=s["z"], act_bwd=ACT_GELU_TANH, amap=rm)
+                dx2 = self._dgrad(dz, mlp.dense_h_to_4h.weight, Rw, H, F4)
+                dh1 = torch.zeros((R, H), dtype=torch.bfloat16, device=dh.device)
+                dh1_m = torch.empty((R, H), dtype=torch.bfloat16, device=dh.device) if drop else None
+                ops.layernorm_bwd(dx2, s["h1"], layer.post_attention_layernorm.weight, *s["s2"], Rw, H, dres=dh, dx=dh1, dx_drop=dh1_m,
+                                  dropout_p=p_h, seed=seed, offset=_offset(ln, _SITE_DROP1), xmap=rm)
+                da = dh1_m if drop else dh1
+                dctx = torch.zeros((R, H), dtype=torch.bfloat16, device=dh.device)
+                self._dgrad(da, att.dense.weight, Rw, H, H, amap=rm, cmap=rm, out=dctx)
+            else:
+                dz = self._dgrad(do, mlp.dense_4h_to_h.weight, R, F4, H, act_bwd_z=s["z"], act_bwd=ACT_GELU_TANH)
+                dx2 = self._dgrad(dz, mlp.dense_h_to_4h.weight, R, H, F4)
+                dh1_m = torch.empty((R, H), dtype=torch.bfloat16, device=dh.device) if drop else None
+                dh1 = ops.layernorm_bwd(dx2, s["h1"], layer.post_attention_layernorm.weight, *s["s2"], R, H, dres=dh, dx_drop=dh1_m,
+                                        dropout_p=p_h, seed=seed, offset=_offset(ln, _SITE_DROP1))
+                da = dh1_m if drop else dh1
+                dctx = self._dgrad(da, att.dense.weight, R, H, H)
             qkv = s["qkv"]
             dqkv = torch.empty_like(qkv)
             ops.attn_bwd(qkv, qkv[:, hn:], qkv[:, 2 * hn:], s["ctx"], s["lse"], dctx, dqkv, dqkv[:, hn:], dqkv[:, 2 * hn:], lay,
