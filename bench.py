@@ -64,7 +64,10 @@ def algorithmic_train_flops(B, T, L, s=Shapes):
     fc = 2 * B * Q * D * H
     # LM head on the L text positions only: the Q query slots are always masked (distributed_gpt3.py:142-159), their logits
     # feed nothing (the reference evaluates them anyway: 2*B*S*H*V); counted as executed here, so step_frac is not inflated
-    gpt = Lyr * 2 * B * S * H * (3 * H + H + 2 * s.ffn) + Lyr * 4 * B * S * S * H + 2 * B * L * H * V
+    # likewise the top decoder layer: its projection and MLP run on the L text rows only (the other rows of the last hidden state
+    # feed nothing once the LM head is windowed); qkv and the attention of that layer stay whole
+    gpt = ((Lyr - 1) * 2 * B * S * H * (3 * H + H + 2 * s.ffn) + 2 * B * S * H * 3 * H + 2 * B * L * H * (H + 2 * s.ffn)
+           + Lyr * 4 * B * S * S * H + 2 * B * L * H * V)
     return 3.0 * (vit + pool + fc) + 2.0 * gpt
 
 
@@ -341,7 +344,7 @@ def main():
         traffic, traffic_src = pmc_traffic()
         roof = {"bound": "mfma", "kernel": "gemm256_kernel<TA,TB,KMAP> (256x256 eight-phase; fwd/dgrad/wgrad) + gemm_bf16_kernel (128x128 fallback)", "achieved": round(fl / tt / 1e12, 1),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / tt / 1e12 / PEAK_BF16_TFLOPS, 4),
-                "traffic": traffic, "traffic_unit": "bytes per launch (L2-miss side: 2*FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
+                "traffic": traffic, "traffic_unit": "bytes per mpv_gemm_bf16 call (L2-miss side: 2*FETCH_SIZE + WRITE_SIZE; a call is 1-3 row-band launches)", "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": round(by / n, 0),
                 "measured": "HIP events around every mpv_gemm_bf16 launch in %d extra steps after the timed region, weight-gradient lane off (kernels do not overlap)" % nroof,
                 "launches_per_step": n // nroof, "avg_launch_us": round(tt / n * 1e6, 1), "avg_launch_gflop": round(fl / n / 1e9, 2),
@@ -353,6 +356,8 @@ def main():
     if dist_on:
         dist.barrier()
     if rank == 0:
+        from youku_mplug_amd import ops as _ops
+        print(f"[bench] mpv_gemm_bf16 calls in this process: {_ops.gemm_calls}", file=sys.stderr)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             ncores = host_cores()

@@ -15,7 +15,8 @@ timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt -o $TAG -- python $R/ben
 python $R/tools/rocpd_stats.py $(find /tmp/kt -name "*.db" | head -1) $OUT/${TAG}_kernel_trace.md > /dev/null
 timeout 400 rocprofv3 --pmc FETCH_SIZE -d /tmp/pf -o f -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/${TAG}_pmc_fetch.log 2>&1
 timeout 400 rocprofv3 --pmc WRITE_SIZE -d /tmp/pw -o w -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/${TAG}_pmc_write.log 2>&1
-python $R/tools/rocpd_pmc.py $(find /tmp/pf -name "*.db" | head -1) $(find /tmp/pw -name "*.db" | head -1) $OUT/${TAG}_pmc_hbm_traffic.md $OUT/pmc_gemm_latest.json > /dev/null
+CALLS=$(grep -o "mpv_gemm_bf16 calls in this process: [0-9]*" $OUT/${TAG}_pmc_fetch.log | grep -o "[0-9]*$" | tail -1)
+python $R/tools/rocpd_pmc.py $(find /tmp/pf -name "*.db" | head -1) $(find /tmp/pw -name "*.db" | head -1) $OUT/${TAG}_pmc_hbm_traffic.md $OUT/pmc_gemm_latest.json ${CALLS:-0} > /dev/null
 # matrix-pipe utilisation (its own pass: SQ + GRBM counters only)
 rm -rf /tmp/pm
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d /tmp/pm -o m -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/${TAG}_pmc_mfma.log 2>&1

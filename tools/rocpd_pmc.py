@@ -40,10 +40,14 @@ def main():
         import json
         gem = [(tot, n) for tot, k, n, fk, wk in rows if k.startswith("gemm_bf16_kernel") or k.startswith("gemm256_kernel")]
         nl = sum(n for _, n in gem)
+        # per mpv_gemm_bf16 CALL (what bench.py's algorithmic bytes are per): a call can be several kernel launches (row bands);
+        # the call count of the profiled process comes from its log (argv[5]), else fall back to kernel launches
+        if len(sys.argv) > 5 and int(sys.argv[5]) > 0:
+            nl = int(sys.argv[5])
         import os
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         from bench import gemm_source_digest
-        json.dump({"hbm_mb_per_launch": round(sum(t for t, _ in gem) / nl / 1024, 1), "launches": nl, "gemm_src_sha": gemm_source_digest(),
+        json.dump({"hbm_mb_per_launch": round(sum(t for t, _ in gem) / nl / 1024, 1), "launches": nl, "per": "mpv_gemm_bf16 call" if len(sys.argv) > 5 and int(sys.argv[5]) > 0 else "kernel launch", "gemm_src_sha": gemm_source_digest(),
                    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 1 --warmup 1`, 2*FETCH+WRITE, " + sys.argv[3]},
                   open(sys.argv[4], "w"))  # note: copy into profiles/ with a repo-relative source
 

@@ -44,6 +44,9 @@ def workspace(nbytes: int, device) -> torch.Tensor:
     return w
 
 
+gemm_calls = 0      # mpv_gemm_bf16 calls of this process (profiles: per-call traffic = counter totals / calls; a call may be several row-band launches)
+
+
 def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: Optional[torch.Tensor] = None,
          trans_a: bool = False, trans_b: bool = False, lda: Optional[int] = None, ldb: Optional[int] = None,
          ldc: Optional[int] = None, bias=None, act: int = 0, preact_out=None, residual=None, ldr: int = 0,
@@ -52,6 +55,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: Optio
          out_rows: Optional[int] = None, accumulate: bool = False, out_f32: bool = False, colsum_out=None,
          tile_hint: int = 0, row_tap_out=None, row_tap_group: int = 0, split_hint: int = 0, gm_hint: int = 0) -> torch.Tensor:
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)).  See include/mpv.h:mpv_gemm_bf16."""
+    global gemm_calls
+    gemm_calls += 1
     _need_cuda(a, b)
     lda = lda if lda is not None else (M if trans_a else K)
     ldb = ldb if ldb is not None else (N if trans_b else K)
