@@ -309,8 +309,10 @@ def main():
     for i in range(args.steps):
         loss = step(args.warmup + i)
         marks[i + 1].record()
+    t_enq = time.perf_counter() - t0            # host time to ENQUEUE the timed steps (no device sync inside a step)
     fence()
     dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    log(f"host enqueue time {t_enq / args.steps * 1e3:.1f} ms/step (launch-bound if this approaches the step time)")
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     if dist_on:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)

@@ -188,6 +188,17 @@ def _qkv_bias(att: Attention):
     return torch.cat([att.q_bias.detach(), torch.zeros_like(att.v_bias), att.v_bias.detach()])
 
 
+def _qkv_biases(atts):
+    """[len(atts), 3D]: row i = cat(q_bias, zeros, v_bias) of atts[i] (models/vision_transformer.py:173), built with
+    five launches for the whole tower instead of a zeros + cat pair per attention."""
+    q = torch.stack([a.q_bias.detach() for a in atts])
+    v = torch.stack([a.v_bias.detach() for a in atts])
+    out = torch.zeros((len(atts), 3, q.shape[1]), dtype=q.dtype, device=q.device)
+    out[:, 0] = q
+    out[:, 2] = v
+    return out.view(len(atts), -1)
+
+
 class TimeSformer(nn.Module):
     def __init__(self, img_size=224, num_frames=4, patch_size=16, in_chans=3, embed_dim=768, depth=12, num_heads=8,
                  mlp_ratio=4.0, eps=1e-6, init_std=0.015, clip_model=True, device=None, **_):
@@ -243,12 +254,13 @@ class TimeSformer(nn.Module):
         else:
             x = x0
         blocks: List[dict] = []
-        for blk in self.blocks:
+        qkv_b = _qkv_biases([a for blk in self.blocks for a in (blk.temporal_attn, blk.attn)])
+        for bi, blk in enumerate(self.blocks):
             s = {}
             # ---- temporal branch on token rows (:247-251)
             lt, s["mt"], s["rt"] = ops.layernorm_fwd(x, blk.temporal_ln.weight, blk.temporal_ln.bias, blk.temporal_ln.eps,
                                                      Rt, D, xmap=tok, ymap=tok, out_rows=R)
-            qkv_t = ops.gemm(lt, blk.temporal_attn.qkv.weight, Rt, 3 * D, D, bias=_qkv_bias(blk.temporal_attn),
+            qkv_t = ops.gemm(lt, blk.temporal_attn.qkv.weight, Rt, 3 * D, D, bias=qkv_b[2 * bi],
                              amap=tok, cmap=tok, out_rows=R)
             at = torch.empty((R, D), dtype=torch.bfloat16, device=x.device)
             ops.temporal_attn_fwd(qkv_t, at, B, T * N1, N, 1, N1, T, heads, hd, blk.temporal_attn.scale)
@@ -259,7 +271,7 @@ class TimeSformer(nn.Module):
             ops.copy_rows(x, xt, B * T, D, smap=(1, N1, 0), dmap=(1, N1, 0))          # cls slots pass through
             # ---- spatial branch on all rows (:254-267)
             l1, s["m1"], s["r1"] = ops.layernorm_fwd(xt, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, R, D)
-            qkv_s = ops.gemm(l1, blk.attn.qkv.weight, R, 3 * D, D, bias=_qkv_bias(blk.attn))
+            qkv_s = ops.gemm(l1, blk.attn.qkv.weight, R, 3 * D, D, bias=qkv_b[2 * bi + 1])
             a_s = torch.empty((R, D), dtype=torch.bfloat16, device=x.device)
             st3 = (N1 * 3 * D, hd, 3 * D)
             lay = ops.AttnLayout(st3, st3, st3, (N1 * D, hd, D))
@@ -337,8 +349,7 @@ class TimeSformer(nn.Module):
             def _qkv_wgrad(dqkv=dqkv):
                 bsum = torch.empty(3 * D, dtype=torch.bfloat16, device=dqkv.device)
                 ops.gemm(dqkv, s["l1"], 3 * D, D, R, trans_a=True, trans_b=True, out=grad_of(blk.attn.qkv.weight), colsum_out=bsum)
-                grad_of(blk.attn.q_bias).copy_(bsum[:D])
-                grad_of(blk.attn.v_bias).copy_(bsum[2 * D:])
+                torch._foreach_copy_([grad_of(blk.attn.q_bias), grad_of(blk.attn.v_bias)], [bsum[:D], bsum[2 * D:]])
             wl(_qkv_wgrad, dqkv)
             dl1 = ops.gemm(dqkv, blk.attn.qkv.weight, R, D, 3 * D, trans_b=True)
             dxt = ops.layernorm_bwd(dl1, s["xt"], blk.norm1.weight, s["m1"], s["r1"], R, D, dres=dy,
@@ -356,8 +367,7 @@ class TimeSformer(nn.Module):
                 bsum_t = torch.empty(3 * D, dtype=torch.bfloat16, device=dqkv_t.device)
                 ops.gemm(dqkv_t, s["lt"], 3 * D, D, Rt, trans_a=True, trans_b=True, kmap=tok,
                          out=grad_of(blk.temporal_attn.qkv.weight), colsum_out=bsum_t)
-                grad_of(blk.temporal_attn.q_bias).copy_(bsum_t[:D])
-                grad_of(blk.temporal_attn.v_bias).copy_(bsum_t[2 * D:])
+                torch._foreach_copy_([grad_of(blk.temporal_attn.q_bias), grad_of(blk.temporal_attn.v_bias)], [bsum_t[:D], bsum_t[2 * D:]])
             wl(_qkv_t_wgrad, dqkv_t)
             dlt = ops.gemm(dqkv_t, blk.temporal_attn.qkv.weight, Rt, D, 3 * D, trans_b=True, amap=tok, cmap=tok, out_rows=R)
             wl.sync()                                   # temporal_fc's wgrad reads dxt, which the next launch updates in place
