@@ -30,6 +30,7 @@
 //  * wgrad: the fused bias gradient (column sums of the A operand) is one extra MFMA per A fragment against a
 //    constant ones operand, spread over the four wave columns.
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "mpv_common.h"
@@ -601,9 +602,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 struct Band { int rows, m_tiles; };
 // Row-band plan of one product (see mpv_gemm256_try_launch): fills plan[0..n) with (tile rows, m-tiles) in row order.
 int plan_bands(int M, int tn, int K, float epi_tiles, int ncu, Band plan[3]) {
+  // MPV_BAND_*: measurement overrides of the model constants (percent / rounds), read once
+  static const float rel192 = [] { const char* e = getenv("MPV_BAND_REL192"); return e ? atoi(e) * 0.01f : 0.80f; }();
+  static const float rel160 = [] { const char* e = getenv("MPV_BAND_REL160"); return e ? atoi(e) * 0.01f : 0.73f; }();
+  static const float thr = [] { const char* e = getenv("MPV_BAND_THR"); return e ? atoi(e) * 0.01f : 0.97f; }();
+  static const int maxr = [] { const char* e = getenv("MPV_BAND_MAXR"); return e ? atoi(e) : 4; }();
   const float nk = (float)(K / TK);
   const float epi = 4.9f * epi_tiles;
-  auto tile_us = [&](int r) { return 2.2f + 1.31f * nk * (r == 256 ? 1.0f : r == 192 ? 0.80f : 0.73f) + epi * (float)r * (1.0f / 256.0f); };
+  auto tile_us = [&](int r) { return 2.2f + 1.31f * nk * (r == 256 ? 1.0f : r == 192 ? rel192 : rel160) + epi * (float)r * (1.0f / 256.0f); };
   auto band_us = [&](int r, int mt) { return mt > 0 ? (float)(((long long)mt * tn + ncu - 1) / ncu) * tile_us(r) + 2.5f : 0.f; };
   const int all256 = (M + 255) / 256;
   int nband = 1;
@@ -613,7 +619,7 @@ int plan_bands(int M, int tn, int K, float epi_tiles, int ncu, Band plan[3]) {
   // measured (tools/gemm_ab.py, 256 CUs): launches of a few rounds gain 2-5 % (N = 768 ViT shapes at 2.31 rounds, the GPT
   // N = 8192 shapes at 2.5); at ~9 rounds (N = 3072) the workgroups have drifted apart, the last round is no longer
   // paid in full and cutting the launch only adds tails (-2..-4 %): single launch from 5 rounds on
-  if (((long long)all256 * tn + ncu - 1) / ncu > 4) return 1;
+  if (((long long)all256 * tn + ncu - 1) / ncu > maxr) return 1;
   // candidates: n256 m-tiles of 256 rows filling whole rounds, then n192 m-tiles of 192 rows likewise, the rest at 160 / 192 / 256
   for (int r1 = 0;; ++r1) {
     int n256 = (int)((long long)r1 * ncu / tn);
@@ -642,7 +648,7 @@ int plan_bands(int M, int tn, int K, float epi_tiles, int ncu, Band plan[3]) {
     }
     if (last1) break;
   }
-  if (best > 0.97f * single256) {                           // not worth the extra launches
+  if (best > thr * single256) {                           // not worth the extra launches
     nband = 1;
     plan[0] = Band{256, all256};
   }
@@ -679,7 +685,10 @@ bool mpv_gemm256_try_launch(const GemmArgs& g0, int transA, int transB, hipStrea
   if (g.K % TK != 0 || g.k_per_split % TK != 0) return false;
   if (g.tail_g > 1) return false;
   g.tiles_n = (g.N + TN - 1) / TN;
-  g.gm = g.gm > 0 ? g.gm : 4;
+  // MPV_GEMM_GM / MPV_GEMM_BANDS=0: measurement knobs (XCD walk width; row bands off), read once
+  static const int env_gm = [] { const char* e = getenv("MPV_GEMM_GM"); return e ? atoi(e) : 0; }();
+  static const bool env_bands = [] { const char* e = getenv("MPV_GEMM_BANDS"); return !e || atoi(e) != 0; }();
+  g.gm = g.gm > 0 ? g.gm : env_gm > 0 ? env_gm : 4;
   const bool km = (transA || transB) && g.kmap.group != 0;
   // Tile rows.  A launch runs in rounds of one workgroup per CU, and a partly filled last round costs a whole tile time
   // (M = 50432, N = 768: 591 tiles = 2.31 rounds on 256 CUs, paid as 3).  With a k-contiguous A operand (forward and
@@ -694,7 +703,7 @@ bool mpv_gemm256_try_launch(const GemmArgs& g0, int transA, int transB, hipStrea
   int nband = 1;
   if (bandable && (g.tile_rows == 192 || g.tile_rows == 160)) {
     plan[0] = Band{g.tile_rows, (g.M + g.tile_rows - 1) / g.tile_rows};
-  } else if (bandable && g.tile_rows == 0) {
+  } else if (bandable && g.tile_rows == 0 && env_bands) {
     static int ncu = 0;
     if (!ncu) {
       int dev = 0;
