@@ -20,6 +20,7 @@ is dropped: 288 GB of HBM hold every activation.
 from __future__ import annotations
 
 import math
+import os
 from typing import List
 
 import torch
@@ -181,6 +182,11 @@ class _WgradLane:
     def sync(self):
         if self.on:
             torch.cuda.current_stream().wait_stream(self.side)
+
+
+# MPV_VIT_COMPOSE=0: measurement knob -- backward of temporal_attn.proj / temporal_fc as the reference's two dgrads + two wgrads
+# instead of the composed projection (TimeSformer.backward_features)
+COMPOSE_TEMPORAL_OUT = os.environ.get("MPV_VIT_COMPOSE", "1") != "0"
 
 
 def _qkv_bias(att: Attention):
@@ -355,12 +361,33 @@ class TimeSformer(nn.Module):
             dxt = ops.layernorm_bwd(dl1, s["xt"], blk.norm1.weight, s["m1"], s["r1"], R, D, dres=dy,
                                     dgamma=grad_of(blk.norm1.weight), dbeta=grad_of(blk.norm1.bias))
             # ---- temporal branch (token rows)
-            wl(lambda: ops.gemm(dxt, s["pt"], D, D, Rt, trans_a=True, trans_b=True, kmap=tok, out=grad_of(blk.temporal_fc.weight),
-                                colsum_out=grad_of(blk.temporal_fc.bias)), dxt)
-            dpt = ops.gemm(dxt, blk.temporal_fc.weight, Rt, D, D, trans_b=True, amap=tok, cmap=tok, out_rows=R)
-            wl(lambda: ops.gemm(dpt, s["at"], D, D, Rt, trans_a=True, trans_b=True, kmap=tok, out=grad_of(blk.temporal_attn.proj.weight),
-                                colsum_out=grad_of(blk.temporal_attn.proj.bias)), dpt)
-            dat = ops.gemm(dpt, blk.temporal_attn.proj.weight, Rt, D, D, trans_b=True, amap=tok, cmap=tok, out_rows=R)
+            if COMPOSE_TEMPORAL_OUT:
+                # Backward of temporal_attn.proj followed by temporal_fc (:199-200 then :250; proj_drop = 0, only a rearrange
+                # between them) as ONE linear map: xt = x + a Wc^T + bc with Wc = Wf Wp, bc = Wf bp + bf.  One dgrad
+                # d(a) = d(xt) Wc and one wgrad dWc = d(xt)^T a over the 50176 token rows instead of two of each; the chain
+                # rule through the composition runs on [D, D] operands (768^3 products): dWf = dWc Wp^T + d(bc) bp^T,
+                # dWp = Wf^T dWc, d(bp) = Wf^T d(bc), d(bf) = d(bc).  The forward keeps the reference's two launches and its
+                # bf16 rounding of proj(a): forward values are untouched, gradients agree to rounding (golden tests).
+                wf, wp = blk.temporal_fc.weight.detach(), blk.temporal_attn.proj.weight.detach()
+                wc = ops.gemm(wf, wp, D, D, D, trans_b=True)                                   # Wc = Wf Wp
+
+                def _temporal_out_wgrad(dxt=dxt, wf=wf, wp=wp):
+                    dbc = grad_of(blk.temporal_fc.bias)                                   # d(bf) = d(bc) = colsum d(xt)
+                    dwc = ops.gemm(dxt, s["at"], D, D, Rt, trans_a=True, trans_b=True, kmap=tok, colsum_out=dbc)
+                    dwf = ops.gemm(dwc, wp, D, D, D)                                     # dWc Wp^T
+                    bp = blk.temporal_attn.proj.bias.detach().float()
+                    grad_of(blk.temporal_fc.weight).copy_(dwf.float() + dbc.float()[:, None] * bp[None, :])
+                    ops.gemm(wf, dwc, D, D, D, trans_a=True, trans_b=True, out=grad_of(blk.temporal_attn.proj.weight))   # Wf^T dWc
+                    grad_of(blk.temporal_attn.proj.bias).copy_((wf.float() * dbc.float()[:, None]).sum(0))              # Wf^T d(bc)
+                wl(_temporal_out_wgrad, dxt)
+                dat = ops.gemm(dxt, wc, Rt, D, D, trans_b=True, amap=tok, cmap=tok, out_rows=R)
+            else:       # the reference's two dgrads and two wgrads (measurement: MPV_VIT_COMPOSE=0)
+                wl(lambda: ops.gemm(dxt, s["pt"], D, D, Rt, trans_a=True, trans_b=True, kmap=tok, out=grad_of(blk.temporal_fc.weight),
+                                    colsum_out=grad_of(blk.temporal_fc.bias)), dxt)
+                dpt = ops.gemm(dxt, blk.temporal_fc.weight, Rt, D, D, trans_b=True, amap=tok, cmap=tok, out_rows=R)
+                wl(lambda: ops.gemm(dpt, s["at"], D, D, Rt, trans_a=True, trans_b=True, kmap=tok, out=grad_of(blk.temporal_attn.proj.weight),
+                                    colsum_out=grad_of(blk.temporal_attn.proj.bias)), dpt)
+                dat = ops.gemm(dpt, blk.temporal_attn.proj.weight, Rt, D, D, trans_b=True, amap=tok, cmap=tok, out_rows=R)
             dqkv_t = torch.empty_like(s["qkv_t"])
             ops.temporal_attn_bwd(s["qkv_t"], dat, dqkv_t, B, T * N1, N, 1, N1, T, heads, hd, blk.temporal_attn.scale)
             def _qkv_t_wgrad(dqkv_t=dqkv_t):
