@@ -187,6 +187,7 @@ class _WgradLane:
 # MPV_VIT_COMPOSE=0: measurement knob -- backward of temporal_attn.proj / temporal_fc as the reference's two dgrads + two wgrads
 # instead of the composed projection (TimeSformer.backward_features)
 COMPOSE_TEMPORAL_OUT = os.environ.get("MPV_VIT_COMPOSE", "1") != "0"
+_SMALL_TILE = int(os.environ.get("MPV_VIT_SMALL_TILE", "128"))    # tile kernel of the [D, D] chain-rule products: 36 tiles of 128x128 beat 9 of 256x256 (same-box 78.5 -> 78.35 ms per step)
 
 
 def _qkv_bias(att: Attention):
@@ -369,15 +370,15 @@ class TimeSformer(nn.Module):
                 # dWp = Wf^T dWc, d(bp) = Wf^T d(bc), d(bf) = d(bc).  The forward keeps the reference's two launches and its
                 # bf16 rounding of proj(a): forward values are untouched, gradients agree to rounding (golden tests).
                 wf, wp = blk.temporal_fc.weight.detach(), blk.temporal_attn.proj.weight.detach()
-                wc = ops.gemm(wf, wp, D, D, D, trans_b=True)                                   # Wc = Wf Wp
+                wc = ops.gemm(wf, wp, D, D, D, trans_b=True, tile_hint=_SMALL_TILE)                # Wc = Wf Wp
 
                 def _temporal_out_wgrad(dxt=dxt, wf=wf, wp=wp):
                     dbc = grad_of(blk.temporal_fc.bias)                                   # d(bf) = d(bc) = colsum d(xt)
                     dwc = ops.gemm(dxt, s["at"], D, D, Rt, trans_a=True, trans_b=True, kmap=tok, colsum_out=dbc)
-                    dwf = ops.gemm(dwc, wp, D, D, D)                                     # dWc Wp^T
+                    dwf = ops.gemm(dwc, wp, D, D, D, tile_hint=_SMALL_TILE)               # dWc Wp^T
                     bp = blk.temporal_attn.proj.bias.detach().float()
                     grad_of(blk.temporal_fc.weight).copy_(dwf.float() + dbc.float()[:, None] * bp[None, :])
-                    ops.gemm(wf, dwc, D, D, D, trans_a=True, trans_b=True, out=grad_of(blk.temporal_attn.proj.weight))   # Wf^T dWc
+                    ops.gemm(wf, dwc, D, D, D, trans_a=True, trans_b=True, out=grad_of(blk.temporal_attn.proj.weight), tile_hint=_SMALL_TILE)   # Wf^T dWc
                     grad_of(blk.temporal_attn.proj.bias).copy_((wf.float() * dbc.float()[:, None]).sum(0))              # Wf^T d(bc)
                 wl(_temporal_out_wgrad, dxt)
                 dat = ops.gemm(dxt, wc, Rt, D, D, trans_b=True, amap=tok, cmap=tok, out_rows=R)
