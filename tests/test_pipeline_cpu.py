@@ -1,0 +1,128 @@
+"""The real host pipelines (vision.py / gpt3.py / pretrain.py) on CPU, with the device entry points replaced by the torch
+stand-ins of tests/standin_ops.py (each restating its C contract of include/mpv.h): row maps, strides, tapes, the loss
+window of the decoder and the composed temporal-projection backward are host logic and are checked here against the
+reference goldens (tests/golden/tiny.pt, produced by the reference's own modules) without a GPU.  The kernels themselves
+are checked on the GPU (`-m gpu`) against the same goldens."""
+import math
+import os
+import types
+
+import pytest
+import torch
+
+import standin_ops
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def _build(monkeypatch, wseed):
+    from oracle.weights import CONFIG_TINY, make_state_dict
+    from youku_mplug_amd.pretrain import synthetic_model
+    standin_ops.install(monkeypatch)
+    model = synthetic_model(CONFIG_TINY, device="cpu")
+    sd = make_state_dict(CONFIG_TINY, wseed)
+    model.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+    return model, CONFIG_TINY
+
+
+def _inputs(cfg, meta):
+    from oracle.weights import make_inputs
+    video, ids, mask = make_inputs(cfg, meta["batch"], meta["text_len"], seed=meta["input_seed"], ragged=meta["ragged"])
+    return video.to(torch.bfloat16), types.SimpleNamespace(input_ids=ids, attention_mask=mask)
+
+
+def _grads(model):
+    return {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.requires_grad and p.grad is not None}
+
+
+def test_pipelines_on_standins_vs_reference_golden(monkeypatch):
+    g = torch.load(os.path.join(GOLD, "tiny.pt"))
+    meta, f32, b16 = g["meta"], g["fp32"], g["bf16"]
+    model, cfg = _build(monkeypatch, meta["weight_seed"])
+    video, text = _inputs(cfg, meta)
+    model.eval()
+    out = model.forward_outputs(video, text)                      # full evaluation: logits / hidden / per-token losses
+    sfrom, vstep = meta["logits_seq_from"], meta["logits_vocab_step"]
+    hs = max(1, cfg.hidden // 256)
+    for what, mine, key, floor in (("logits", out.logits[:, sfrom:, ::vstep], "logits", 1e-2),
+                                   ("hidden", out.last_hidden_state[:, :, ::hs], "last_hidden_state", 2e-2),
+                                   ("losses", out.losses, "losses", 1e-2)):
+        e, e_ref = rel(mine, f32[key]), rel(b16[key], f32[key])
+        assert math.isfinite(e) and e <= max(floor, 1.5 * e_ref), f"{what}: {e:.3e} (reference bf16 deviation {e_ref:.3e})"
+    loss, _ = model(video, text)                                  # training entry: loss window + explicit backward pipelines
+    assert abs(loss.item() - f32["loss"].item()) <= max(2e-3 * abs(f32["loss"].item()), 2 * abs(b16["loss"].item() - f32["loss"].item()))
+    loss.backward()
+    bad = []
+    for n, gr in _grads(model).items():
+        assert n in f32["grad_norm"], n
+        e = abs(gr.norm().item() - f32["grad_norm"][n]) / (f32["grad_norm"][n] + 1e-12)
+        e_ref = abs(b16["grad_norm"][n] - f32["grad_norm"][n]) / (f32["grad_norm"][n] + 1e-12)
+        f = gr.reshape(-1)
+        smp = f[::max(1, f.numel() // 64)][:64]
+        es, es_ref = rel(smp, f32["grad_sample"][n]), rel(b16["grad_sample"][n], f32["grad_sample"][n])
+        if e > max(2e-2, 3 * e_ref) or es > max(8e-2, 3 * es_ref):
+            bad.append((n, e, e_ref, es, es_ref))
+    assert not bad, bad[:8]
+
+
+def test_composed_temporal_backward_matches_two_launch_backward(monkeypatch):
+    """TimeSformer.backward_features: proj + temporal_fc as one composed projection vs the reference's two dgrads and two
+    wgrads -- the same gradients up to bf16 rounding of the intermediate products, for every parameter."""
+    from youku_mplug_amd import vision
+    g = torch.load(os.path.join(GOLD, "tiny.pt"))
+    meta = g["meta"]
+    res = {}
+    for compose in (True, False):
+        monkeypatch.setattr(vision, "COMPOSE_TEMPORAL_OUT", compose)
+        model, cfg = _build(monkeypatch, meta["weight_seed"])
+        with torch.no_grad():      # the golden weights leave temporal_fc at its zero init: make the composition non-trivial
+            gen = torch.Generator().manual_seed(3)
+            for blk in model.visual_encoder.blocks:
+                blk.temporal_fc.weight.copy_((torch.randn(blk.temporal_fc.weight.shape, generator=gen) * 0.05).to(torch.bfloat16))
+                blk.temporal_fc.bias.copy_((torch.randn(blk.temporal_fc.bias.shape, generator=gen) * 0.05).to(torch.bfloat16))
+                blk.temporal_attn.proj.bias.copy_((torch.randn(blk.temporal_attn.proj.bias.shape, generator=gen) * 0.05).to(torch.bfloat16))
+        video, text = _inputs(cfg, meta)
+        model.eval()
+        loss, _ = model(video, text)
+        loss.backward()
+        res[compose] = (loss.item(), _grads(model))
+    assert res[True][0] == res[False][0], "the forward is the same code in both modes"
+    for n, ga in res[True][1].items():
+        gb = res[False][1][n]
+        e = (ga - gb).abs().max().item() / (gb.abs().max().item() + 1e-12)
+        assert e <= 3e-2, f"{n}: composed vs two-launch backward differ by {e:.3e}"
+        en = abs(ga.norm().item() - gb.norm().item()) / (gb.norm().item() + 1e-12)
+        assert en <= 5e-3, f"{n}: gradient norms differ by {en:.3e}"
+
+
+def test_loss_window_is_exact_on_standins(monkeypatch):
+    """gpt3.DistributedGPT3.forward_lm / backward_lm: the loss-window form (LM head, CE, top-layer projection / LN2 / MLP /
+    final LayerNorm on the window rows) against the full evaluation: same loss, same per-token losses inside the window, same
+    gradient of the query features."""
+    model, cfg = _build(monkeypatch, 0)
+    model.eval()
+    dec = model.text_decoder
+    from oracle.weights import make_inputs
+    B, L = 3, 12
+    _, ids, mask = make_inputs(cfg, B, L, seed=77, ragged=True)
+    Q, H = model.num_learnable_token, model.text_width
+    gen = torch.Generator().manual_seed(5)
+    qf = (torch.randn(B * Q, H, generator=gen) * 0.5).to(torch.bfloat16)
+    targets = torch.cat([torch.full((B, Q), 100, dtype=torch.long), ids[:, 1:], ids[:, 1:2]], dim=1)
+    loss_mask = torch.cat([torch.zeros((B, Q), dtype=torch.long), mask[:, 1:]], dim=1)
+    one = torch.ones((), dtype=torch.float32)
+    res = {}
+    for name, win in (("full", None), ("window", (Q, L))):
+        tape = {}
+        out = dec.forward_lm(qf, ids, targets, loss_mask, tape, loss_window=win)
+        res[name] = (out["loss"].float().item(), out["losses"].float(), dec.backward_lm(tape, one).float(), out["last_hidden_state"])
+    assert res["full"][3] is not None and res["window"][3] is None
+    assert abs(res["full"][0] - res["window"][0]) <= 1e-6 * abs(res["full"][0]) + 1e-7
+    assert torch.equal(res["full"][1][:, Q:], res["window"][1][:, Q:])
+    assert res["window"][1][:, :Q].abs().max().item() == 0.0
+    assert rel(res["window"][2], res["full"][2]) <= 1e-2

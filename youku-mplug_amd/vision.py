@@ -166,7 +166,7 @@ class _WgradLane:
 
     def __init__(self, device):
         import os
-        self.on = os.environ.get("MPV_WGRAD_STREAM", "1") == "1"
+        self.on = os.environ.get("MPV_WGRAD_STREAM", "1") == "1" and torch.device(device).type == "cuda"
         self.side = torch.cuda.Stream(device=device) if self.on else None
 
     def __call__(self, fn, *tensors):
