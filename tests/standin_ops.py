@@ -320,7 +320,45 @@ def cross_entropy(logits, labels, weight, rows, vocab, *, ld=None, dlogits=None,
     return (losses if want_losses else None), (losses * w).sum()
 
 
-NAMES = ["gemm", "layernorm_fwd", "layernorm_bwd", "AttnLayout", "attn_fwd", "attn_bwd", "temporal_attn_fwd", "temporal_attn_bwd",
+def add(a, b, out=None):
+    out = out if out is not None else torch.empty_like(a)
+    out.copy_((a.float() + b.float()).to(BF))
+    return out
+
+
+def gather_rows(src, idx, rows, cols, ld=None):
+    return _rd(src, idx.view(-1)[:rows], ld or cols, cols).to(BF)
+
+
+def scatter_rows(src, idx, dst, rows, cols, ld=None):
+    _wr(dst, idx.view(-1)[:rows], ld or cols, _rd(src, torch.arange(rows), cols, cols))
+    return dst
+
+
+def l2norm_fwd(x, rows, cols, eps=1e-12):
+    xv = _rd(x, torch.arange(rows), cols, cols)
+    n = xv.norm(dim=1).clamp_min(eps)
+    return (xv / n[:, None]).to(BF), n
+
+
+def l2norm_bwd(dy, x, nrm, rows, cols):
+    y = _rd(x, torch.arange(rows), cols, cols) / nrm[:rows, None]
+    dv = _rd(dy, torch.arange(rows), cols, cols)
+    return ((dv - y * (y * dv).sum(1, keepdim=True)) / nrm[:rows, None]).to(BF)
+
+
+def soft_target_ce(sim, row_ids, col_ids, scale, rows, cols, want_grad=True):
+    s = sim.float().view(rows, cols)
+    t = (row_ids.view(-1)[:rows, None] == col_ids.view(-1)[None, :cols]).float()
+    t = t / t.sum(1, keepdim=True)
+    losses = -(torch.log_softmax(s, dim=1) * t).sum(1)
+    if not want_grad:
+        return losses, None, None
+    dsim = ((torch.softmax(s, dim=1) - t) * scale).to(BF)
+    return losses, dsim, (dsim.float() * s).sum(1)
+
+
+NAMES = ["add", "gather_rows", "scatter_rows", "l2norm_fwd", "l2norm_bwd", "soft_target_ce", "gemm", "layernorm_fwd", "layernorm_bwd", "AttnLayout", "attn_fwd", "attn_bwd", "temporal_attn_fwd", "temporal_attn_bwd",
          "im2col_patches", "vit_embed_assemble_fwd", "vit_embed_assemble_bwd", "vit_cls_fix_fwd", "vit_cls_merge_bwd_inplace",
          "copy_rows", "colsum", "gpt_embed_fwd", "gpt_embed_bwd", "cross_entropy"]
 

@@ -126,3 +126,30 @@ def test_loss_window_is_exact_on_standins(monkeypatch):
     assert torch.equal(res["full"][1][:, Q:], res["window"][1][:, Q:])
     assert res["window"][1][:, :Q].abs().max().item() == 0.0
     assert rel(res["window"][2], res["full"][2]) <= 1e-2
+
+
+def _on_cpu(monkeypatch):
+    standin_ops.install(monkeypatch)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    return torch.device("cpu")
+
+
+def test_retrieval_itc_pipeline_on_standins(monkeypatch):
+    """retrieval.DistributedGPT3_Retrieval (ITC; models/distributed_gpt3.py:817-985) through the same golden check as the GPU
+    test, host pipelines on the stand-ins."""
+    import test_model_gpu as t
+    t.test_retrieval_itc_vs_reference_golden(_on_cpu(monkeypatch))
+
+
+def test_eva_image_pipeline_on_standins(monkeypatch):
+    """eva_vit.EvaVisionTransformer inside DistributedGPT3_Pretrain_Image (models/eva_vit.py, distributed_gpt3.py:229-427)."""
+    import test_model_gpu as t
+    t.test_eva_image_model_vs_reference_golden(_on_cpu(monkeypatch))
+
+
+@pytest.mark.parametrize("kind", ["itm", "cls"])
+def test_generation_cls_heads_pipeline_on_standins(monkeypatch, kind):
+    """downstream.DistributedGPT3_Retrieval_Cls / DistributedGPT3_Cls (models/distributed_gpt3.py:988-1218, 431-657): both
+    losses, every gradient and the train=False scores, host pipelines on the stand-ins."""
+    import test_model_gpu as t
+    t.test_generation_cls_heads_vs_reference_golden(_on_cpu(monkeypatch), kind)
