@@ -153,3 +153,78 @@ def test_generation_cls_heads_pipeline_on_standins(monkeypatch, kind):
     losses, every gradient and the train=False scores, host pipelines on the stand-ins."""
     import test_model_gpu as t
     t.test_generation_cls_heads_vs_reference_golden(_on_cpu(monkeypatch), kind)
+
+
+# ------------------------------------------------------------------------------------------------ data parallel, real model
+class _MP:      # minimal monkeypatch for spawned workers
+    def setattr(self, obj, name, val):
+        setattr(obj, name, val)
+
+
+def _dp_setup(seed):
+    from oracle.weights import CONFIG_TINY, make_inputs
+    from test_engine_cpu import _stub_optimizer_kernels
+    from youku_mplug_amd import engine as eng
+    from youku_mplug_amd.pretrain import synthetic_model
+    standin_ops.install(_MP())
+    _stub_optimizer_kernels(_MP())
+    torch.manual_seed(seed)
+    model = synthetic_model(CONFIG_TINY, device="cpu")
+    model.eval()                                     # the stand-ins do not model the hash dropout
+    groups = eng.get_parameter_groups(model, 0.05, model.no_weight_decay(), visual_backbone_scale=True)
+    engine, opt, _, _ = eng.initialize(model=model, model_parameters=groups, config=dict(lr=1e-4, clip_grad=3.0))
+    video, ids, mask = make_inputs(CONFIG_TINY, 4, 8, seed=9, ragged=False)     # equal token counts: mean of rank means = batch mean
+    return engine, video.to(torch.bfloat16), ids, mask
+
+
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    engine, video, ids, mask = _dp_setup(1234 + rank)            # the reference seeds every rank differently
+    launched = []
+    orig = engine.reducer.stage_ready
+    engine.reducer.stage_ready = lambda name: (launched.append(name), orig(name))[1]
+    engine.module.visual_encoder.on_block_grads_ready = lambda bi: engine.reducer.stage_ready("stem" if bi < 0 else f"block{bi}")
+    engine.module.on_stage_grads_ready = engine.reducer.stage_ready
+    p0 = engine.flat.params.clone()
+    sl = slice(rank * 2, rank * 2 + 2)
+    text = types.SimpleNamespace(input_ids=ids[sl], attention_mask=mask[sl])
+    loss, _ = engine(video[sl], text)
+    engine.backward(loss)
+    first = list(launched)
+    engine.reducer.finish()
+    q.put((rank, p0, engine.flat.grads.clone(), first, loss.item()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_real_model_data_parallel_world2_gloo():
+    """The REAL tiny DistributedGPT3_Pretrain under the real MplugEngine / DPReducer on two gloo ranks (device entry points on
+    the stand-ins): replicas identical after initialize() although seeded differently, buckets announced by the real backward
+    pipelines in completion order (head, ViT blocks from the last to the first, stem), and the reduced gradient / world equal
+    to the gradient of the whole batch in one process (run_pretrain_distributed_gpt3.py:263-274, DeepSpeed's averaged all-reduce)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 26000 + os.getpid() % 3000
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r[1:] for r in (q.get(timeout=300) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert torch.equal(res[0][0], res[1][0]), "parameters must be broadcast from rank 0 at initialize()"
+    assert torch.equal(res[0][1], res[1][1]), "every rank holds the same reduced gradient"
+    assert res[0][2] == ["head", "block1", "block0", "stem"], res[0][2]
+    engine, video, ids, mask = _dp_setup(1234)                     # one process, whole batch, rank 0's initialisation
+    assert torch.equal(engine.flat.params, res[0][0])
+    loss, _ = engine(video, types.SimpleNamespace(input_ids=ids, attention_mask=mask))
+    engine.backward(loss)
+    assert abs(loss.item() - 0.5 * (res[0][3] + res[1][3])) <= 2e-3 * abs(loss.item())
+    full, summed = engine.flat.grads.float(), res[0][1].float()
+    for name, (a, b) in engine.flat.stage_slices.items():
+        ga, gb = 0.5 * summed[a:b], full[a:b]
+        cos = torch.dot(ga, gb) / (ga.norm() * gb.norm() + 1e-30)
+        assert cos > 0.999 and abs(ga.norm() - gb.norm()) <= 2e-2 * gb.norm(), (name, cos.item(), ga.norm().item(), gb.norm().item())
