@@ -228,3 +228,28 @@ def test_real_model_data_parallel_world2_gloo():
         ga, gb = 0.5 * summed[a:b], full[a:b]
         cos = torch.dot(ga, gb) / (ga.norm() * gb.norm() + 1e-30)
         assert cos > 0.999 and abs(ga.norm() - gb.norm()) <= 2e-2 * gb.norm(), (name, cos.item(), ga.norm().item(), gb.norm().item())
+
+
+def test_entrypoint_loop_on_standins(tmp_path, monkeypatch):
+    """run_pretrain_distributed_gpt3.py (the reference's entry point restated on this engine: CLI, YAML + JSON configs, epoch
+    loop, per-step schedule mutation, loss all-gather / NaN guard, checkpoint + `latest` + log cadence, auto-resume) driven on
+    CPU / gloo for 2 epochs x 3 steps with the device entry points on the stand-ins -- the same assertions as the GPU test
+    (tests/test_entrypoint_gpu.py), dropout set to 0 in the decoder config because the stand-ins do not model it."""
+    import json
+    import test_entrypoint_gpu as t
+    from test_engine_cpu import _stub_optimizer_kernels
+    orig = t._write_configs
+
+    def write(d, update_freq=1):
+        path = orig(d, update_freq)
+        cfg = json.load(open(os.path.join(d, "txt.json")))
+        cfg.update(hidden_dropout=0.0, attention_dropout=0.0)
+        json.dump(cfg, open(os.path.join(d, "txt.json"), "w"))
+        return path
+    monkeypatch.setattr(t, "_write_configs", write)
+    _stub_optimizer_kernels(monkeypatch)
+    monkeypatch.setenv("MASTER_PORT", str(27000 + os.getpid() % 2000))
+    t.test_entrypoint_three_steps_from_yaml(tmp_path, _on_cpu(monkeypatch))
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.destroy_process_group()
