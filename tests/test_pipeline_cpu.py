@@ -253,3 +253,24 @@ def test_entrypoint_loop_on_standins(tmp_path, monkeypatch):
     import torch.distributed as dist
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def test_kv_cache_decode_on_standins(monkeypatch):
+    """generation.DecodeState (prefill + single-token steps + beam re-order over the KV caches) against one full causal forward,
+    host logic on the stand-ins (the C decode step restated in tests/standin_ops.decode_step)."""
+    import test_model_gpu as t
+    t.test_kv_cache_decode_matches_full_forward(_on_cpu(monkeypatch))
+
+
+def test_caption_generate_on_standins(monkeypatch):
+    """DistributedGPT3_Caption.generate: beam search over the KV-cache path, token-exact against the reference module's golden."""
+    import test_model_gpu as t
+    from youku_mplug_amd import downstream
+    orig = downstream.synthetic_gencls_model
+
+    def build(*a, **k):      # the test ends with a train-mode caption loss: the stand-ins do not model the decoder's dropout
+        m = orig(*a, **k)
+        m.text_decoder.config.hidden_dropout = m.text_decoder.config.attention_dropout = 0.0
+        return m
+    monkeypatch.setattr(downstream, "synthetic_gencls_model", build)
+    t.test_caption_generate_vs_reference_golden(_on_cpu(monkeypatch))
