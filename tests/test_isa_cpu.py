@@ -1,0 +1,102 @@
+"""Build-time guards on the gfx950 code objects inside libmpv_hip.so (no GPU needed): register / LDS / scratch budgets of
+the hot kernels -- the occupancy every measured number in DESIGN.md rests on -- and the CDNA4 instructions the design depends
+on (16x16x32 bf16 MFMA, LDS-DMA, the transposing LDS read).  A compiler or source change that pushes the 256x256 GEMM past
+256 VGPRs (spills) or the LayerNorm backward past 128 (3 instead of 4 waves per SIMD) fails here, on CPU."""
+import os
+import re
+import struct
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "youku-mplug_amd", "libmpv_hip.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def _code_objects():
+    data = open(LIB, "rb").read()
+    out = []
+    for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", data):
+        p = m.start()
+        (n,) = struct.unpack_from("<Q", data, p + 24)
+        off = p + 32
+        for _ in range(n):
+            o, s, tl = struct.unpack_from("<QQQ", data, off)
+            off += 24
+            triple = data[off:off + tl].decode()
+            off += tl
+            if "gfx950" in triple and s > 0:
+                out.append(data[p + o:p + o + s])
+    return out
+
+
+@pytest.fixture(scope="module")
+def kernels(tmp_path_factory):
+    if not os.path.isfile(os.path.join(LLVM, "llvm-readelf")):
+        pytest.skip("ROCm LLVM tools not present")
+    d = tmp_path_factory.mktemp("co")
+    ks, files = {}, []
+    for i, blob in enumerate(_code_objects()):
+        f = str(d / f"co_{i}.elf")
+        open(f, "wb").write(blob)
+        files.append(f)
+        txt = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", f], capture_output=True, text=True).stdout
+        for blk in txt.split("- .agpr_count:")[1:]:
+            g = lambda key: int(re.search(r"\." + key + r":\s+(\d+)", blk).group(1))
+            name = re.search(r"\.name:\s+(\S+)", blk).group(1)          # mangled: template arguments read as ILb0ELi4EE etc.
+            ks[name] = dict(vgpr=g("vgpr_count"), agpr=int(blk.split()[0]), sgpr=g("sgpr_count"), lds=g("group_segment_fixed_size"),
+                           scratch=g("private_segment_fixed_size"), file=f)
+    assert len(ks) > 80, f"only {len(ks)} kernels found in {LIB}"
+    return ks, files
+
+
+def _sel(ks, frag):
+    r = {n: k for n, k in ks.items() if frag in n}
+    assert r, frag
+    return r
+
+
+def test_gemm_kernels_fit_their_occupancy(kernels):
+    ks, _ = kernels
+    for n, k in _sel(ks, "14gemm256_kernelI").items():      # one 512-thread workgroup per CU = 2 waves per SIMD: 256 registers
+        assert k["scratch"] == 0 and k["vgpr"] + k["agpr"] <= 256 and k["lds"] == 135168, (n, k)
+    assert len(_sel(ks, "14gemm256_kernelI")) == 9          # fwd x {256,192,160}, dgrad x {256,192,160}, kmapped dgrad, wgrad, kmapped wgrad
+    for n, k in _sel(ks, "16gemm_bf16_kernelI").items():    # two 256-thread workgroups per CU
+        assert k["scratch"] == 0 and k["vgpr"] <= 256 and k["lds"] == 65536, (n, k)
+
+
+def test_streaming_kernels_keep_their_waves(kernels):
+    ks, _ = kernels
+    budget = {"14ln_fwd8_kernelILi2EE": 72, "14ln_fwd8_kernelILi4EE": 128, "14ln_bwd8_kernelILi2ELb1EE": 128,      # <2>, <4>, <2, true>
+              "20ln_bwd8_plain_kernelILi4EE": 168, "20temporal_attn_kernelILb0ELi8ELi96EE": 128, "20temporal_attn_kernelILb1ELi8ELi96EE": 128}
+    for prefix, lim in budget.items():
+        for n, k in _sel(ks, prefix).items():
+            assert k["scratch"] == 0 and k["vgpr"] <= lim, (n, k, lim)
+
+
+def test_attention_kernels_budgets(kernels):
+    ks, _ = kernels
+    for n, k in ks.items():
+        if "attn_" not in n or "temporal" in n:
+            continue
+        lean = "ELi320ELi3EE" in n                               # <..., 320, 3>: GPT instances, two 5-wave workgroups per CU, 3 waves per SIMD
+        assert k["vgpr"] + (0 if "attn_bwd_dkv_kernel" in n else k["agpr"]) <= (170 if lean else 512), (n, k)
+        # known small spills outside the tile loops (20 / 32 bytes); anything larger is a regression
+        assert k["scratch"] <= (32 if ("attn_bwd_dq_res_kernelILi96ELi7E" in n or "attn_bwd_dkv_res_kernelILi64ELi320E" in n) else 0), (n, k)
+
+
+def test_no_other_kernel_spills(kernels):
+    ks, _ = kernels
+    bad = {n: k["scratch"] for n, k in ks.items() if k["scratch"] and "attn_" not in n}
+    assert not bad, bad
+
+
+def test_gemm256_uses_the_cdna4_instructions_it_is_designed_on(kernels):
+    ks, _ = kernels
+    f = next(k["file"] for n, k in ks.items() if "14gemm256_kernelI" in n)
+    asm = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", f], capture_output=True, text=True).stdout
+    assert asm.count("v_mfma_f32_16x16x32_bf16") >= 9 * 100, "16x16x32 bf16 MFMA main loops"
+    assert len(re.findall(r"buffer_load_dwordx4 .* lds", asm)) >= 9 * 8, "LDS-DMA ring fills"
+    assert asm.count("ds_read_b64_tr_b16") >= 100, "transposing LDS reads of the dgrad / wgrad forms"
+    assert "scratch_" not in asm
