@@ -342,6 +342,11 @@ def test_im2col_and_assemble(dev):
     cols = ops.im2col_patches(video, B, Cc, T, H, W, P, Cc * P * P)
     ref = F.unfold(video.permute(0, 2, 1, 3, 4).reshape(B * T, Cc, H, W).float(), P, stride=P).transpose(1, 2).reshape(-1, Cc * P * P)
     assert torch.equal(cols.float(), ref)
+    colsp = ops.im2col_patches(video, B, Cc, T, H, W, P, Cc * P * P + 8)                             # 16-byte form with a padded K
+    assert torch.equal(colsp[:, :Cc * P * P].float(), ref) and colsp[:, Cc * P * P:].abs().max().item() == 0
+    big = rn(2, 3, 3, 224, 224, dev=dev, seed=67)                                                    # full-size frames, odd frame count
+    refb = F.unfold(big.permute(0, 2, 1, 3, 4).reshape(6, 3, 224, 224).float(), 16, stride=16).transpose(1, 2).reshape(-1, 768)
+    assert torch.equal(ops.im2col_patches(big, 2, 3, 3, 224, 224, 16, 768).float(), refb)
     cols14 = ops.im2col_patches(rn(1, 3, 1, 28, 28, dev=dev, seed=61), 1, 3, 1, 28, 28, 14, 592)   # EVA patch 14, padded K
     assert cols14.shape == (4, 592) and cols14[:, 588:].abs().max().item() == 0
     patch, cls, pos, tmp = rn(B * T * N, D, dev=dev, seed=62), rn(D, dev=dev, seed=63), rn(N + 1, D, dev=dev, seed=64), rn(T, D, dev=dev, seed=65)
