@@ -109,6 +109,14 @@ int mpv_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* 
                       int64_t rows, int64_t cols, int64_t ldx, int64_t ldy, float eps, int x_group, int x_stride,
                       int x_offset, int y_group, int y_stride, int y_offset, mpv_stream_t stream);
 size_t mpv_layernorm_bwd_workspace_size(int64_t cols);
+/* accumulate_dparams == MPV_LN_DPARAM_DEFER: the call leaves its per-workgroup dgamma/dbeta partials -- fp32
+ * [mpv_layernorm_bwd_partial_rows(rows)][2][cols] at the start of `workspace`, which the caller then owns until the
+ * finish -- and launches no reduction; mpv_layernorm_dparam_finish folds the partials of up to 8 such calls in ONE launch
+ * (a ViT block has three LayerNorms).  dgamma / dbeta only select the mode in the deferred call (non-NULL). */
+#define MPV_LN_DPARAM_DEFER 2
+int mpv_layernorm_bwd_partial_rows(int64_t rows);
+int mpv_layernorm_dparam_finish(const float* const* partials, const int* partial_rows, void* const* dgamma, void* const* dbeta,
+                                const int* accumulate, int n, int64_t cols, mpv_stream_t stream);
 /* dx[xmap(r)] = (dres ? dres[xmap(r)] : 0) + LNbwd(dy[ymap(r)]); dx may alias dres.
  * dx_drop (optional) = dx * keepmask/(1-p) with element index offset + r*cols + c.
  * dgamma/dbeta (bf16 [cols]) may be NULL (frozen GPT: dgrad only); workspace needed if not. */
@@ -188,6 +196,24 @@ int mpv_colsum(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld
                int accumulate, void* workspace, size_t workspace_bytes, mpv_stream_t stream);
 /* out = a + b (bf16, n elements); used for gradient joins */
 int mpv_add(const void* a, const void* b, void* out, int64_t n, mpv_stream_t stream);
+/* acc (fp32) += g (bf16), n elements: the gradient-accumulation window sum (DeepSpeed's bf16 optimizer keeps it in fp32,
+ * run_pretrain_distributed_gpt3.py:46-53 with --update_freq); mpv_f32_to_bf16 rounds the window sum once at the boundary */
+int mpv_accum_f32(float* acc, const void* g, int64_t n, int first, mpv_stream_t stream);
+int mpv_f32_to_bf16(const float* src, void* dst, int64_t n, mpv_stream_t stream);
+/* n independent bf16 copies dst[i][0:count[i]] = src[i][0:count[i]] in ONE launch (host arrays of device pointers): the
+ * q / v halves of the packed qkv bias (models/vision_transformer.py:173) of every attention of the tower, and the
+ * q_bias / v_bias gradients out of the packed bias-gradient of the qkv weight-gradient products */
+int mpv_copy_segments(const void* const* src, void* const* dst, const int64_t* count, int n, mpv_stream_t stream);
+/* Finishing step of the composed temporal_attn.proj + temporal_fc backward (models/vision_transformer.py:199-200, 250;
+ * Wc = Wf Wp): dWf = bf16(float(dWc Wp^T) + d(bc) bp^T) and d(bp) = Wf^T d(bc), all operands bf16 [D,D] / [D]. */
+int mpv_vit_compose_bwd_finish(const void* dwc_wpT, const void* dbc, const void* bp, const void* wf, void* dwf, void* dbp, int D,
+                               mpv_stream_t stream);
+/* Labels and loss weights of the L text positions behind the Q query slots (models/distributed_gpt3.py:142-159,
+ * 348-351; the masked mean of models/modeling_distributed_gpt3.py:1615-1617 as per-position weights):
+ * labels[b][l] = ids[b][l+1] (ids[b][1] at l = L-1), weights[b][l] = attention_mask[b][l+1] / sum(attention_mask[:,1:])
+ * with positions l < prompt_len[b] (optional) zeroed, weights[b][L-1] = 0. */
+int mpv_caption_targets(const int64_t* ids, const int64_t* attention_mask, const int64_t* prompt_len, int B, int L,
+                        int64_t* labels, float* weights, mpv_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * GPT-3 embedding front: h[b,s,:] = (s < Q ? query[b,s,:] : wte[ids[b,s-Q],:]) + wpe[s,:], then

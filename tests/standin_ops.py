@@ -128,8 +128,24 @@ def layernorm_fwd(x, gamma, beta, eps, rows, cols, *, out=None, xmap=IDENT, ymap
     return out, (mu if want_stats else None), (rs if want_stats else None)
 
 
+class LnDparamBatch:
+    """Deferred dgamma / dbeta reductions (mpv_layernorm_dparam_finish): the partial is held as one fp32 row pair."""
+
+    def __init__(self):
+        self._pending = []
+
+    def finish(self):
+        for dg, db, dgamma, dbeta, acc in self._pending:
+            if acc:
+                dg, db = dg + dgamma.float().view(-1), db + dbeta.float().view(-1)
+            dgamma.view(-1).copy_(dg.to(BF))
+            dbeta.view(-1).copy_(db.to(BF))
+        self._pending = []
+
+
 def layernorm_bwd(dy, x, gamma, mean, rstd, rows, cols, *, dres=None, dx=None, dx_drop=None, dropout_p=0.0, seed=0, offset=0,
-                  dgamma=None, dbeta=None, accumulate_dparams=False, xmap=IDENT, ymap=IDENT, ldx=None, ldy=None, dx_rows=None):
+                  dgamma=None, dbeta=None, accumulate_dparams=False, xmap=IDENT, ymap=IDENT, ldx=None, ldy=None, dx_rows=None,
+                  defer=None):
     assert dropout_p == 0.0
     ldx, ldy = ldx or cols, ldy or cols
     if dx is None:
@@ -145,7 +161,9 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, rows, cols, *, dres=None, dx=None, d
     _wr(dx, xr, ldx, o)
     if dx_drop is not None:
         _wr(dx_drop, xr, ldx, _r16(o))
-    if dgamma is not None:
+    if dgamma is not None and defer is not None:       # MPV_LN_DPARAM_DEFER: nothing is written until the batch's finish()
+        defer._pending.append(((dv * xh).sum(0), dv.sum(0), dgamma, dbeta, bool(accumulate_dparams)))
+    elif dgamma is not None:
         dg, db = (dv * xh).sum(0), dv.sum(0)
         if accumulate_dparams:
             dg, db = dg + dgamma.float().view(-1), db + dbeta.float().view(-1)
@@ -326,6 +344,41 @@ def add(a, b, out=None):
     return out
 
 
+def accum_f32(acc, g, first):
+    if first:
+        acc.copy_(g.float())
+    else:
+        acc.add_(g.float())
+    return acc
+
+
+def f32_to_bf16(src, dst):
+    dst.copy_(src.to(BF))
+    return dst
+
+
+def copy_segments(pairs):
+    for src, dst in pairs:
+        assert src.numel() == dst.numel() and src.is_contiguous() and dst.is_contiguous()
+        dst.view(-1).copy_(src.reshape(-1))
+
+
+def vit_compose_bwd_finish(dwc_wpT, dbc, bp, wf, dwf, dbp, D):
+    dwf.copy_((dwc_wpT.float().view(D, D) + dbc.float().view(D, 1) * bp.float().view(1, D)).to(BF))
+    dbp.view(-1).copy_((wf.float().view(D, D) * dbc.float().view(D, 1)).sum(0).to(BF))
+
+
+def caption_targets(ids, attention_mask, prompt_len=None):
+    B, L = ids.shape
+    m = attention_mask[:, 1:].clone().float()
+    if prompt_len is not None:
+        m[torch.arange(L - 1)[None] < prompt_len.view(-1, 1)] = 0
+    w = torch.zeros((B, L), dtype=torch.float32)
+    w[:, :L - 1] = m / m.sum()
+    labels = torch.cat([ids[:, 1:], ids[:, 1:2]], dim=1) if L > 1 else torch.zeros_like(ids)
+    return labels.reshape(-1).contiguous(), w.view(-1)
+
+
 def gather_rows(src, idx, rows, cols, ld=None):
     return _rd(src, idx.view(-1)[:rows], ld or cols, cols).to(BF)
 
@@ -410,7 +463,7 @@ def decode_step(self, tokens, query_embeds=None):
     return gemm(xf, lm.embedding.word_embeddings.weight, B, V, H)
 
 
-NAMES = ["gather_rows_ld", "logprob_topk", "add", "gather_rows", "scatter_rows", "l2norm_fwd", "l2norm_bwd", "soft_target_ce", "gemm", "layernorm_fwd", "layernorm_bwd", "AttnLayout", "attn_fwd", "attn_bwd", "temporal_attn_fwd", "temporal_attn_bwd",
+NAMES = ["LnDparamBatch", "accum_f32", "f32_to_bf16", "copy_segments", "vit_compose_bwd_finish", "caption_targets", "gather_rows_ld", "logprob_topk", "add", "gather_rows", "scatter_rows", "l2norm_fwd", "l2norm_bwd", "soft_target_ce", "gemm", "layernorm_fwd", "layernorm_bwd", "AttnLayout", "attn_fwd", "attn_bwd", "temporal_attn_fwd", "temporal_attn_bwd",
          "im2col_patches", "vit_embed_assemble_fwd", "vit_embed_assemble_bwd", "vit_cls_fix_fwd", "vit_cls_merge_bwd_inplace",
          "copy_rows", "colsum", "gpt_embed_fwd", "gpt_embed_bwd", "cross_entropy"]
 

@@ -47,7 +47,20 @@ def _stub_optimizer_kernels(monkeypatch_target):
         torch.add(a, b, out=out)
         return out
 
+    def accum_f32(acc, g, first):
+        if first:
+            acc.copy_(g.float())
+        else:
+            acc.add_(g.float())
+        return acc
+
+    def f32_to_bf16(src, dst):
+        dst.copy_(src.to(dst.dtype))
+        return dst
+
     from youku_mplug_amd import ops
+    monkeypatch_target.setattr(ops, "accum_f32", accum_f32)
+    monkeypatch_target.setattr(ops, "f32_to_bf16", f32_to_bf16)
     monkeypatch_target.setattr(ops, "grad_sumsq", grad_sumsq)
     monkeypatch_target.setattr(ops, "adamw_step_grouped", adamw_step_grouped)
     monkeypatch_target.setattr(ops, "add", add)

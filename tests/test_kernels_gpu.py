@@ -564,3 +564,95 @@ def test_cls_merge_through_gemm_tap_matches_full_pass(dev):
     assert torch.equal(dy2, ref)
     ops.copy_rows(saved, dy2, B * T, D, dmap=(1, N1, 0))
     assert torch.equal(dy2, dy)
+
+
+# ------------------------------------------------------------------------------ glue kernels (csrc/glue.hip)
+def test_copy_segments_and_f32_accumulation(dev):
+    from youku_mplug_amd import ops
+    src = [rn(768, dev=dev, seed=i) for i in range(70)] + [rn(13, dev=dev, seed=99)]       # > 64 segments: two launches; a ragged one
+    big = torch.zeros((71, 1024), dtype=torch.bfloat16, device=dev)
+    dst = [big[i, 3:3 + s.numel()] if i % 2 else big[i, :s.numel()] for i, s in enumerate(src)]   # odd rows: only 2-byte aligned
+    ops.copy_segments(list(zip(src, dst)))
+    for s, d in zip(src, dst):
+        assert torch.equal(s, d)
+    assert big[0, 768:].abs().max().item() == 0
+    g = [rn(4096, dev=dev, seed=200 + i, scale=1e-2) for i in range(5)]
+    acc = torch.empty(4096, dtype=torch.float32, device=dev)
+    for i, x in enumerate(g):
+        ops.accum_f32(acc, x, first=i == 0)
+    assert torch.equal(acc, sum(x.float() for x in g))
+    out = torch.empty(4096, dtype=torch.bfloat16, device=dev)
+    ops.f32_to_bf16(acc, out)
+    assert torch.equal(out, acc.to(torch.bfloat16))
+
+
+def test_compose_finish_and_caption_targets(dev):
+    from youku_mplug_amd import ops
+    D = 192
+    P, wf = rn(D, D, dev=dev, seed=1), rn(D, D, dev=dev, seed=2)
+    dbc, bp = rn(D, dev=dev, seed=3), rn(D, dev=dev, seed=4)
+    dwf, dbp = torch.empty_like(P), torch.empty_like(bp)
+    ops.vit_compose_bwd_finish(P, dbc, bp, wf, dwf, dbp, D)
+    assert torch.equal(dwf, (P.float() + dbc.float()[:, None] * bp.float()[None, :]).to(torch.bfloat16))
+    close(dbp, (wf.float() * dbc.float()[:, None]).sum(0), 4e-3, "d(bp) = Wf^T d(bc)")
+    B, L = 5, 12
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, 50000, (B, L), generator=g).to(dev)
+    mask = torch.ones(B, L, dtype=torch.long)
+    for b, n in enumerate([12, 3, 7, 2, 9]):
+        mask[b, n:] = 0
+    mask = mask.to(dev)
+    for pl in (None, torch.tensor([0, 1, 2, 0, 5], device=dev)):
+        labels, w = ops.caption_targets(ids, mask, pl)
+        tla = mask[:, 1:].clone()
+        if pl is not None:                                           # models/distributed_gpt3.py:348-351
+            tla[torch.arange(L - 1, device=dev)[None] < pl.view(-1, 1)] = 0
+        ref_w = torch.zeros(B, L, device=dev)
+        ref_w[:, :L - 1] = tla.float() / tla.float().sum()
+        assert torch.equal(labels.view(B, L), torch.cat([ids[:, 1:], ids[:, 1:2]], dim=1))       # :142-143,150-153
+        assert torch.allclose(w.view(B, L), ref_w, atol=0, rtol=1e-6)
+
+
+@pytest.mark.parametrize("rows,cols", [(50432, 768), (300, 768), (1024, 2048)])
+def test_layernorm_deferred_dparams_match_immediate(dev, rows, cols):
+    """MPV_LN_DPARAM_DEFER + mpv_layernorm_dparam_finish (three LayerNorms in one launch, one of them accumulating) against the
+    immediate two-level reduce of the same calls: same fp32 partials, summed in another fixed order."""
+    from youku_mplug_amd import ops
+    x, dy = rn(rows, cols, dev=dev, seed=1), rn(rows, cols, dev=dev, seed=2)
+    gam, bet = rn(cols, dev=dev, seed=3), rn(cols, dev=dev, seed=4)
+    _, m, r = ops.layernorm_fwd(x, gam, bet, 1e-6, rows, cols)
+    ref, got = [], []
+    for k in range(3):
+        dg, db = rn(cols, dev=dev, seed=10 + k), rn(cols, dev=dev, seed=20 + k)
+        dg2, db2 = dg.clone(), db.clone()
+        dx_ref = ops.layernorm_bwd(dy, x, gam, m, r, rows, cols, dgamma=dg, dbeta=db, accumulate_dparams=(k == 1))
+        ref.append((dx_ref, dg, db))
+        got.append((dg2, db2))
+    batch = ops.LnDparamBatch()
+    dxs = [ops.layernorm_bwd(dy, x, gam, m, r, rows, cols, dgamma=got[k][0], dbeta=got[k][1], accumulate_dparams=(k == 1), defer=batch)
+           for k in range(3)]
+    batch.finish()
+    for k in range(3):
+        assert torch.equal(dxs[k], ref[k][0])
+        close(got[k][0], ref[k][1], 8e-3, f"deferred dgamma {k}")
+        close(got[k][1], ref[k][2], 8e-3, f"deferred dbeta {k}")
+    fp = (dy.float() * ((x.float() - m[:, None]) * r[:, None])).sum(0)
+    close(got[0][0], fp, 1e-2, "dgamma vs fp32")
+
+
+def test_gelu_tails(dev):
+    """GEMM activation epilogues at |x| up to ~100 (CLIP pre-activations reach there): exact GELU is 0 on the far negative side
+    and x on the far positive side; the polynomial form must not grow with |x| on the negative tail."""
+    from youku_mplug_amd import ops
+    M, K = 256, 64
+    a = torch.zeros((M, K), dtype=torch.bfloat16, device=dev)
+    a[:, 0] = 1.0
+    w = torch.zeros((256, K), dtype=torch.bfloat16, device=dev)
+    w[:, 0] = torch.linspace(-100.0, 100.0, 256).to(torch.bfloat16).to(dev)
+    z = w[:, 0].float()[None, :].expand(M, 256)
+    for act, approx in ((ops.ACT_GELU_ERF, "none"), (ops.ACT_GELU_TANH, "tanh")):
+        for hint in (128, 256):
+            out = ops.gemm(a, w, M, 256, K, act=act, tile_hint=hint).float()
+            ref = F.gelu(z, approximate=approx)
+            assert ((out - ref).abs() <= 4e-3 + 8e-3 * ref.abs()).all().item(), (approx, hint, (out - ref).abs().max().item())
+            assert out[:, z[0] < -8].abs().max().item() <= 2.5e-4, "negative tail must stay at ~0"

@@ -161,13 +161,16 @@ class _MP:      # minimal monkeypatch for spawned workers
         setattr(obj, name, val)
 
 
-def _dp_setup(seed):
+def _dp_setup(seed, mp=None):
+    """mp: the patch target -- pytest's monkeypatch in the parent process (undone at test end, so later tests see the real
+    device wrappers again), the undo-less _MP only inside spawned workers."""
     from oracle.weights import CONFIG_TINY, make_inputs
     from test_engine_cpu import _stub_optimizer_kernels
     from youku_mplug_amd import engine as eng
     from youku_mplug_amd.pretrain import synthetic_model
-    standin_ops.install(_MP())
-    _stub_optimizer_kernels(_MP())
+    mp = mp if mp is not None else _MP()
+    standin_ops.install(mp)
+    _stub_optimizer_kernels(mp)
     torch.manual_seed(seed)
     model = synthetic_model(CONFIG_TINY, device="cpu")
     model.eval()                                     # the stand-ins do not model the hash dropout
@@ -199,7 +202,7 @@ def _dp_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_real_model_data_parallel_world2_gloo():
+def test_real_model_data_parallel_world2_gloo(monkeypatch):
     """The REAL tiny DistributedGPT3_Pretrain under the real MplugEngine / DPReducer on two gloo ranks (device entry points on
     the stand-ins): replicas identical after initialize() although seeded differently, buckets announced by the real backward
     pipelines in completion order (head, ViT blocks from the last to the first, stem), and the reduced gradient / world equal
@@ -218,7 +221,7 @@ def test_real_model_data_parallel_world2_gloo():
     assert torch.equal(res[0][0], res[1][0]), "parameters must be broadcast from rank 0 at initialize()"
     assert torch.equal(res[0][1], res[1][1]), "every rank holds the same reduced gradient"
     assert res[0][2] == ["head", "block1", "block0", "stem"], res[0][2]
-    engine, video, ids, mask = _dp_setup(1234)                     # one process, whole batch, rank 0's initialisation
+    engine, video, ids, mask = _dp_setup(1234, monkeypatch)        # one process, whole batch, rank 0's initialisation
     assert torch.equal(engine.flat.params, res[0][0])
     loss, _ = engine(video, types.SimpleNamespace(input_ids=ids, attention_mask=mask))
     engine.backward(loss)

@@ -71,6 +71,14 @@ _SIGS = {
     "mpv_colsum_workspace_size": (c_size_t, [c_int64]),
     "mpv_colsum": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64] + _RM + [c_int, c_void_p, c_size_t, c_void_p]),
     "mpv_add": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mpv_accum_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "mpv_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "mpv_copy_segments": (c_int, [C.POINTER(c_void_p), C.POINTER(c_void_p), C.POINTER(c_int64), c_int, c_void_p]),
+    "mpv_vit_compose_bwd_finish": (c_int, [c_void_p] * 6 + [c_int, c_void_p]),
+    "mpv_caption_targets": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "mpv_layernorm_bwd_partial_rows": (c_int, [c_int64]),
+    "mpv_layernorm_dparam_finish": (c_int, [C.POINTER(c_void_p), C.POINTER(c_int), C.POINTER(c_void_p), C.POINTER(c_void_p),
+                                            C.POINTER(c_int), c_int, c_int64, c_void_p]),
     "mpv_gpt_embed_fwd": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_float, c_uint64, c_uint64, c_void_p]),
     "mpv_gpt_embed_bwd": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_float, c_uint64, c_uint64, c_void_p]),
     "mpv_cross_entropy": (c_int, [c_void_p] * 6 + [c_int64] * 3 + [c_void_p]),

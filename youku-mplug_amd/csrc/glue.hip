@@ -1,0 +1,229 @@
+// glue.hip -- the small fused kernels that take framework tensor ops (cat / zeros / slice-assign / foreach-copy /
+// float round trips) off the hot path of the step: each replaces a chain of 4-12 generic element-wise launches of the
+// host framework by ONE launch.  All of them move a few KB; what they save is launches (1.2-1.9 us per kernel boundary).
+#include "mpv_common.h"
+#include "mpv_kernels.h"
+
+namespace {
+
+// ---- multi-segment bf16 copy --------------------------------------------------------------------------------
+constexpr int SEG_MAX = 64;
+struct SegArgs {
+  const bf16* src[SEG_MAX];
+  bf16* dst[SEG_MAX];
+  int count[SEG_MAX];
+};
+// one workgroup per segment; 16-byte pieces when both ends are 16-byte aligned, element-wise otherwise
+__global__ __launch_bounds__(256) void copy_segments_kernel(const SegArgs a) {
+  const int s = blockIdx.x;
+  const bf16* __restrict__ src = a.src[s];
+  bf16* __restrict__ dst = a.dst[s];
+  const int n = a.count[s];
+  if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+    const int n8 = n >> 3;
+    for (int i = threadIdx.x; i < n8; i += 256) *(bf16x8*)(dst + i * 8) = *(const bf16x8*)(src + i * 8);
+    for (int i = (n8 << 3) + threadIdx.x; i < n; i += 256) dst[i] = src[i];
+  } else {
+    for (int i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+  }
+}
+
+// ---- composed temporal-projection backward: the two [D, D] / [D] finishing steps ----------------------------
+// dWf[i][j] = bf16( float(P[i][j]) + dbc[i] * bp[j] )      (P = dWc Wp^T from the GEMM, rounded to bf16 there)
+// dbp[j]    = bf16( sum_i Wf[i][j] * dbc[i] )               (= Wf^T d(bc))
+// grid: D / 64 column groups x (D / 64 + 1) row groups; the last row group of a column group does the column sum.
+__global__ __launch_bounds__(256) void compose_finish_kernel(const bf16* __restrict__ P, const bf16* __restrict__ dbc,
+                                                             const bf16* __restrict__ bp, const bf16* __restrict__ wf,
+                                                             bf16* __restrict__ dwf, bf16* __restrict__ dbp, int D) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + cl;
+  if ((int)blockIdx.y < (D + 63) / 64) {
+    if (j < D) {
+      const float b = bf2f(bp[j]);
+      for (int i = blockIdx.y * 64 + rl; i < min(D, (int)blockIdx.y * 64 + 64); i += 4)
+        dwf[(long long)i * D + j] = f2bf(bf2f(P[(long long)i * D + j]) + bf2f(dbc[i]) * b);
+    }
+    return;
+  }
+  float acc = 0.f;
+  if (j < D)
+    for (int i = rl; i < D; i += 4) acc += bf2f(wf[(long long)i * D + j]) * bf2f(dbc[i]);
+  red[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && j < D) dbp[j] = f2bf((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
+}
+
+// ---- caption targets of the loss window ---------------------------------------------------------------------
+// models/distributed_gpt3.py:142-159 on the L text positions behind the Q query slots (the only ones whose loss weight can
+// be non-zero): label[b][l] = ids[b][l+1] (l < L-1), ids[b][1] (l = L-1); weight[b][l] = m[b][l+1] / sum(m[:,1:]) with
+// m = attention_mask, zeroed where l < prompt_len[b] (:348-351); weight of the last position = 0 (losses[:, :-1], :1615-1617).
+__global__ __launch_bounds__(256) void caption_targets_kernel(const long long* __restrict__ ids, const long long* __restrict__ mask,
+                                                              const long long* __restrict__ plen, int B, int L,
+                                                              long long* __restrict__ labels, float* __restrict__ weights) {
+  __shared__ float red[4];
+  const int n = B * L;
+  float cnt = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int b = i / L, l = i - b * L;
+    if (l < L - 1 && !(plen && l < plen[b])) cnt += (float)mask[(long long)b * L + l + 1];
+  }
+  cnt = wave_sum(cnt);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  const float denom = (red[0] + red[1]) + (red[2] + red[3]);
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int b = i / L, l = i - b * L;
+    labels[i] = L > 1 ? ids[(long long)b * L + (l < L - 1 ? l + 1 : 1)] : 0;
+    float w = 0.f;
+    if (l < L - 1 && !(plen && l < plen[b])) w = (float)mask[(long long)b * L + l + 1] / denom;
+    weights[i] = w;
+  }
+}
+
+// ---- deferred LayerNorm parameter-gradient reduction --------------------------------------------------------
+// mpv_layernorm_bwd in deferred mode leaves its per-workgroup partials [nblk][2][cols] (fp32) in a caller-owned buffer;
+// this kernel folds up to LNF_MAX such buffers in ONE launch (a ViT block has three LayerNorms: 6 reduce launches -> 1).
+// grid (cols / 32, n): a workgroup = 32 columns x 8 row lanes, fixed summation order (deterministic).
+constexpr int LNF_MAX = 8;
+struct LnFinishArgs {
+  const float* part[LNF_MAX];
+  bf16* dgamma[LNF_MAX];
+  bf16* dbeta[LNF_MAX];
+  int nblk[LNF_MAX];
+  int accumulate[LNF_MAX];
+  int cols;
+};
+__global__ __launch_bounds__(256) void ln_dparam_finish_kernel(const LnFinishArgs a) {
+  __shared__ float red[2][8][32];
+  const int s = blockIdx.y;
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const float* __restrict__ part = a.part[s];
+  const int nblk = a.nblk[s], cols = a.cols;
+  float g0 = 0.f, b0 = 0.f, g1 = 0.f, b1 = 0.f;
+  if (c < cols) {
+    int i = rl;
+    for (; i + 8 < nblk; i += 16) {
+      g0 += part[(long long)i * 2 * cols + c];
+      b0 += part[(long long)i * 2 * cols + cols + c];
+      g1 += part[(long long)(i + 8) * 2 * cols + c];
+      b1 += part[(long long)(i + 8) * 2 * cols + cols + c];
+    }
+    if (i < nblk) {
+      g0 += part[(long long)i * 2 * cols + c];
+      b0 += part[(long long)i * 2 * cols + cols + c];
+    }
+  }
+  red[0][rl][cl] = g0 + g1;
+  red[1][rl][cl] = b0 + b1;
+  __syncthreads();
+  if (rl == 0 && c < cols) {
+    float g = 0.f, b = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      g += red[0][r][cl];
+      b += red[1][r][cl];
+    }
+    if (a.accumulate[s]) {
+      g += bf2f(a.dgamma[s][c]);
+      b += bf2f(a.dbeta[s][c]);
+    }
+    a.dgamma[s][c] = f2bf(g);
+    a.dbeta[s][c] = f2bf(b);
+  }
+}
+
+// ---- gradient-accumulation window in fp32 -------------------------------------------------------------------
+__global__ __launch_bounds__(256) void accum_f32_kernel(float* __restrict__ acc, const bf16* __restrict__ g, long long n8, int first) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    f32x8 v = cvt8(*(const bf16x8*)(g + i * 8));
+    if (!first) v += *(const f32x8*)(acc + i * 8);
+    *(f32x8*)(acc + i * 8) = v;
+  }
+}
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst, long long n8) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256)
+    *(bf16x8*)(dst + i * 8) = cvt8(*(const f32x8*)(src + i * 8));
+}
+unsigned stream_grid(long long n8) { return (unsigned)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192); }
+
+}  // namespace
+
+extern "C" int mpv_accum_f32(float* acc, const void* g, int64_t n, int first, hipStream_t stream) {
+  MPV_REQUIRE(acc && g, MPV_E_ARG, "mpv_accum_f32: null pointer");
+  MPV_REQUIRE(n >= 0 && n % 8 == 0, MPV_E_SHAPE, "mpv_accum_f32: n must be a multiple of 8");
+  MPV_REQUIRE((((uintptr_t)acc & 31) | ((uintptr_t)g & 15)) == 0, MPV_E_ALIGN, "mpv_accum_f32: buffers must be 32- / 16-byte aligned");
+  if (n == 0) return MPV_OK;
+  hipLaunchKernelGGL(accum_f32_kernel, dim3(stream_grid(n / 8)), dim3(256), 0, stream, acc, (const bf16*)g, (long long)(n / 8), first);
+  return mpv_check_launch("mpv_accum_f32");
+}
+
+extern "C" int mpv_f32_to_bf16(const float* src, void* dst, int64_t n, hipStream_t stream) {
+  MPV_REQUIRE(src && dst, MPV_E_ARG, "mpv_f32_to_bf16: null pointer");
+  MPV_REQUIRE(n >= 0 && n % 8 == 0, MPV_E_SHAPE, "mpv_f32_to_bf16: n must be a multiple of 8");
+  MPV_REQUIRE((((uintptr_t)src & 31) | ((uintptr_t)dst & 15)) == 0, MPV_E_ALIGN, "mpv_f32_to_bf16: buffers must be 32- / 16-byte aligned");
+  if (n == 0) return MPV_OK;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(stream_grid(n / 8)), dim3(256), 0, stream, src, (bf16*)dst, (long long)(n / 8));
+  return mpv_check_launch("mpv_f32_to_bf16");
+}
+
+extern "C" int mpv_copy_segments(const void* const* src, void* const* dst, const int64_t* count, int n, hipStream_t stream) {
+  MPV_REQUIRE(n >= 0 && (n == 0 || (src && dst && count)), MPV_E_ARG, "mpv_copy_segments: null pointer");
+  for (int base = 0; base < n; base += SEG_MAX) {
+    SegArgs a = {};
+    const int m = n - base < SEG_MAX ? n - base : SEG_MAX;
+    for (int i = 0; i < m; ++i) {
+      MPV_REQUIRE(src[base + i] && dst[base + i] && count[base + i] >= 0 && count[base + i] < (1LL << 31), MPV_E_ARG,
+                  "mpv_copy_segments: bad segment %d", base + i);
+      a.src[i] = (const bf16*)src[base + i];
+      a.dst[i] = (bf16*)dst[base + i];
+      a.count[i] = (int)count[base + i];
+    }
+    hipLaunchKernelGGL(copy_segments_kernel, dim3((unsigned)m), dim3(256), 0, stream, a);
+  }
+  return mpv_check_launch("mpv_copy_segments");
+}
+
+extern "C" int mpv_vit_compose_bwd_finish(const void* dwc_wpT, const void* dbc, const void* bp, const void* wf, void* dwf, void* dbp,
+                                          int D, hipStream_t stream) {
+  MPV_REQUIRE(dwc_wpT && dbc && bp && wf && dwf && dbp, MPV_E_ARG, "mpv_vit_compose_bwd_finish: null pointer");
+  MPV_REQUIRE(D > 0, MPV_E_SHAPE, "mpv_vit_compose_bwd_finish: empty problem");
+  const unsigned g = (unsigned)((D + 63) / 64);
+  hipLaunchKernelGGL(compose_finish_kernel, dim3(g, g + 1), dim3(256), 0, stream, (const bf16*)dwc_wpT, (const bf16*)dbc, (const bf16*)bp,
+                     (const bf16*)wf, (bf16*)dwf, (bf16*)dbp, D);
+  return mpv_check_launch("mpv_vit_compose_bwd_finish");
+}
+
+extern "C" int mpv_caption_targets(const int64_t* ids, const int64_t* attention_mask, const int64_t* prompt_len, int B, int L,
+                                   int64_t* labels, float* weights, hipStream_t stream) {
+  MPV_REQUIRE(ids && attention_mask && labels && weights, MPV_E_ARG, "mpv_caption_targets: null pointer");
+  MPV_REQUIRE(B > 0 && L > 0 && (long long)B * L < (1LL << 30), MPV_E_SHAPE, "mpv_caption_targets: bad shape");
+  hipLaunchKernelGGL(caption_targets_kernel, dim3(1), dim3(256), 0, stream, (const long long*)ids, (const long long*)attention_mask,
+                     (const long long*)prompt_len, B, L, (long long*)labels, weights);
+  return mpv_check_launch("mpv_caption_targets");
+}
+
+extern "C" int mpv_layernorm_dparam_finish(const float* const* partials, const int* nblk, void* const* dgamma, void* const* dbeta,
+                                           const int* accumulate, int n, int64_t cols, hipStream_t stream) {
+  MPV_REQUIRE(n >= 0 && (n == 0 || (partials && nblk && dgamma && dbeta && accumulate)), MPV_E_ARG, "mpv_layernorm_dparam_finish: null pointer");
+  MPV_REQUIRE(cols > 0, MPV_E_SHAPE, "mpv_layernorm_dparam_finish: cols must be positive");
+  for (int base = 0; base < n; base += LNF_MAX) {
+    LnFinishArgs a = {};
+    const int m = n - base < LNF_MAX ? n - base : LNF_MAX;
+    for (int i = 0; i < m; ++i) {
+      MPV_REQUIRE(partials[base + i] && dgamma[base + i] && dbeta[base + i] && nblk[base + i] > 0, MPV_E_ARG,
+                  "mpv_layernorm_dparam_finish: bad entry %d", base + i);
+      for (int j = 0; j < i; ++j)
+        MPV_REQUIRE(a.dgamma[j] != (bf16*)dgamma[base + i], MPV_E_ARG, "mpv_layernorm_dparam_finish: two entries of one launch share a dgamma");
+      a.part[i] = partials[base + i];
+      a.nblk[i] = nblk[base + i];
+      a.dgamma[i] = (bf16*)dgamma[base + i];
+      a.dbeta[i] = (bf16*)dbeta[base + i];
+      a.accumulate[i] = accumulate[base + i];
+    }
+    a.cols = (int)cols;
+    hipLaunchKernelGGL(ln_dparam_finish_kernel, dim3((unsigned)((cols + 31) / 32), (unsigned)m), dim3(256), 0, stream, a);
+  }
+  return mpv_check_launch("mpv_layernorm_dparam_finish");
+}

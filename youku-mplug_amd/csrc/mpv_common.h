@@ -22,6 +22,7 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 #define MPV_E_ARCH (-3)
 #define MPV_E_HIP (-4)
 #define MPV_E_ARG (-5)
+#define MPV_LN_DPARAM_DEFER 2   // include/mpv.h: mpv_layernorm_bwd leaves its dgamma/dbeta partials for mpv_layernorm_dparam_finish
 
 // thread-local error text (mpv_last_error)
 void mpv_set_error(const char* fmt, ...);
@@ -173,12 +174,17 @@ __device__ __forceinline__ T mpv_gelu_grad_poly(T w) {
     return mpv_fma_t(q, w, mpv_splat<T>(7.975339890e-01f));
   }
 }
-// GELU(x) = x * (1/2 + xc * P(xc^2)), xc = clamp(x)
+// GELU(x) = x~ * (1/2 + xc * P(xc^2)), xc = clamp(x), x~ = max(x, -6).  Left of the clamp the bracket is frozen at Phi~(-4) =
+// 3e-5 (not 0), so the multiplier is held at -6 there: the far negative tail returns >= -2e-4 where the true value is -0
+// (with the raw x it grew linearly: -3e-3 at x = -100; CLIP towers do produce such pre-activations).
+__device__ __forceinline__ float mpv_tail_t(float x) { return fmaxf(x, -6.0f); }
+__device__ __forceinline__ f32x2 mpv_tail_t(f32x2 x) { return f32x2{fmaxf(x[0], -6.0f), fmaxf(x[1], -6.0f)}; }
 template <int KIND, typename T>
 __device__ __forceinline__ T mpv_gelu_t(T x) {
   const T xc = mpv_clamp_t(x);
   const T s = xc * mpv_gelu_cdf_poly<KIND>(xc * xc);
-  return mpv_fma_t(x, s, x * mpv_splat<T>(0.5f));
+  const T xe = mpv_tail_t(x);
+  return mpv_fma_t(xe, s, xe * mpv_splat<T>(0.5f));
 }
 // dy * GELU'(x) = dy * (1/2 + xc * Q(xc^2))
 template <int KIND, typename T>

@@ -593,6 +593,12 @@ extern "C" size_t mpv_layernorm_bwd_workspace_size(int64_t cols) {
   return (size_t)(LN_BWD_MAX_BLOCKS + LN_L1_ROWS) * 2 * (size_t)cols * sizeof(float);
 }
 
+// rows of per-workgroup partials [rows][2][cols] a deferred-mode call (accumulate_dparams == MPV_LN_DPARAM_DEFER) leaves at
+// the start of its workspace for mpv_layernorm_dparam_finish
+extern "C" int mpv_layernorm_bwd_partial_rows(int64_t rows) {
+  return (int)((rows + 3) / 4 < LN_BWD_MAX_BLOCKS ? (rows + 3) / 4 : LN_BWD_MAX_BLOCKS);
+}
+
 extern "C" int mpv_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
                                  const void* dres, void* dx, void* dx_drop, float drop_p, uint64_t seed,
                                  uint64_t offset, void* dgamma, void* dbeta, int accumulate_dparams, int64_t rows,
@@ -643,7 +649,7 @@ extern "C" int mpv_layernorm_bwd(const void* dy, const void* x, const void* gamm
   else if (nc <= 8) launch_bwd<8>(a, dparam, grid, stream);
   else if (nc <= 10) launch_bwd<10>(a, dparam, grid, stream);
   else launch_bwd<16>(a, dparam, grid, stream);
-  if (dparam) {
+  if (dparam && accumulate_dparams != MPV_LN_DPARAM_DEFER) {
     float* l0 = (float*)workspace;
     float* l1 = l0 + (size_t)grid * 2 * cols;
     const unsigned gx = (unsigned)((cols + 63) / 64);

@@ -218,10 +218,15 @@ class MplugEngine(nn.Module):
         self.flat = FlatParams(stages, group_of)
         broadcast_module_state(model, self.flat, process_group)     # replicas start identical (before the fp32 master copy)
         self.reducer = DPReducer(self.flat, process_group)
-        self.grad_acc = torch.zeros_like(self.flat.grads) if self.gas > 1 else None
+        # the window sum of micro-batch gradients is kept in fp32 (DeepSpeed's bf16 optimizer does the same): in bf16 every add
+        # rounds to 8 mantissa bits and small contributions vanish against a large running sum
+        self.grad_acc = torch.zeros(self.flat.numel, dtype=torch.float32, device=self.flat.device) if self.gas > 1 else None
         self.optimizer = FlatAdamW(self.flat, param_groups, lr=lr, betas=betas, eps=eps, clip_grad=clip_grad)
-        self.micro_steps = 0
+        self.micro_steps = 0                  # the training loop resets this every epoch (run_pretrain_distributed_gpt3.py:72-73)
+        self._window_fill = 0                 # micro-batches summed into the current accumulation window
+        self.micro_batches_seen = 0           # never reset, saved with the optimizer state: drives the dropout seed
         self.global_steps = 0
+        self._set_dropout_seed()              # rank-distinct masks from the very first micro-batch on
         ve = getattr(model, "visual_encoder", None)
         if ve is not None and hasattr(ve, "on_block_grads_ready"):
             depth = len(ve.blocks)
@@ -234,7 +239,7 @@ class MplugEngine(nn.Module):
         return self.module(*a, **k)
 
     def is_gradient_accumulation_boundary(self) -> bool:
-        return self.micro_steps % self.gas == 0
+        return self._window_fill == 0
 
     def backward(self, loss):
         """DeepSpeed semantics (`--update_freq`, run_pretrain_distributed_gpt3.py:46-53,88-96): the gradient of a window of
@@ -244,20 +249,21 @@ class MplugEngine(nn.Module):
         self.reducer.hold = self.gas > 1
         loss.backward()
         self.micro_steps += 1
+        self.micro_batches_seen += 1
         if self.gas > 1:
-            if self.micro_steps % self.gas == 1:
-                self.grad_acc.copy_(self.flat.grads)
-            else:
-                from . import ops
-                ops.add(self.grad_acc, self.flat.grads, self.grad_acc)
+            from . import ops
+            ops.accum_f32(self.grad_acc, self.flat.grads, first=self._window_fill == 0)
+            self._window_fill = (self._window_fill + 1) % self.gas
         self._set_dropout_seed()
 
     def _set_dropout_seed(self):
-        """Fresh, rank-distinct dropout streams for the next micro-batch: a 64-bit mix of (micro step, rank)."""
+        """Fresh, rank-distinct dropout streams for the next micro-batch: a 64-bit mix of (micro-batches seen so far, rank).
+        The counter is monotonic over the whole run (`micro_steps` is reset by the loop every epoch, which would replay the same
+        mask sequence each epoch and after every resume) and travels in the optimizer-state file of a checkpoint."""
         td = getattr(self.module, "text_decoder", None)
         if td is not None and hasattr(td, "step_seed"):
             rank = dist.get_rank() if dist.is_initialized() else 0
-            x = (self.micro_steps * 0x9E3779B97F4A7C15 + (rank + 1) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+            x = (self.micro_batches_seen * 0x9E3779B97F4A7C15 + (rank + 1) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
             x ^= x >> 30
             x = (x * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
             x ^= x >> 27
@@ -269,7 +275,8 @@ class MplugEngine(nn.Module):
         if not self.is_gradient_accumulation_boundary():
             return                                        # mid-window micro step: nothing to apply yet
         if self.gas > 1:
-            self.flat.grads.copy_(self.grad_acc)
+            from . import ops
+            ops.f32_to_bf16(self.grad_acc, self.flat.grads)     # one rounding of the fp32 window sum, then the bucketed reduce
         self.reducer.hold = False
         self.reducer.finish()
         self.optimizer.step(grad_scale=1.0 / (self.reducer.world * self.gas))
@@ -287,8 +294,8 @@ class MplugEngine(nn.Module):
             state = {"module": {k: v.detach().cpu() for k, v in self.module.state_dict().items()}}
             state.update(client_state or {})
             torch.save(state, os.path.join(d, "mp_rank_00_model_states.pt"))
-            torch.save({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in self.optimizer.state_dict().items()},
-                       os.path.join(d, "mp_rank_00_optim_states.pt"))
+            osd = dict(self.optimizer.state_dict(), micro_batches_seen=self.micro_batches_seen)
+            torch.save({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in osd.items()}, os.path.join(d, "mp_rank_00_optim_states.pt"))
             with open(os.path.join(save_dir, "latest"), "w") as f:
                 f.write(str(tag))
         if dist.is_initialized():
@@ -316,6 +323,15 @@ class MplugEngine(nn.Module):
             self.optimizer.exp_avg.zero_()
             self.optimizer.exp_avg_sq.zero_()
             self.optimizer.step_count = 0
+        # a resume starts a fresh accumulation window (a NaN auto-resume may arrive mid-window with a stale partial sum) and
+        # continues the dropout stream where the checkpoint left it
+        self._window_fill = 0
+        self.micro_steps = 0
+        self.reducer.pending.clear()
+        self.reducer.launched.clear()
+        if osd is not None:
+            self.micro_batches_seen = int(osd.get("micro_batches_seen", self.micro_batches_seen))
+        self._set_dropout_seed()
         return d, state
 
 

@@ -171,14 +171,17 @@ class DistributedGPT3(nn.Module):
     # -------------------------------------------------------------- explicit forward / backward
     def forward_lm(self, query_features: Optional[torch.Tensor], ids: torch.Tensor, labels: Optional[torch.Tensor],
                    loss_mask: Optional[torch.Tensor], tape: dict, want_logits: bool = False, hidden_only: bool = False,
-                   pass_index: int = 0, loss_window: Optional[tuple] = None):
+                   pass_index: int = 0, loss_window: Optional[tuple] = None, window_targets: Optional[tuple] = None):
         """query_features [B*Q, H] (or None), ids [B,L] int64, labels [B,S] int64, loss_mask [B,S-1].
         Returns dict(loss fp32 scalar, losses [B,S-1] fp32, logits?, last_hidden_state [B,S,H]).
         loss_window = (start, length): the caller's promise that loss_mask is zero outside positions
         [start, start + length) of every sequence (pre-training: the Q query slots in front are always masked,
         models/distributed_gpt3.py:142-159).  The tied LM head, the CE and the LM head's dgrad then run on those
         B * length rows only -- the reference evaluates all B * S rows of [S, V] logits and multiplies 80 % of the
-        per-token losses by zero; the loss and every gradient are unchanged (those rows' dlogits are exactly 0)."""
+        per-token losses by zero; the loss and every gradient are unchanged (those rows' dlogits are exactly 0).
+        window_targets = (labels int64 [B * length], weights fp32 [B * length]) of the window rows, already on the device
+        (ops.caption_targets): labels / loss_mask are then not consulted and no per-token `losses` tensor is assembled (the
+        training step only needs the scalar) -- it takes a dozen small framework launches off every step."""
         cfg = self.config
         lm = self.dist_model.language_model
         B, L = ids.shape
@@ -255,6 +258,13 @@ class DistributedGPT3(nn.Module):
                         seed=seed, p_h=p_h, p_a=p_a)
             return dict(last_hidden_state=xf.view(B, S, H))
         # masked mean of per-token CE over positions 0..S-2 (:1615-1617)
+        if window is not None and window_targets is not None:
+            Rw = B * window[1]
+            logits = ops.gemm(xf, lm.embedding.word_embeddings.weight, Rw, V, H)       # xf is already the window's rows
+            _, loss = ops.cross_entropy(logits, window_targets[0], window_targets[1], Rw, V, dlogits=logits)
+            tape.update(B=B, Q=Q, L=L, S=S, layers=layers, h_last=h, sf=(mf, rf), dlogits=logits, lm_window=window, lay=lay, scale=scale,
+                        seed=seed, p_h=p_h, p_a=p_a)
+            return dict(loss=loss, losses=None, last_hidden_state=None)
         lmf = loss_mask.to(torch.float32)
         denom = lmf.sum()
         w = torch.zeros((B, S), dtype=torch.float32, device=h.device)
@@ -279,6 +289,15 @@ class DistributedGPT3(nn.Module):
         if want_logits:
             out["logits"] = keep_logits.view(B, S, V)
         return out
+
+    def _window_zero_pair(self, R, H, rows, device):
+        key = (R, H, tuple(rows), str(device), torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0)
+        ent = self.__dict__.setdefault("_wz_cache", {}).get(key)
+        if ent is None:
+            self._wz_cache.clear()
+            ent = self._wz_cache[key] = (torch.zeros((R, H), dtype=torch.bfloat16, device=device),
+                                         torch.zeros((R, H), dtype=torch.bfloat16, device=device))
+        return ent
 
     def _dgrad(self, dy, weight, R, n_in, n_out, **kw):
         """dX[R, n_in] = dY[R, n_out] W[n_out, n_in].  A frozen weight (the recipes' freeze_text_decoder: true) is
@@ -343,12 +362,13 @@ class DistributedGPT3(nn.Module):
                 Rw = B * rm[0]
                 dz = self._dgrad(do, mlp.dense_4h_to_h.weight, Rw, F4, H, act_bwd_z=s["z"], act_bwd=ACT_GELU_TANH, amap=rm)
                 dx2 = self._dgrad(dz, mlp.dense_h_to_4h.weight, Rw, H, F4)
-                dh1 = torch.zeros((R, H), dtype=torch.bfloat16, device=dh.device)
+                # the rows outside the window stay exact zeros: two buffers cleared once and kept across steps (only window rows
+                # are ever written), instead of two activation-sized clears per step
+                dh1, dctx = self._window_zero_pair(R, H, rm, dh.device)
                 dh1_m = torch.empty((R, H), dtype=torch.bfloat16, device=dh.device) if drop else None
                 ops.layernorm_bwd(dx2, s["h1"], layer.post_attention_layernorm.weight, *s["s2"], Rw, H, dres=dh, dx=dh1, dx_drop=dh1_m,
                                   dropout_p=p_h, seed=seed, offset=_offset(ln, _SITE_DROP1), xmap=rm)
                 da = dh1_m if drop else dh1
-                dctx = torch.zeros((R, H), dtype=torch.bfloat16, device=dh.device)
                 self._dgrad(da, att.dense.weight, Rw, H, H, amap=rm, cmap=rm, out=dctx)
             else:
                 dz = self._dgrad(do, mlp.dense_4h_to_h.weight, R, F4, H, act_bwd_z=s["z"], act_bwd=ACT_GELU_TANH)

@@ -114,23 +114,71 @@ def layernorm_fwd(x, gamma, beta, eps: float, rows: int, cols: int, *, out=None,
     return out, mean, rstd
 
 
+LN_DPARAM_DEFER = 2      # include/mpv.h: MPV_LN_DPARAM_DEFER
+
+
+class LnDparamBatch:
+    """dgamma / dbeta reductions of several LayerNorm backward calls in ONE launch (mpv_layernorm_dparam_finish).
+    Pass it as `defer=` to layernorm_bwd: the call then leaves its per-workgroup partials in a buffer of this batch (kept
+    and reused across steps) instead of launching its own two reduce kernels; finish() folds every pending entry on the
+    current stream.  Entries of one batch must target distinct parameters."""
+
+    def __init__(self):
+        self._bufs = []
+        self._pending = []
+        self.cols = None
+
+    def slot(self, nbytes: int, device) -> torch.Tensor:
+        i = len(self._pending)
+        while len(self._bufs) <= i:
+            self._bufs.append(None)
+        b = self._bufs[i]
+        if b is None or b.numel() < nbytes or b.device != torch.device(device):
+            b = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self._bufs[i] = b
+        return b
+
+    def add(self, buf, nrows, dgamma, dbeta, accumulate, cols):
+        assert self.cols in (None, cols), "one LnDparamBatch serves LayerNorms of one width"
+        self.cols = cols
+        self._pending.append((buf, nrows, dgamma, dbeta, int(accumulate)))
+
+    def finish(self):
+        n = len(self._pending)
+        if n == 0:
+            return
+        vp, ip = C.c_void_p * n, C.c_int * n
+        check(_lib.lib().mpv_layernorm_dparam_finish(vp(*[e[0].data_ptr() for e in self._pending]), ip(*[e[1] for e in self._pending]),
+                                                     vp(*[e[2].data_ptr() for e in self._pending]), vp(*[e[3].data_ptr() for e in self._pending]),
+                                                     ip(*[e[4] for e in self._pending]), n, self.cols, _stream()),
+              "mpv_layernorm_dparam_finish")
+        self._pending = []
+
+
 def layernorm_bwd(dy, x, gamma, mean, rstd, rows: int, cols: int, *, dres=None, dx=None, dx_drop=None,
                   dropout_p: float = 0.0, seed: int = 0, offset: int = 0, dgamma=None, dbeta=None,
                   accumulate_dparams: bool = False, xmap: RowMap = IDENT, ymap: RowMap = IDENT,
-                  ldx: Optional[int] = None, ldy: Optional[int] = None, dx_rows: Optional[int] = None):
+                  ldx: Optional[int] = None, ldy: Optional[int] = None, dx_rows: Optional[int] = None,
+                  defer: Optional[LnDparamBatch] = None):
     _need_cuda(dy, x, gamma)
     ldx = ldx or cols
     ldy = ldy or cols
     if dx is None:
         dx = torch.empty((dx_rows if dx_rows is not None else rows, ldx), dtype=torch.bfloat16, device=x.device)
     ws, wsn = None, 0
+    mode = int(accumulate_dparams)
     if dgamma is not None:
         wsn = _lib.lib().mpv_layernorm_bwd_workspace_size(cols)
-        ws = workspace(wsn, x.device)
+        if defer is not None:
+            ws = defer.slot(wsn, x.device)
+            defer.add(ws, _lib.lib().mpv_layernorm_bwd_partial_rows(rows), dgamma, dbeta, accumulate_dparams, cols)
+            mode = LN_DPARAM_DEFER
+        else:
+            ws = workspace(wsn, x.device)
         wsn = ws.numel()
     check(_lib.lib().mpv_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                        _p(dres), dx.data_ptr(), _p(dx_drop), dropout_p, seed, offset, _p(dgamma), _p(dbeta),
-                                       int(accumulate_dparams), rows, cols, ldx, ldy, *xmap, *ymap, _p(ws), wsn, _stream()),
+                                       mode, rows, cols, ldx, ldy, *xmap, *ymap, _p(ws), wsn, _stream()),
           "mpv_layernorm_bwd")
     return dx
 
@@ -256,6 +304,44 @@ def add(a, b, out=None):
     out = out if out is not None else torch.empty_like(a)
     check(_lib.lib().mpv_add(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "mpv_add")
     return out
+
+
+def accum_f32(acc, g, first: bool):
+    """acc (fp32) = g if first else acc + g, g bf16: the gradient-accumulation window sum."""
+    check(_lib.lib().mpv_accum_f32(acc.data_ptr(), g.data_ptr(), g.numel(), int(first), _stream()), "mpv_accum_f32")
+    return acc
+
+
+def f32_to_bf16(src, dst):
+    check(_lib.lib().mpv_f32_to_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), _stream()), "mpv_f32_to_bf16")
+    return dst
+
+
+def copy_segments(pairs):
+    """[(src, dst), ...] of equally sized contiguous bf16 tensors: dst[i] <- src[i], one launch."""
+    n = len(pairs)
+    if n == 0:
+        return
+    vp, lp = C.c_void_p * n, C.c_int64 * n
+    check(_lib.lib().mpv_copy_segments(vp(*[s.data_ptr() for s, _ in pairs]), vp(*[d.data_ptr() for _, d in pairs]),
+                                       lp(*[d.numel() for _, d in pairs]), n, _stream()), "mpv_copy_segments")
+
+
+def vit_compose_bwd_finish(dwc_wpT, dbc, bp, wf, dwf, dbp, D):
+    """dwf <- bf16(float(dwc_wpT) + dbc (x) bp);  dbp <- Wf^T dbc  (include/mpv.h: mpv_vit_compose_bwd_finish)."""
+    check(_lib.lib().mpv_vit_compose_bwd_finish(dwc_wpT.data_ptr(), dbc.data_ptr(), bp.data_ptr(), wf.data_ptr(), dwf.data_ptr(),
+                                                dbp.data_ptr(), D, _stream()), "mpv_vit_compose_bwd_finish")
+
+
+def caption_targets(ids, attention_mask, prompt_len=None):
+    """-> (labels int64 [B*L], weights fp32 [B*L]) of the L text positions (include/mpv.h: mpv_caption_targets)."""
+    _need_cuda(ids, attention_mask)
+    B, L = ids.shape
+    labels = torch.empty(B * L, dtype=torch.long, device=ids.device)
+    weights = torch.empty(B * L, dtype=torch.float32, device=ids.device)
+    check(_lib.lib().mpv_caption_targets(ids.contiguous().data_ptr(), attention_mask.contiguous().data_ptr(), _p(prompt_len), B, L,
+                                         labels.data_ptr(), weights.data_ptr(), _stream()), "mpv_caption_targets")
+    return labels, weights
 
 
 def gpt_embed_fwd(query, ids, wte, wpe, B, Q, L, H, dropout_p=0.0, seed=0, offset=0):

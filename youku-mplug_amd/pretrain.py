@@ -120,6 +120,14 @@ class DistributedGPT3_Pretrain(nn.Module):
         image_query = self.attn_pool.forward_pool(self.learnable_queries, emb, B, S_img, tape["pool"])      # :134
         qf = ops.gemm(image_query, self.visual_fc.weight, B * Q, Hh, self.vision_width, bias=self.visual_fc.bias)   # :136
         tape["image_query"] = image_query
+        if not want_logits and Q > 0 and ids.shape[1] > 0:
+            # training / loss-only evaluation: labels and loss weights of the L text positions from one kernel (the Q query slots
+            # in front never carry loss, :142-159): LM head + CE run on that window and no [B, S] target tensors are built
+            pl = None if prompt_lengths is None else torch.as_tensor(prompt_lengths, device=ids.device, dtype=torch.long).contiguous()
+            out = self.text_decoder.forward_lm(qf, ids, None, None, tape["gpt"], loss_window=(Q, ids.shape[1]),
+                                               window_targets=ops.caption_targets(ids, mask, pl))
+            tape["out"] = out
+            return out["loss"], tape
         # targets / loss mask exactly as :142-159 (filler id 100 is always masked)
         targets = torch.cat([ids[:, 1:], ids[:, 1:2]], dim=1)
         targets = torch.cat([torch.full((B, Q), 100, dtype=torch.long, device=ids.device), targets], dim=1)

@@ -195,15 +195,38 @@ def _qkv_bias(att: Attention):
     return torch.cat([att.q_bias.detach(), torch.zeros_like(att.v_bias), att.v_bias.detach()])
 
 
-def _qkv_biases(atts):
-    """[len(atts), 3D]: row i = cat(q_bias, zeros, v_bias) of atts[i] (models/vision_transformer.py:173), built with
-    five launches for the whole tower instead of a zeros + cat pair per attention."""
-    q = torch.stack([a.q_bias.detach() for a in atts])
-    v = torch.stack([a.v_bias.detach() for a in atts])
-    out = torch.zeros((len(atts), 3, q.shape[1]), dtype=q.dtype, device=q.device)
-    out[:, 0] = q
-    out[:, 2] = v
-    return out.view(len(atts), -1)
+class _PackedQkvBias:
+    """[len(atts), 3D]: row i = cat(q_bias, zeros, v_bias) of atts[i] (models/vision_transformer.py:173).  The buffer is kept
+    across steps (its key third stays zero); refresh() re-copies the q / v halves of every attention of the tower in ONE
+    launch (mpv_copy_segments) -- the framework form was a zeros + cat pair per attention, then five launches per tower."""
+
+    def __init__(self):
+        self.buf = None
+
+    def refresh(self, atts):
+        D = atts[0].q_bias.shape[0]
+        dev = atts[0].q_bias.device
+        if self.buf is None or self.buf.shape != (len(atts), 3 * D) or self.buf.device != dev:
+            self.buf = torch.zeros((len(atts), 3 * D), dtype=torch.bfloat16, device=dev)
+        pairs = []
+        for i, a in enumerate(atts):
+            pairs.append((a.q_bias.detach(), self.buf[i, :D]))
+            pairs.append((a.v_bias.detach(), self.buf[i, 2 * D:]))
+        ops.copy_segments(pairs)
+        return self.buf
+
+
+_zero_rows = {}
+
+
+def _zero_row(cols, device):
+    """A [1, cols] bf16 row of zeros kept per device: the source of row-mapped zero fills (mpv_copy_rows with a source map of
+    stride 0), which touch only the rows that need zeroing instead of clearing a whole activation-sized tensor."""
+    key = (cols, str(device))
+    z = _zero_rows.get(key)
+    if z is None:
+        z = _zero_rows[key] = torch.zeros((1, cols), dtype=torch.bfloat16, device=device)
+    return z
 
 
 class TimeSformer(nn.Module):
@@ -261,7 +284,9 @@ class TimeSformer(nn.Module):
         else:
             x = x0
         blocks: List[dict] = []
-        qkv_b = _qkv_biases([a for blk in self.blocks for a in (blk.temporal_attn, blk.attn)])
+        if not hasattr(self, "_qkv_bias_pack"):
+            self._qkv_bias_pack = _PackedQkvBias()
+        qkv_b = self._qkv_bias_pack.refresh([a for blk in self.blocks for a in (blk.temporal_attn, blk.attn)])
         for bi, blk in enumerate(self.blocks):
             s = {}
             # ---- temporal branch on token rows (:247-251)
@@ -319,7 +344,10 @@ class TimeSformer(nn.Module):
         tok = (N, N1, 1)
         x_last = tape["x_last"]
         mt_, rt_, mc_, rc_ = tape["final_stats"]
-        dx = torch.zeros((R, D), dtype=torch.bfloat16, device=demb.device)     # cls slots t>0 get no final-LN grad
+        # cls slots t>0 get no final-LN gradient: zero the B*T cls rows (the t=0 ones are then overwritten below) instead of
+        # clearing the whole [R, D] tensor
+        dx = torch.empty((R, D), dtype=torch.bfloat16, device=demb.device)
+        ops.copy_rows(_zero_row(D, demb.device), dx, B * T, D, smap=(1, 0, 0), dmap=(1, N1, 0))
         gw, gb = grad_of(self.norm.weight), grad_of(self.norm.bias)
         ops.layernorm_bwd(demb, x_last, self.norm.weight, mt_, rt_, Rt, D, dx=dx, dgamma=gw, dbeta=gb, xmap=tok,
                           ymap=(T * N, S, 1))
@@ -327,6 +355,7 @@ class TimeSformer(nn.Module):
                           xmap=(1, T * N1, 0), ymap=(1, S, 0))
         wl = _WgradLane(demb.device) if not hasattr(self, "_wgrad_lane") else self._wgrad_lane
         self._wgrad_lane = wl
+        lnb = self.__dict__.setdefault("_ln_batch", ops.LnDparamBatch())   # a block's three dgamma/dbeta reductions: one launch
         for bi in range(len(self.blocks) - 1, -1, -1):
             blk, s = self.blocks[bi], tape["blocks"][bi]
             hid = blk.mlp.fc1.out_features
@@ -339,7 +368,7 @@ class TimeSformer(nn.Module):
                                 colsum_out=grad_of(blk.mlp.fc1.bias)), dz)
             dl2 = ops.gemm(dz, blk.mlp.fc1.weight, R, D, hid, trans_b=True)
             dy = ops.layernorm_bwd(dl2, s["y"], blk.norm2.weight, s["m2"], s["r2"], R, D, dres=dout,
-                                   dgamma=grad_of(blk.norm2.weight), dbeta=grad_of(blk.norm2.bias))
+                                   dgamma=grad_of(blk.norm2.weight), dbeta=grad_of(blk.norm2.bias), defer=lnb)
             # ---- cls merge + spatial attention
             # the projection sees dy with every cls row replaced by the mean over t: done in place on the B*T cls rows,
             # which are put back before dy is used as the residual gradient
@@ -353,14 +382,12 @@ class TimeSformer(nn.Module):
             dqkv = torch.empty_like(qkv_s)
             ops.attn_bwd(qkv_s, qkv_s[:, D:], qkv_s[:, 2 * D:], s["a_s"], s["lse"], das, dqkv, dqkv[:, D:], dqkv[:, 2 * D:],
                          s["lay"], B * T, heads, N1, N1, hd, scale=blk.attn.scale, scale_q_bf16=True)
-            def _qkv_wgrad(dqkv=dqkv):
-                bsum = torch.empty(3 * D, dtype=torch.bfloat16, device=dqkv.device)
-                ops.gemm(dqkv, s["l1"], 3 * D, D, R, trans_a=True, trans_b=True, out=grad_of(blk.attn.qkv.weight), colsum_out=bsum)
-                torch._foreach_copy_([grad_of(blk.attn.q_bias), grad_of(blk.attn.v_bias)], [bsum[:D], bsum[2 * D:]])
-            wl(_qkv_wgrad, dqkv)
+            bsum = torch.empty((2, 3 * D), dtype=torch.bfloat16, device=dqkv.device)   # packed bias gradients of the two qkv products
+            wl(lambda: ops.gemm(dqkv, s["l1"], 3 * D, D, R, trans_a=True, trans_b=True, out=grad_of(blk.attn.qkv.weight),
+                                colsum_out=bsum[0]), dqkv)
             dl1 = ops.gemm(dqkv, blk.attn.qkv.weight, R, D, 3 * D, trans_b=True)
             dxt = ops.layernorm_bwd(dl1, s["xt"], blk.norm1.weight, s["m1"], s["r1"], R, D, dres=dy,
-                                    dgamma=grad_of(blk.norm1.weight), dbeta=grad_of(blk.norm1.bias))
+                                    dgamma=grad_of(blk.norm1.weight), dbeta=grad_of(blk.norm1.bias), defer=lnb)
             # ---- temporal branch (token rows)
             if COMPOSE_TEMPORAL_OUT:
                 # Backward of temporal_attn.proj followed by temporal_fc (:199-200 then :250; proj_drop = 0, only a rearrange
@@ -376,10 +403,10 @@ class TimeSformer(nn.Module):
                     dbc = grad_of(blk.temporal_fc.bias)                                   # d(bf) = d(bc) = colsum d(xt)
                     dwc = ops.gemm(dxt, s["at"], D, D, Rt, trans_a=True, trans_b=True, kmap=tok, colsum_out=dbc)
                     dwf = ops.gemm(dwc, wp, D, D, D, tile_hint=_SMALL_TILE)               # dWc Wp^T
-                    bp = blk.temporal_attn.proj.bias.detach().float()
-                    grad_of(blk.temporal_fc.weight).copy_(dwf.float() + dbc.float()[:, None] * bp[None, :])
                     ops.gemm(wf, dwc, D, D, D, trans_a=True, trans_b=True, out=grad_of(blk.temporal_attn.proj.weight), tile_hint=_SMALL_TILE)   # Wf^T dWc
-                    grad_of(blk.temporal_attn.proj.bias).copy_((wf.float() * dbc.float()[:, None]).sum(0))              # Wf^T d(bc)
+                    # dWf = dWc Wp^T + d(bc) bp^T and d(bp) = Wf^T d(bc) in one launch
+                    ops.vit_compose_bwd_finish(dwf, dbc, blk.temporal_attn.proj.bias.detach(), wf, grad_of(blk.temporal_fc.weight),
+                                               grad_of(blk.temporal_attn.proj.bias), D)
                 wl(_temporal_out_wgrad, dxt)
                 dat = ops.gemm(dxt, wc, Rt, D, D, trans_b=True, amap=tok, cmap=tok, out_rows=R)
             else:       # the reference's two dgrads and two wgrads (measurement: MPV_VIT_COMPOSE=0)
@@ -391,17 +418,21 @@ class TimeSformer(nn.Module):
                 dat = ops.gemm(dpt, blk.temporal_attn.proj.weight, Rt, D, D, trans_b=True, amap=tok, cmap=tok, out_rows=R)
             dqkv_t = torch.empty_like(s["qkv_t"])
             ops.temporal_attn_bwd(s["qkv_t"], dat, dqkv_t, B, T * N1, N, 1, N1, T, heads, hd, blk.temporal_attn.scale)
-            def _qkv_t_wgrad(dqkv_t=dqkv_t):
-                bsum_t = torch.empty(3 * D, dtype=torch.bfloat16, device=dqkv_t.device)
+            def _qkv_t_wgrad(dqkv_t=dqkv_t, bsum=bsum):
                 ops.gemm(dqkv_t, s["lt"], 3 * D, D, Rt, trans_a=True, trans_b=True, kmap=tok,
-                         out=grad_of(blk.temporal_attn.qkv.weight), colsum_out=bsum_t)
-                torch._foreach_copy_([grad_of(blk.temporal_attn.q_bias), grad_of(blk.temporal_attn.v_bias)], [bsum_t[:D], bsum_t[2 * D:]])
-            wl(_qkv_t_wgrad, dqkv_t)
+                         out=grad_of(blk.temporal_attn.qkv.weight), colsum_out=bsum[1])
+                # q / v thirds of both packed bias gradients -> the four bias parameters' gradients (the key third belongs to no
+                # parameter: the key bias is identically zero, models/vision_transformer.py:173), one launch
+                ops.copy_segments([(bsum[0, :D], grad_of(blk.attn.q_bias)), (bsum[0, 2 * D:], grad_of(blk.attn.v_bias)),
+                                   (bsum[1, :D], grad_of(blk.temporal_attn.q_bias)), (bsum[1, 2 * D:], grad_of(blk.temporal_attn.v_bias))])
+            wl(_qkv_t_wgrad, dqkv_t, bsum)
             dlt = ops.gemm(dqkv_t, blk.temporal_attn.qkv.weight, Rt, D, 3 * D, trans_b=True, amap=tok, cmap=tok, out_rows=R)
             wl.sync()                                   # temporal_fc's wgrad reads dxt, which the next launch updates in place
             # dx = dxt (all rows) + LN_t-backward on token rows, accumulated in place
             ops.layernorm_bwd(dlt, s["x"], blk.temporal_ln.weight, s["mt"], s["rt"], Rt, D, dres=dxt, dx=dxt,
-                              dgamma=grad_of(blk.temporal_ln.weight), dbeta=grad_of(blk.temporal_ln.bias), xmap=tok, ymap=tok)
+                              dgamma=grad_of(blk.temporal_ln.weight), dbeta=grad_of(blk.temporal_ln.bias), xmap=tok, ymap=tok,
+                              defer=lnb)
+            lnb.finish()
             dx = dxt
             tape["blocks"][bi] = None          # release activations
             if self.on_block_grads_ready is not None:
@@ -465,8 +496,9 @@ class AttentionPool(nn.Module):
         Wi, bi = a.in_proj_weight.detach(), a.in_proj_bias.detach()
         q = ops.gemm(x, Wi[:D], B * Q, D, D, bias=bi[:D])
         kv = ops.gemm(kn, Wi[D:], B * S, 2 * D, D, bias=bi[D:], cmap=(S, S + 1, 0), out_rows=B * (S + 1))
-        bkv = torch.cat([a.bias_k.detach().view(1, D), a.bias_v.detach().view(1, D)], dim=1)
-        ops.copy_rows(bkv, kv, B, 2 * D, smap=(1, 0, 0), dmap=(1, S + 1, S))           # add_bias_kv token (last key)
+        # add_bias_kv token (last key / value row of every sequence)
+        ops.copy_rows(a.bias_k.detach().view(1, D), kv, B, D, smap=(1, 0, 0), dmap=(1, S + 1, S), lds=D, ldd=2 * D)
+        ops.copy_rows(a.bias_v.detach().view(1, D), kv[:, D:], B, D, smap=(1, 0, 0), dmap=(1, S + 1, S), lds=D, ldd=2 * D)
         o = torch.empty((B * Q, D), dtype=torch.bfloat16, device=emb.device)
         lay = ops.AttnLayout((Q * D, hd, D), ((S + 1) * 2 * D, hd, 2 * D), ((S + 1) * 2 * D, hd, 2 * D), (Q * D, hd, D))
         lse = ops.attn_fwd(q, kv, kv[:, D:], o, lay, B, heads, Q, S + 1, hd, scale=hd ** -0.5)
