@@ -86,6 +86,26 @@ def test_attention_kernels_budgets(kernels):
         assert k["scratch"] <= (32 if ("attn_bwd_dq_res_kernelILi96ELi7E" in n or "attn_bwd_dkv_res_kernelILi64ELi320E" in n) else 0), (n, k)
 
 
+def test_persistent_attention_kernels_never_touch_scratch(kernels):
+    """attn_*_pres_kernel: a scratch reload waits with s_waitcnt vmcnt(0), which would also drain the next item's LDS-DMA in the
+    middle of the current item; every shipped instance must fit 256 registers (two waves per SIMD) without scratch, and the
+    only vmcnt waits between the DMA issue and the end-of-item wait are the explicit ones (<= 2 per loop body: one per branch)."""
+    ks, _ = kernels
+    pres = {n: k for n, k in ks.items() if "_pres_kernel" in n}
+    assert len(pres) == 6, sorted(pres)
+    for n, k in pres.items():
+        assert k["scratch"] == 0 and k["vgpr"] + k["agpr"] <= 256, (n, k)
+    asm = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", next(iter(pres.values()))["file"]], capture_output=True, text=True).stdout
+    for n in pres:
+        body = asm[asm.index("<" + n + ">:"):]
+        body = body[:body.index("s_endpgm")]
+        first_loop_dma = [m.start() for m in re.finditer(r"buffer_load_dwordx4 v\d+, s\[\d+:\d+\], 0 offen lds", body)]
+        assert len(first_loop_dma) >= 4, n                                  # prologue pair + loop pair
+        loop = body[first_loop_dma[2]:]
+        assert "scratch_" not in loop
+        assert len(re.findall(r"s_waitcnt vmcnt\(", loop)) <= 2, (n, re.findall(r"s_waitcnt vmcnt\(\d+\)", loop))
+
+
 def test_no_other_kernel_spills(kernels):
     ks, _ = kernels
     bad = {n: k["scratch"] for n, k in ks.items() if k["scratch"] and "attn_" not in n}

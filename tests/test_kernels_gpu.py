@@ -199,6 +199,13 @@ ATTN_CASES = [  # B, H, Sq, Sk, hd, causal, scale_q_bf16
     (1, 2, 33, 33, 96, True, False),
     (2, 3, 257, 257, 88, False, True),      # EVA-ViT-g spatial attention (models/eva_vit.py:413-427: 1408 / 16 heads)
     (2, 2, 32, 258, 88, False, False),      # its abstractor: 257 keys + bias_kv
+    # more (batch, head) items than CUs: the persistent double-buffered kernels (csrc/attention.hip, attn_*_pres_kernel), 2-3 items
+    # per workgroup, the second operand set and the register prefetch of the next item in use
+    (34, 8, 197, 197, 96, False, True),     # ViT-B/16 spatial attention: lean 7-tile forward instance
+    (40, 16, 160, 160, 64, True, False),    # decoder at config B (S = 128 + 32)
+    (20, 16, 208, 208, 64, True, False),    # decoder at the YAML-as-shipped geometry (S = 128 + 80)
+    (17, 16, 160, 160, 80, True, False),    # 2.7B decoder heads; batch not a multiple of 8 (padding items are skipped)
+    (36, 8, 100, 100, 64, False, False),    # ragged tile (100 = 3 * 32 + 4): tile over-reads cross into the other operand set
 ]
 
 
@@ -241,10 +248,11 @@ def test_attention_fwd_bwd(dev, B, H, Sq, Sk, hd, causal, sqb):
         close(dq.permute(0, 2, 1, 3), q2.grad, 3e-2, "dQ (pre-scaled q)")
 
 
-def test_attention_packed_gpt_layout_and_dropout(dev):
+@pytest.mark.parametrize("B", [2, 80])      # 80 x 4 heads = 320 items: the persistent kernels
+def test_attention_packed_gpt_layout_and_dropout(dev, B):
     """GPT layout: qkv [B,S,np,3*hn] head-interleaved (modeling_distributed_gpt3.py:895-902)."""
     from youku_mplug_amd import ops
-    B, S, np_, hn = 2, 96, 4, 64
+    S, np_, hn = 96, 4, 64
     Hh = np_ * hn
     qkv = rn(B, S, np_, 3 * hn, dev=dev, seed=40)
     o = torch.empty(B, S, Hh, dtype=torch.bfloat16, device=dev)
@@ -280,11 +288,12 @@ def test_attention_packed_gpt_layout_and_dropout(dev):
     assert abs(lhs - rhs) <= 1e-4 * do.float().norm().item() * o3.float().norm().item(), (lhs, rhs)
 
 
-def test_attention_dropout_masks_forward_vs_dkv(dev):
+@pytest.mark.parametrize("B,H", [(1, 2), (40, 8)])      # (40, 8): 320 items -> the persistent kernels
+def test_attention_dropout_masks_forward_vs_dkv(dev, B, H):
     """The masks the forward and the dK/dV kernels draw, recovered element by element (q = k = 0 -> uniform
     probabilities, one-hot V and dO): identical, and the keep rate is 1 - p."""
     from youku_mplug_amd import ops
-    B, H, S, hd = 1, 2, 64, 64
+    S, hd = 64, 64
     st = (S * H * hd, hd, H * hd)
     lay = ops.AttnLayout(st, st, st, st)
     eye = torch.eye(S, hd, dtype=torch.bfloat16, device=dev).view(1, S, 1, hd)
@@ -304,6 +313,36 @@ def test_attention_dropout_masks_forward_vs_dkv(dev):
         assert not ((fwd_mask != bwd_mask) & vis).any()
         rate = fwd_mask[..., vis].float().mean().item()
         assert abs(rate - 0.75) < 0.02, rate
+
+
+@pytest.mark.parametrize("B,H", [(1, 2), (40, 8)])      # (40, 8): 320 items -> the persistent kernels
+def test_attention_dropout_backward_vs_reference_with_recovered_mask(dev, B, H):
+    """dQ / dK / dV under probability dropout against autograd through the SAME mask: the mask is a function of (seed, offset,
+    row, key) only, so it is first recovered from a forward with q = k = 0 and one-hot V, then applied in a torch reference."""
+    from youku_mplug_amd import ops
+    S, hd, pdrop = 64, 64, 0.25
+    st = (S * H * hd, hd, H * hd)
+    lay = ops.AttnLayout(st, st, st, st)
+    kw = dict(causal=True, scale=hd ** -0.5, dropout_p=pdrop, seed=11, offset=3 << 36)
+    z = torch.zeros(B, S, H, hd, dtype=torch.bfloat16, device=dev)
+    eye = z.clone()
+    eye[:] = torch.eye(S, hd, dtype=torch.bfloat16, device=dev).view(1, S, 1, hd)
+    o = torch.empty_like(z)
+    ops.attn_fwd(z, z, eye, o, lay, B, H, S, S, hd, **kw)
+    mask = (o.float().permute(0, 2, 1, 3) > 0).float()                       # [B,H,q,key] keep mask (visible part)
+    q, k, v, do = (rn(B, S, H, hd, dev=dev, seed=50 + i) for i in range(4))
+    lse = ops.attn_fwd(q, k, v, o, lay, B, H, S, S, hd, **kw)
+    dq, dk, dv = (torch.empty_like(q) for _ in range(3))
+    ops.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, lay, B, H, S, S, hd, **kw)
+    qr, kr, vr = (t.permute(0, 2, 1, 3).float().requires_grad_(True) for t in (q, k, v))
+    sc = (qr * hd ** -0.5) @ kr.transpose(-1, -2)
+    sc = sc.masked_fill(~torch.ones(S, S, dtype=torch.bool, device=dev).tril(), float("-inf"))
+    ref = (sc.softmax(-1) * mask / (1.0 - pdrop)) @ vr
+    close(o.permute(0, 2, 1, 3), ref, 2e-2, "dropout forward")
+    ref.backward(do.permute(0, 2, 1, 3).float())
+    close(dv.permute(0, 2, 1, 3), vr.grad, 2e-2, "dV under dropout")
+    close(dk.permute(0, 2, 1, 3), kr.grad, 2.5e-2, "dK under dropout")
+    close(dq.permute(0, 2, 1, 3), qr.grad, 2.5e-2, "dQ under dropout")
 
 
 @pytest.mark.parametrize("T", [4, 8, 16])

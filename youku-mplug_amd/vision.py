@@ -523,8 +523,9 @@ class AttentionPool(nn.Module):
         dz = ops.gemm(dout, self.mlp.fc2.weight, R, hid, D, trans_b=True, act_bwd_z=tape["z"], act_bwd=ACT_GELU_ERF)
         ops.gemm(dz, tape["l2"], hid, D, R, trans_a=True, trans_b=True, out=grad_of(self.mlp.fc1.weight), colsum_out=grad_of(self.mlp.fc1.bias))
         dl2 = ops.gemm(dz, self.mlp.fc1.weight, R, D, hid, trans_b=True)
+        lnb = self.__dict__.setdefault("_ln_batch", ops.LnDparamBatch())      # the three dgamma/dbeta reductions: one launch at the end
         dx2 = ops.layernorm_bwd(dl2, tape["x2"], self.norm2.weight, *tape["s2"], R, D, dres=dout,
-                                dgamma=grad_of(self.norm2.weight), dbeta=grad_of(self.norm2.bias))
+                                dgamma=grad_of(self.norm2.weight), dbeta=grad_of(self.norm2.bias), defer=lnb)
         ops.gemm(dx2, tape["o"], D, D, R, trans_a=True, trans_b=True, out=grad_of(a.out_proj.weight), colsum_out=grad_of(a.out_proj.bias))
         do = ops.gemm(dx2, a.out_proj.weight, R, D, D, trans_b=True)
         kv = tape["kv"]
@@ -545,9 +546,10 @@ class AttentionPool(nn.Module):
         ops.colsum(dkv[:, D:], B, D, ld=2 * D, rmap=(1, S + 1, S), out=grad_of(a.bias_v).view(D))
         dkn = ops.gemm(dkv, a.in_proj_weight.detach()[D:], B * S, D, 2 * D, trans_b=True, amap=kmap)
         demb = ops.layernorm_bwd(dkn, tape["emb"], self.normk.weight, *tape["sk"], B * S, D,
-                                 dgamma=grad_of(self.normk.weight), dbeta=grad_of(self.normk.bias))
+                                 dgamma=grad_of(self.normk.weight), dbeta=grad_of(self.normk.bias), defer=lnb)
         dxin = ops.layernorm_bwd(dx, tape["xin"], self.norm1.weight, *tape["s1"], R, D,
-                                 dgamma=grad_of(self.norm1.weight), dbeta=grad_of(self.norm1.bias))
+                                 dgamma=grad_of(self.norm1.weight), dbeta=grad_of(self.norm1.bias), defer=lnb)
+        lnb.finish()
         ops.colsum(dxin, B, Q * D, out=grad_of(queries).view(Q * D))                                # sum over the batch repeat
         return demb
 
