@@ -74,6 +74,19 @@ def algorithmic_train_flops(B, T, L, s=Shapes):
     return 3.0 * (vit + pool + fc) + 2.0 * gpt
 
 
+def algorithmic_train_flops_E(B, T, L, s=Shapes, E=256):
+    """BASELINE.json configs[4] (ITC retrieval step, models/distributed_gpt3.py:938-980): the video tower trains (x3, with the
+    composed temporal-projection backward counted as executed), the frozen text tower runs FORWARD only on the L title tokens
+    (nothing trainable sits below its hidden state), plus the two projection heads and the similarity products."""
+    D, N, H, Lyr = s.vit_dim, (s.img_size // s.patch_size) ** 2, s.hidden, s.layers
+    M = B * T * N
+    vit = 2 * M * D * D + s.vit_depth * (M * 2 * D * (2304 + 768 + 768 * (1.0 / 3.0) + 2304 + 768) + 2 * D * D * D + (M + B) * 4 * D * 4 * D
+                                         + B * T * 2 * D * 4 * D + B * T * 4 * (N + 1) ** 2 * D + B * N * 4 * T * T * D)
+    gpt = Lyr * 2 * B * L * H * (3 * H + H + 2 * s.ffn) + Lyr * 4 * B * L * L * H
+    heads = 3.0 * (2 * B * D * E + 2 * B * H * E) + 3.0 * 2 * 2 * B * B * E
+    return 3.0 * vit + gpt + heads
+
+
 class GemmTimer:
     """Times every mpv_gemm_bf16 launch with HIP events on the launch stream (torch's current stream)."""
 
@@ -228,9 +241,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", choices=["B", "D"], default="B", help="B = the headline 1.3B config; D = 2.7B decoder dims (side line)")
+    ap.add_argument("--config", choices=["B", "D", "E"], default="B",
+                    help="B = the headline 1.3B config; D = 2.7B decoder dims (side line); E = ITC retrieval fine-tune step at 16 frames (side line)")
     ap.add_argument("--batch", type=int, default=None)
-    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--frames", type=int, default=None)
     ap.add_argument("--text-len", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -263,10 +277,16 @@ def main():
     if args.config == "D":
         Shapes = ShapesD
     if args.batch is None:
-        args.batch = 32 if args.config == "B" else 16
+        args.batch = {"B": 32, "D": 16, "E": 96}[args.config]        # E: configs/retrieval/retrieval_gpt3_1.3B_youku_v0.yaml:19 (batch_size_train 96)
+    if args.frames is None:
+        args.frames = 16 if args.config == "E" else 8                # E: ...yaml:24 (num_frames 16)
     Shapes.num_frames = args.frames
     torch.manual_seed(1234 + rank)                                   # run_pretrain_distributed_gpt3.py:210 (initialize() broadcasts rank 0's weights)
-    model = synthetic_model(Shapes, device=dev, num_frames=args.frames)
+    if args.config == "E":
+        from youku_mplug_amd.retrieval import synthetic_retrieval_model
+        model = synthetic_retrieval_model(Shapes, device=dev, num_frames=args.frames)
+    else:
+        model = synthetic_model(Shapes, device=dev, num_frames=args.frames)
     with torch.no_grad():                                            # module-default init zeroes the temporal branch
         for blk in model.visual_encoder.blocks:
             blk.temporal_fc.weight.normal_(0, 0.015)
@@ -284,10 +304,16 @@ def main():
     total = args.warmup + args.steps
     lr_sched = [1e-4 * min(1.0, (i + 1) / 2000.0) for i in range(2 * total + 8)]     # linear warm-up (utils.py:350-372)
 
+    idx = torch.arange(B, device=dev) + rank * B                      # retrieval: one positive per (video, title) pair across the global batch
+    flops_fn = algorithmic_train_flops_E if args.config == "E" else algorithmic_train_flops
+
     def step(i):
         for g in opt.param_groups:                                   # run_pretrain_distributed_gpt3.py:88-96
             g["lr"] = lr_sched[i] * g["lr_scale"]
-        loss, _ = engine(video, text)
+        if args.config == "E":
+            loss = engine(video, text, idx)                          # downstream/run_retrieval_distributed_gpt3.py:137
+        else:
+            loss, _ = engine(video, text)
         engine.backward(loss)
         engine.step()
         return loss
@@ -357,8 +383,8 @@ def main():
                 "gemm_ms_per_step": round(tt / nroof * 1e3, 2),
                 "by_kernel": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / nroof * 1e3, 2), "launches": v[2] // nroof}
                             for k, v in tot.items()},
-                "step_algorithmic_tflop": round(algorithmic_train_flops(B, T, L, Shapes) / 1e12, 2),
-                "step_frac": round(algorithmic_train_flops(B, T, L, Shapes) / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4)}
+                "step_algorithmic_tflop": round(flops_fn(B, T, L, Shapes) / 1e12, 2),
+                "step_frac": round(flops_fn(B, T, L, Shapes) / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4)}
     if dist_on:
         dist.barrier()
     if rank == 0:
@@ -370,14 +396,19 @@ def main():
             log(f"cpu baseline on {ncores} cores ...")
             cpu = cpu_baseline(ncores)
             log("cpu baseline done")
-        rec = {"metric": "video-text samples/sec/node, mPLUG-Video 1.3B pretrain step", "value": round(world * B * args.steps / dt, 2),
+        names = {"B": "mPLUG-Video GPT3-1.3B pretrain step (freezeGPT, TimeSformer CLIP-B/16)",
+                 "D": "mPLUG-Video GPT3-2.7B pretrain step (freezeGPT, TimeSformer CLIP-B/16) -- side line, not the headline config",
+                 "E": "mPLUG-Video GPT3-1.3B ITC retrieval fine-tune step (run_retrieval_distributed_gpt3, TimeSformer CLIP-B/16) -- side line, not the headline config"}
+        rec = {"metric": "video-text samples/sec/node, mPLUG-Video 1.3B pretrain step" if args.config == "B" else
+               "video-text samples/sec/node (side line: " + ("2.7B pretrain step)" if args.config == "D" else "1.3B ITC retrieval step)"),
+               "value": round(world * B * args.steps / dt, 2),
                "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 2),
                "ms_per_step_hip_events": {"median": round(per_step[len(per_step) // 2], 2), "mean": round(sum(per_step) / len(per_step), 2),
                                           "p10": round(per_step[len(per_step) // 10], 2), "p90": round(per_step[(9 * len(per_step)) // 10], 2)},
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": f"mPLUG-Video GPT3-{'1.3B' if args.config == 'B' else '2.7B (side line, not the headline config)'} pretrain step (freezeGPT, TimeSformer CLIP-B/16), per-GPU bs={B} x {T} frames x 224^2 + {L}-token titles",
+               "config": {"workload": f"{names[args.config]}, per-GPU bs={B} x {T} frames x 224^2 + {L}-token titles",
                           "global_batch": world * B, "frames": T, "text_len": L, "queries": Shapes.num_queries, "parallelism": f"dp{world}",
                           "trainable_params_m": round(engine.flat.numel / 1e6, 1), "final_loss": round(final_loss, 4)},
                "roofline": roof, "cpu_baseline": cpu}

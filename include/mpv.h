@@ -111,8 +111,9 @@ int mpv_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* 
 size_t mpv_layernorm_bwd_workspace_size(int64_t cols);
 /* accumulate_dparams == MPV_LN_DPARAM_DEFER: the call leaves its per-workgroup dgamma/dbeta partials -- fp32
  * [mpv_layernorm_bwd_partial_rows(rows)][2][cols] at the start of `workspace`, which the caller then owns until the
- * finish -- and launches no reduction; mpv_layernorm_dparam_finish folds the partials of up to 8 such calls in ONE launch
- * (a ViT block has three LayerNorms).  dgamma / dbeta only select the mode in the deferred call (non-NULL). */
+ * finish -- and launches no reduction; mpv_layernorm_dparam_finish folds the partials of up to 8 such calls in two launches
+ * (a ViT block has three LayerNorms: six reduce launches otherwise; it uses the 16 partial rows behind the call's own as
+ * scratch, which the workspace size already covers).  dgamma / dbeta only select the mode in the deferred call (non-NULL). */
 #define MPV_LN_DPARAM_DEFER 2
 int mpv_layernorm_bwd_partial_rows(int64_t rows);
 int mpv_layernorm_dparam_finish(const float* const* partials, const int* partial_rows, void* const* dgamma, void* const* dbeta,

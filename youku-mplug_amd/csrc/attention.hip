@@ -1098,6 +1098,11 @@ __global__ __launch_bounds__(THREADS, WPE) void attn_bwd_dkv_res_kernel(const At
 // so that those stay in flight across the barrier).  Register operands of the next item (the wave's own Q / dO / K / V rows)
 // are requested at the point where the current item's copy is dead, into the same registers.
 //   item i -> (batch, head) exactly as decode_bh: i % 8 = XCD, so the heads of one sequence share an L2.
+// Measured (profiles/r03_c1_kernel_trace.md, config B in-step): the 7-tile ViT forward 108 -> 87 us per layer.  The same
+// structure for the decoder (head_dim 64, 5 waves per item) LOST to the one-shot kernels -- forward 34.9 vs 29.0 us, dQ 48.0 vs
+// 48.9, dK/dV 62.3 vs 48.6: those items are bound by the dependent chain inside one wave (few tiles, a dropout hash per
+// element), and two co-resident one-shot workgroups hide more of it than one workgroup with a hidden load -- so only the
+// forward instances of the ViT shape are kept.
 // LDS images are UNPADDED [rows][pitch] with only the region size rounded up to whole 1 KiB DMA pieces (the tail of the last
 // piece is zero-filled): a 32-row tile read past the last row lands in the next region, which always holds finite data of
 // some item (or, past the allocation, reads as zero) -- every product with such a row is masked by a select or multiplied
@@ -1148,24 +1153,6 @@ __device__ __forceinline__ int pres_next(const AttnArgs& p, int it, int step, in
   return it;
 }
 
-// Row fragments through a wave-uniform base and ONE 32-bit element offset per lane (host-checked: every offset < 2^31): the
-// generic loader's 64-bit per-lane addresses, hoisted out of the item loop as loop invariants, were what the register
-// allocator spilled first.  `lane` is made opaque once per item so that this arithmetic is redone per item, not kept live.
-template <int HD>
-__device__ __forceinline__ void load_row_frags32(bf16x8 (&f)[HD / 16], const bf16* base, int rs, int row, int nrows, int lane, int hd) {
-  const uint32_t r0 = (uint32_t)(row * rs + (lane >> 5) * 8);
-#pragma unroll
-  for (int s = 0; s < HD / 16; ++s) {
-    union { i32x4 i; bf16x8 b; } u;
-    u.i = i32x4{0, 0, 0, 0};
-    if (row < nrows && s * 16 + (lane >> 5) * 8 < hd) u.i = *(const i32x4*)(base + (r0 + (uint32_t)(s * 16)));
-    f[s] = u.b;
-  }
-}
-__device__ __forceinline__ int opaque(int v) {
-  asm volatile("" : "+v"(v));
-  return v;
-}
 // the lane id recomputed where it is needed (two VALU instructions) instead of a value kept live across the item loop (the
 // allocator parked threadIdx.x in scratch and re-read it mid-item behind an s_waitcnt vmcnt(0) -- which also waits for the
 // next item's LDS-DMA)
@@ -1361,352 +1348,6 @@ __global__ __launch_bounds__(THREADS, WPE) void attn_fwd_pres_kernel(const AttnA
       pres_wait_all();
     }
     __syncthreads();          // every wave's pieces are in, and nobody still reads set `cur`
-    if (nx >= nitems) break;
-    it = nx;
-    cur ^= 1;
-  }
-}
-
-// rowsum(dO * O) from two sets of row fragments (lanes l and l^32 own the two halves of row l & 31)
-template <int NS>
-__device__ __forceinline__ float frag_row_dot(const bf16x8 (&a)[NS], const bf16x8 (&b)[NS]) {
-  float s = 0.f;
-#pragma unroll
-  for (int st = 0; st < NS; ++st) {
-    const f32x8 x = cvt8(a[st]), y = cvt8(b[st]);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s += x[e] * y[e];
-  }
-  return s + __shfl_xor(s, 32, 64);
-}
-// n fp32 values -> LDS (256-byte pieces: lane l's dword goes to lds_addr + 4 * l); values past n read as zero
-__device__ __forceinline__ void pres_dma_f32(i32x4 rsrc, uint32_t lds_base, int n, int wave, int nwaves, int lane) {
-  const int ninstr = (n + 63) >> 6;
-  for (int i = wave; i < ninstr; i += nwaves) {
-    const int g = i * 64 + lane;
-    const uint32_t off = g < n ? (uint32_t)g * 4u : 0x80000000u;
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tbuffer_load_dword %1, %2, 0 offen lds" : : "s"(lds_base + (uint32_t)i * 256u), "v"(off), "s"(rsrc) : "memory");
-  }
-}
-
-// dQ: K and V of the item resident (two sets), the wave's q / dO rows and statistics in registers, the next item's requested
-// at the top of the current one (their registers are the only extra state: the kernel has no score-tile array).
-template <int HD, int THREADS = 512, int WPE = 1>
-__global__ __launch_bounds__(THREADS, WPE) void attn_bwd_dq_pres_kernel(const AttnArgs p, const int nitems) {
-  constexpr int NS = HD / 16;
-  constexpr int NDT = (HD + 31) / 32;
-  constexpr int RP = PresPitch<HD>::R;
-  extern __shared__ __attribute__((aligned(1024))) char rsm[];
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
-  const int rbytes = pres_region(p.sk, RP), setb = 2 * rbytes;      // set = [V | K]
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)rsm;
-  const int step = gridDim.x;
-  const int q0 = wave * 32;
-  const bool active = q0 < p.sq;
-  auto issue = [&](int it, int buf) {
-    int b, h;
-    pres_item(p, it, b, h);
-    const int lane = fresh_lane();
-    const uint32_t kspan = (uint32_t)(((p.sk - 1) * (int)p.k_rs + p.hd) * 2), vspan = (uint32_t)(((p.sk - 1) * (int)p.v_rs + p.hd) * 2);
-    pres_dma_rows<RP>(pres_rsrc(p.k + pres_off(b, h, p.k_bs, p.k_hs), kspan), lds0 + buf * setb + rbytes, p.sk, (int)p.k_rs, wave, nwaves, lane, p.hd);
-    pres_dma_rows<RP>(pres_rsrc(p.v + pres_off(b, h, p.v_bs, p.v_hs), vspan), lds0 + buf * setb, p.sk, (int)p.v_rs, wave, nwaves, lane, p.hd);
-  };
-  auto request = [&](int it, bf16x8 (&q)[NS], bf16x8 (&d)[NS], bf16x8 (&o)[NS], float& ls) {
-    int b, h;
-    pres_item(p, it, b, h);
-    const int lane = fresh_lane();
-    const int qrow = q0 + (lane & 31);
-    const uint32_t oo = pres_off(b, h, p.o_bs, p.o_hs);
-    const uint32_t ospan = (uint32_t)(((p.sq - 1) * (int)p.o_rs + p.hd) * 2);
-    load_row_frags_buf<HD>(q, p.q + pres_off(b, h, p.q_bs, p.q_hs), (uint32_t)(((p.sq - 1) * (int)p.q_rs + p.hd) * 2), (int)p.q_rs, qrow, p.sq, lane, p.hd);
-    load_row_frags_buf<HD>(d, p.dO + oo, ospan, (int)p.o_rs, qrow, p.sq, lane, p.hd);
-    load_row_frags_buf<HD>(o, p.o + oo, ospan, (int)p.o_rs, qrow, p.sq, lane, p.hd);
-    ls = qrow < p.sq ? p.lse[(uint32_t)((b * p.heads + h) * p.sq + qrow)] : INFINITY;
-  };
-  int it = pres_next(p, blockIdx.x, step, nitems);
-  if (it >= nitems) return;
-  pres_clear_lds(rsm, 2 * setb);
-  issue(it, 0);
-  bf16x8 qf[NS], dof[NS], qn[NS], don[NS], on[NS];
-  float lse, lse_n = 0.f, dl;
-  request(it, qf, dof, on, lse);
-  dl = frag_row_dot<NS>(dof, on);
-  pres_wait_all();
-  __syncthreads();
-  const lds_char* sm = (const lds_char*)rsm;
-  int cur = 0;
-  while (true) {
-    const int nx = pres_next(p, it + step, step, nitems);
-    if (nx < nitems) {
-      issue(nx, cur ^ 1);
-      request(nx, qn, don, on, lse_n);
-    }
-    int b, h;
-    pres_item(p, it, b, h);
-    const int bh = b * p.heads + h;
-    const int lane = fresh_lane();
-    const int qrow = q0 + (lane & 31);
-    const bool qok = qrow < p.sq;
-    if (qok && lane < 32) p.delta[(uint32_t)(bh * p.sq + qrow)] = dl;       // read by the dK/dV kernel that follows
-    f32x16 dqacc[NDT];
-#pragma unroll
-    for (int d = 0; d < NDT; ++d)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) dqacc[d][e] = 0.f;
-    if (active) {
-      const int my_last = last_visible_key(p, qrow);
-      const int nt = last_visible_key(p, min(p.sq - 1, q0 + 31)) / 32 + 1;
-      const int wave_first_last = last_visible_key(p, q0);
-      float sc = p.scale;
-      if (p.scale_q_bf16) {
-        scale_frags_bf16(qf, p.scale);
-        sc = 1.0f;
-      }
-      const float c2 = sc * 1.4426950408889634f, lse2 = lse * 1.4426950408889634f;
-      const int kroff = cur * setb + rbytes + rows_lane_base<RP>(lane), vroff = cur * setb + rows_lane_base<RP>(lane);
-      const int kcoff = cur * setb + rbytes + cols_lane_base<RP>(lane);
-      for (int kt = 0; kt < nt; ++kt) {
-        f32x16 s, dp, s_odd, dp_odd;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) s[e] = dp[e] = s_odd[e] = dp_odd[e] = 0.f;
-#pragma unroll
-        for (int st = 0; st < NS; ++st) {
-          if (st & 1) {
-            s_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, kroff + kt * 32 * RP, st), qf[st], s_odd, 0, 0, 0);
-            dp_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, vroff + kt * 32 * RP, st), dof[st], dp_odd, 0, 0, 0);
-          } else {
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, kroff + kt * 32 * RP, st), qf[st], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, vroff + kt * 32 * RP, st), dof[st], dp, 0, 0, 0);
-          }
-        }
-        s += s_odd;
-        dp += dp_odd;
-        if (kt * 32 + 31 <= wave_first_last && !p.drop_thr) {
-#pragma unroll
-          for (int e = 0; e < 16; e += 2) {
-            const f32x2 t = __builtin_elementwise_fma(f32x2{s[e], s[e + 1]}, f32x2{c2, c2}, f32x2{-lse2, -lse2});
-            const f32x2 pr = {fexp2(t[0]), fexp2(t[1])};
-            const f32x2 ds = pr * (f32x2{dp[e], dp[e + 1]} - f32x2{dl, dl});
-            s[e] = ds[0];
-            s[e + 1] = ds[1];
-          }
-        } else {
-          const uint64_t rb = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qrow) * (uint64_t)p.sk;
-#pragma unroll
-          for (int e = 0; e < 16; e += 2) {      // registers e, e+1 hold keys k, k+1 with k even: one hash per pair
-            const int key = kt * 32 + acc_row(e, lane);
-            float d0 = dp[e], d1 = dp[e + 1];
-            if (p.drop_thr) {
-              const uint32_t r = mpv_rand_pair(p.seed, rb + (uint64_t)key);
-              d0 = (r & 0xffffu) >= p.drop_thr ? d0 * p.drop_scale : 0.f;
-              d1 = (r >> 16) >= p.drop_thr ? d1 * p.drop_scale : 0.f;
-            }
-            const float p0 = fexp2(s[e] * c2 - lse2), p1 = fexp2(s[e + 1] * c2 - lse2);
-            s[e] = key <= my_last ? p0 * (d0 - dl) : 0.f;
-            s[e + 1] = key + 1 <= my_last ? p1 * (d1 - dl) : 0.f;
-          }
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const bf16x8 dsf = acc_to_frag(s, ks);
-#pragma unroll
-          for (int d = 0; d < NDT; ++d)
-            dqacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_f<RP>(sm, kcoff + kt * 32 * RP, ks, d), dsf, dqacc[d], 0, 0, 0);
-        }
-      }
-    }
-    pres_wait_all();
-    const int lane_e = fresh_lane();      // fresh: store addresses formed here, not hoisted to the top of the item
-    if (q0 + (lane_e & 31) < p.sq) {
-      bf16* qb = p.dq + pres_off(b, h, p.q_bs, p.q_hs);
-      const uint32_t ro = (uint32_t)((q0 + (lane_e & 31)) * (int)p.q_rs + 4 * (lane_e >> 5));
-#pragma unroll
-      for (int d = 0; d < NDT; ++d)
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          const int col = d * 32 + 8 * q4;
-          if (col + 4 * (lane_e >> 5) < p.hd) {
-            f32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = dqacc[d][4 * q4 + e] * p.scale;
-            *(bf16x4*)(qb + (ro + (uint32_t)col)) = cvt4(v);
-          }
-        }
-    }
-    if (nx < nitems) {
-      dl = frag_row_dot<NS>(don, on);
-      lse = lse_n;
-#pragma unroll
-      for (int st = 0; st < NS; ++st) {
-        qf[st] = qn[st];
-        dof[st] = don[st];
-      }
-    }
-    __syncthreads();
-    if (nx >= nitems) break;
-    it = nx;
-    cur ^= 1;
-  }
-}
-
-// dK/dV for head_dim <= 80 (the wave's K and V rows in registers): Q, dO and the per-row statistics of the item resident in
-// two sets.  LDS = [stats 0 | stats 1 | dO 0 | Q 0 | dO 1 | Q 1]: a tile over-read of dO lands in Q, of Q in the other set's
-// dO (or past the allocation) -- never in the fp32 statistics.  No scale_q_bf16 form (the decoder does not use it).
-template <int HD, int THREADS, int WPE = 1>
-__global__ __launch_bounds__(THREADS, WPE) void attn_bwd_dkv_pres_kernel(const AttnArgs p, const int nitems) {
-  constexpr int NS = HD / 16;
-  constexpr int NDT = (HD + 31) / 32;
-  constexpr int RP = PresPitch<HD>::R;
-  static_assert(HD <= 80, "head_dim 96 keeps V in LDS (attn_bwd_dkv_res_kernel)");
-  extern __shared__ __attribute__((aligned(1024))) char rsm[];
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
-  const int qtiles = (p.sq + 31) / 32, qrows = qtiles * 32;
-  const int sarr = (p.sq + 63) / 64 * 64;      // floats per statistics array: whole 256-byte DMA pieces, so the two arrays' pieces never overlap
-  const int sbytes = (2 * sarr * 4 + 1023) / 1024 * 1024, rbytes = pres_region(p.sq, RP), setb = 2 * rbytes;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)rsm;
-  const int step = gridDim.x;
-  const int k0 = wave * 32;
-  const bool active = k0 < p.sk;
-  auto issue = [&](int it, int buf) {
-    int b, h;
-    pres_item(p, it, b, h);
-    const int lane = fresh_lane();
-    const uint32_t qspan = (uint32_t)(((p.sq - 1) * (int)p.q_rs + p.hd) * 2), ospan = (uint32_t)(((p.sq - 1) * (int)p.o_rs + p.hd) * 2);
-    const uint32_t base = lds0 + 2 * sbytes + buf * setb;
-    pres_dma_rows<RP>(pres_rsrc(p.dO + pres_off(b, h, p.o_bs, p.o_hs), ospan), base, p.sq, (int)p.o_rs, wave, nwaves, lane, p.hd);
-    pres_dma_rows<RP>(pres_rsrc(p.q + pres_off(b, h, p.q_bs, p.q_hs), qspan), base + rbytes, p.sq, (int)p.q_rs, wave, nwaves, lane, p.hd);
-    const uint32_t so = (uint32_t)((b * p.heads + h) * p.sq);
-    pres_dma_f32(pres_rsrc(p.lse + so, (uint32_t)p.sq * 4u), lds0 + buf * sbytes, p.sq, wave, nwaves, lane);
-    pres_dma_f32(pres_rsrc(p.delta + so, (uint32_t)p.sq * 4u), lds0 + buf * sbytes + sarr * 4, p.sq, wave, nwaves, lane);
-  };
-  bf16x8 kf[NS], vf[NS], kn[NS], vn[NS];
-  auto request = [&](int it, bf16x8 (&k)[NS], bf16x8 (&v)[NS]) {
-    int b, h;
-    pres_item(p, it, b, h);
-    const int lane = fresh_lane();
-    load_row_frags_buf<HD>(k, p.k + pres_off(b, h, p.k_bs, p.k_hs), (uint32_t)(((p.sk - 1) * (int)p.k_rs + p.hd) * 2), (int)p.k_rs, k0 + (lane & 31), p.sk, lane, p.hd);
-    load_row_frags_buf<HD>(v, p.v + pres_off(b, h, p.v_bs, p.v_hs), (uint32_t)(((p.sk - 1) * (int)p.v_rs + p.hd) * 2), (int)p.v_rs, k0 + (lane & 31), p.sk, lane, p.hd);
-  };
-  int it = pres_next(p, blockIdx.x, step, nitems);
-  if (it >= nitems) return;
-  pres_clear_lds(rsm, 2 * sbytes + 2 * setb);
-  issue(it, 0);
-  request(it, kf, vf);
-  pres_wait_all();
-  __syncthreads();
-  const lds_char* sm = (const lds_char*)rsm;
-  int cur = 0;
-  while (true) {
-    const int nx = pres_next(p, it + step, step, nitems);
-    if (nx < nitems) {
-      issue(nx, cur ^ 1);
-      request(nx, kn, vn);
-    }
-    int b, h;
-    pres_item(p, it, b, h);
-    const int bh = b * p.heads + h;
-    const int lane = fresh_lane();
-    const int krow = k0 + (lane & 31);
-    const bool kok = krow < p.sk;
-    f32x16 dkacc[NDT], dvacc[NDT];
-#pragma unroll
-    for (int d = 0; d < NDT; ++d)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) dkacc[d][e] = dvacc[d][e] = 0.f;
-    if (active) {
-      const float c2 = p.scale * 1.4426950408889634f;
-      const int first_q = p.causal ? max(0, k0 - (p.sk - p.sq)) : 0;
-      const float* sl = (const float*)(rsm + cur * sbytes);
-      const int dbase = 2 * sbytes + cur * setb, qbase = dbase + rbytes;
-      const int qroff = qbase + rows_lane_base<RP>(lane), droff = dbase + rows_lane_base<RP>(lane);
-      const int qcoff = qbase + cols_lane_base<RP>(lane), dcoff = dbase + cols_lane_base<RP>(lane);
-      for (int qt = first_q / 32; qt < qtiles; ++qt) {
-        f32x16 s, dp;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
-#pragma unroll
-        for (int st = 0; st < NS; ++st) {
-          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, qroff + qt * 32 * RP, st), kf[st], s, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_f(sm, droff + qt * 32 * RP, st), vf[st], dp, 0, 0, 0);
-        }
-        const bool interior = !p.drop_thr && (k0 + 31 < p.sk) && (qt * 32 + 31 < p.sq) && (!p.causal || (k0 + 31 <= qt * 32 + (p.sk - p.sq)));
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          f32x8 pr8, ds8;
-#pragma unroll
-          for (int qh = 0; qh < 2; ++qh) {
-            const int q4 = 2 * ks + qh;
-            const int qb4 = qt * 32 + 8 * q4 + 4 * (lane >> 5);
-            const f32x4 l4 = *(const f32x4*)(sl + qb4) * 1.4426950408889634f, d4 = *(const f32x4*)(sl + sarr + qb4);
-            if (interior) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const int e = 4 * q4 + j;
-                const float pr = fexp2(s[e] * c2 - l4[j]);
-                pr8[4 * qh + j] = pr;
-                ds8[4 * qh + j] = pr * (dp[e] - d4[j]);
-              }
-            } else {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const int e = 4 * q4 + j;
-                const int qr = qb4 + j;
-                const int lastk = p.causal ? qr + (p.sk - p.sq) : p.sk - 1;
-                const bool vis = kok && krow <= lastk && qr < p.sq;
-                const float pr = vis ? fexp2(s[e] * c2 - l4[j]) : 0.f;
-                float keep = 1.0f;
-                if (p.drop_thr) {
-                  const uint64_t rb = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qr) * (uint64_t)p.sk;
-                  keep = attn_keep(p.seed, rb, krow, p.drop_thr) ? p.drop_scale : 0.f;
-                }
-                pr8[4 * qh + j] = vis ? pr * keep : 0.f;
-                ds8[4 * qh + j] = vis ? pr * (dp[e] * keep - d4[j]) : 0.f;
-              }
-            }
-          }
-          const bf16x8 pf = cvt8(pr8), dsf = cvt8(ds8);
-#pragma unroll
-          for (int d = 0; d < NDT; ++d) {
-            dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_f<RP>(sm, dcoff + qt * 32 * RP, ks, d), pf, dvacc[d], 0, 0, 0);
-            dkacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_f<RP>(sm, qcoff + qt * 32 * RP, ks, d), dsf, dkacc[d], 0, 0, 0);
-          }
-        }
-      }
-    }
-    pres_wait_all();
-    const int lane_e = fresh_lane();      // fresh: store addresses formed here, not hoisted to the top of the item
-    const int krow_e = k0 + (lane_e & 31);
-    if (krow_e < p.sk) {
-      bf16* dvb = p.dv + pres_off(b, h, p.v_bs, p.v_hs);
-      bf16* dkb = p.dk + pres_off(b, h, p.k_bs, p.k_hs);
-      const uint32_t rv = (uint32_t)(krow_e * (int)p.v_rs + 4 * (lane_e >> 5)), rk = (uint32_t)(krow_e * (int)p.k_rs + 4 * (lane_e >> 5));
-#pragma unroll
-      for (int d = 0; d < NDT; ++d)
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          const int col = d * 32 + 8 * q4;
-          if (col + 4 * (lane_e >> 5) < p.hd) {
-            f32x4 a, c;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              a[e] = dvacc[d][4 * q4 + e];
-              c[e] = dkacc[d][4 * q4 + e] * p.scale;
-            }
-            *(bf16x4*)(dvb + (rv + (uint32_t)col)) = cvt4(a);
-            *(bf16x4*)(dkb + (rk + (uint32_t)col)) = cvt4(c);
-          }
-        }
-    }
-    if (nx < nitems) {
-#pragma unroll
-      for (int st = 0; st < NS; ++st) {
-        kf[st] = kn[st];
-        vf[st] = vn[st];
-      }
-    }
-    __syncthreads();
     if (nx >= nitems) break;
     it = nx;
     cur ^= 1;
@@ -2025,17 +1666,14 @@ static void pres_attr_once() {
   static bool done = false;
   if (done) return;
   const int L = (int)PRES_LDS_MAX;
-  allow_lds(attn_fwd_pres_kernel<64, 0, 5, 320, 1>, L); allow_lds(attn_fwd_pres_kernel<64>, L);
   allow_lds(attn_fwd_pres_kernel<96, 7>, L); allow_lds(attn_fwd_pres_kernel<96, 7, 8, 512, 1, true>, L);
-  allow_lds(attn_bwd_dq_pres_kernel<64>, L);
-  allow_lds(attn_bwd_dkv_pres_kernel<64, 512>, L);
   done = true;
 }
-// Instances exist where the item loop fits the register file without scratch (a scratch reload sits behind an s_waitcnt
-// vmcnt(0), which would drain the next item's DMA in the middle of the current one): head_dim <= 64 (every kernel) and the
-// 7-tile non-causal head_dim-96 forward (ViT-B/16).  head_dim 80 / generic 96 stay on the one-shot resident kernels.
+// Instances exist where the structure measured faster than the one-shot kernels and the item loop fits the register file
+// without scratch (a scratch reload sits behind an s_waitcnt vmcnt(0), which would drain the next item's DMA in the middle of
+// the current one): the 7-tile non-causal head_dim-96 forward (ViT-B/16 spatial attention).
 static bool pres_fwd_has(int hdc, const mpv_attn_desc* d) {
-  return hdc == 64 || (hdc == 96 && !d->causal && d->dropout_p == 0.f && (d->sk + 31) / 32 == 7);
+  return hdc == 96 && !d->causal && d->dropout_p == 0.f && (d->sk + 31) / 32 == 7;
 }
 
 static void res_attr_once() {
@@ -2068,10 +1706,7 @@ extern "C" int mpv_attn_fwd(const mpv_attn_desc* d, hipStream_t stream) {
     if (grid.x == 1 && plds <= PRES_LDS_MAX && pres_wanted(gy) && pres_offsets_ok(d) && pres_fwd_has(hdc, d)) {
       pres_attr_once();
       const dim3 pg((unsigned)(gy < attn_ncu() ? gy : attn_ncu()));
-      if (hdc == 64) {
-        if (d->sk <= 160 && nw <= 5) hipLaunchKernelGGL((attn_fwd_pres_kernel<64, 0, 5, 320, 1>), pg, block, plds, stream, a, gy);
-        else hipLaunchKernelGGL((attn_fwd_pres_kernel<64>), pg, block, plds, stream, a, gy);
-      } else if (d->sk <= 200) {
+      if (d->sk <= 200) {
         hipLaunchKernelGGL((attn_fwd_pres_kernel<96, 7, 8, 512, 1, true>), pg, block, plds, stream, a, gy);   // ViT-B/16: 197 keys
       } else {
         hipLaunchKernelGGL((attn_fwd_pres_kernel<96, 7>), pg, block, plds, stream, a, gy);
@@ -2123,20 +1758,10 @@ extern "C" int mpv_attn_bwd(const mpv_attn_desc* d, const void* dO, void* dq, vo
     dim3 gq((d->sq + 32 * nw - 1) / (32 * nw), gy), gk((d->sk + 32 * nwk - 1) / (32 * nwk), gy);
     const size_t lq = res_lds_bytes(d->sk, false), lk = res_lds_bytes(d->sq, true) + (d->head_dim > 64 ? res_region(d->sk, ROWB) : 0);
     const int hdc = d->head_dim <= 64 ? 64 : d->head_dim <= 80 ? 80 : 96;
-    const bool strides_ok = pres_offsets_ok(d);
-    const size_t pq = 4 * pres_region_h(d->sk, pres_pitch_r(hdc));
-    const int sarr = (d->sq + 63) / 64 * 64;
-    const size_t pk = 2 * (((size_t)2 * sarr * 4 + 1023) / 1024 * 1024) + 4 * pres_region_h(d->sq, pres_pitch_r(hdc));
-    const bool pres_q = gq.x == 1 && pq <= PRES_LDS_MAX && pres_wanted(gy) && strides_ok && hdc == 64;
-    const bool pres_k = gk.x == 1 && pk <= PRES_LDS_MAX && pres_wanted(gy) && strides_ok && hdc == 64 && !d->scale_q_bf16;
-    if (pres_q || pres_k) pres_attr_once();
-    const dim3 pg((unsigned)(gy < attn_ncu() ? gy : attn_ncu()));
     const bool small64 = hdc == 64 && d->sk <= 160 && d->sq <= 160 && nw <= 5 && nwk <= 5;     // two workgroups per CU (see attn_fwd_res_kernel)
     const bool vit7 = hdc == 96 && !d->causal && d->dropout_p == 0.f && (d->sk + 31) / 32 == 7;
     // dQ first: it also stores delta = rowsum(dO * O), which the dK/dV kernel reads
-    if (pres_q) {
-      hipLaunchKernelGGL((attn_bwd_dq_pres_kernel<64>), pg, dim3(64 * nw), pq, stream, a, gy);
-    } else {
+    {
       switch (hdc) {
         case 64:
           if (small64) hipLaunchKernelGGL((attn_bwd_dq_res_kernel<64, 0, 320, 3>), gq, dim3(64 * nw), lq, stream, a);
@@ -2149,9 +1774,7 @@ extern "C" int mpv_attn_bwd(const mpv_attn_desc* d, const void* dO, void* dq, vo
           break;
       }
     }
-    if (pres_k) {
-      hipLaunchKernelGGL((attn_bwd_dkv_pres_kernel<64, 512>), pg, dim3(64 * nwk), pk, stream, a, gy);
-    } else {
+    {
       switch (hdc) {
         case 64:
           if (small64) hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<64, 320, 3>), gk, dim3(64 * nwk), lk, stream, a);

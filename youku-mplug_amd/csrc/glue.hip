@@ -31,25 +31,38 @@ __global__ __launch_bounds__(256) void copy_segments_kernel(const SegArgs a) {
 // ---- composed temporal-projection backward: the two [D, D] / [D] finishing steps ----------------------------
 // dWf[i][j] = bf16( float(P[i][j]) + dbc[i] * bp[j] )      (P = dWc Wp^T from the GEMM, rounded to bf16 there)
 // dbp[j]    = bf16( sum_i Wf[i][j] * dbc[i] )               (= Wf^T d(bc))
-// grid: D / 64 column groups x (D / 64 + 1) row groups; the last row group of a column group does the column sum.
+// grid.x < nrank: rank-1 update, one thread per 8 consecutive columns of a row (16-byte accesses; D % 8 == 0);
+// the remaining D / 64 workgroups: column sums, 64 columns x 4 row lanes each.
 __global__ __launch_bounds__(256) void compose_finish_kernel(const bf16* __restrict__ P, const bf16* __restrict__ dbc,
                                                              const bf16* __restrict__ bp, const bf16* __restrict__ wf,
-                                                             bf16* __restrict__ dwf, bf16* __restrict__ dbp, int D) {
+                                                             bf16* __restrict__ dwf, bf16* __restrict__ dbp, int D, int nrank) {
   __shared__ float red[4][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + cl;
-  if ((int)blockIdx.y < (D + 63) / 64) {
-    if (j < D) {
-      const float b = bf2f(bp[j]);
-      for (int i = blockIdx.y * 64 + rl; i < min(D, (int)blockIdx.y * 64 + 64); i += 4)
-        dwf[(long long)i * D + j] = f2bf(bf2f(P[(long long)i * D + j]) + bf2f(dbc[i]) * b);
+  if ((int)blockIdx.x < nrank) {
+    const int d8 = D >> 3;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g < D * d8) {
+      const int i = g / d8, c = (g - i * d8) * 8;
+      const float a = bf2f(dbc[i]);
+      const f32x8 b = cvt8(*(const bf16x8*)(bp + c));
+      f32x8 v = cvt8(*(const bf16x8*)(P + (long long)i * D + c));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += a * b[e];
+      *(bf16x8*)(dwf + (long long)i * D + c) = cvt8(v);
     }
     return;
   }
-  float acc = 0.f;
-  if (j < D)
-    for (int i = rl; i < D; i += 4) acc += bf2f(wf[(long long)i * D + j]) * bf2f(dbc[i]);
-  red[rl][cl] = acc;
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int j = (blockIdx.x - nrank) * 64 + cl;
+  float acc0 = 0.f, acc1 = 0.f;
+  if (j < D) {
+    int i = rl;
+    for (; i + 4 < D; i += 8) {
+      acc0 += bf2f(wf[(long long)i * D + j]) * bf2f(dbc[i]);
+      acc1 += bf2f(wf[(long long)(i + 4) * D + j]) * bf2f(dbc[i + 4]);
+    }
+    if (i < D) acc0 += bf2f(wf[(long long)i * D + j]) * bf2f(dbc[i]);
+  }
+  red[rl][cl] = acc0 + acc1;
   __syncthreads();
   if (rl == 0 && j < D) dbp[j] = f2bf((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
 }
@@ -82,35 +95,41 @@ __global__ __launch_bounds__(256) void caption_targets_kernel(const long long* _
 }
 
 // ---- deferred LayerNorm parameter-gradient reduction --------------------------------------------------------
-// mpv_layernorm_bwd in deferred mode leaves its per-workgroup partials [nblk][2][cols] (fp32) in a caller-owned buffer;
-// this kernel folds up to LNF_MAX such buffers in ONE launch (a ViT block has three LayerNorms: 6 reduce launches -> 1).
-// grid (cols / 32, n): a workgroup = 32 columns x 8 row lanes, fixed summation order (deterministic).
+// mpv_layernorm_bwd in deferred mode leaves its per-workgroup partials [nblk][2][cols] (fp32) in a caller-owned buffer; the
+// finish folds up to LNF_MAX such buffers in TWO launches (a ViT block has three LayerNorms: six reduce launches before):
+// level 1, grid (cols / 64, LNF_SLICES, n): every workgroup (64 columns x 4 row lanes) folds its slice of the partial rows into
+// row `slice` of the buffer's tail area [nblk + slice]; level 2, grid (cols / 64, 1, n): folds the LNF_SLICES rows and writes bf16.
+// Fixed summation order (deterministic).
 constexpr int LNF_MAX = 8;
+constexpr int LNF_SLICES = 16;
 struct LnFinishArgs {
-  const float* part[LNF_MAX];
+  float* part[LNF_MAX];
   bf16* dgamma[LNF_MAX];
   bf16* dbeta[LNF_MAX];
   int nblk[LNF_MAX];
   int accumulate[LNF_MAX];
   int cols;
 };
+template <bool FINAL>
 __global__ __launch_bounds__(256) void ln_dparam_finish_kernel(const LnFinishArgs a) {
-  __shared__ float red[2][8][32];
-  const int s = blockIdx.y;
-  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
-  const float* __restrict__ part = a.part[s];
+  __shared__ float red[2][4][64];
+  const int s = blockIdx.z;
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   const int nblk = a.nblk[s], cols = a.cols;
+  const float* __restrict__ part = FINAL ? a.part[s] + (long long)nblk * 2 * cols : a.part[s];
+  const int per = (nblk + LNF_SLICES - 1) / LNF_SLICES;
+  const int i0 = FINAL ? 0 : blockIdx.y * per, i1 = FINAL ? LNF_SLICES : min(nblk, i0 + per);
   float g0 = 0.f, b0 = 0.f, g1 = 0.f, b1 = 0.f;
   if (c < cols) {
-    int i = rl;
-    for (; i + 8 < nblk; i += 16) {
+    int i = i0 + rl;
+    for (; i + 4 < i1; i += 8) {
       g0 += part[(long long)i * 2 * cols + c];
       b0 += part[(long long)i * 2 * cols + cols + c];
-      g1 += part[(long long)(i + 8) * 2 * cols + c];
-      b1 += part[(long long)(i + 8) * 2 * cols + cols + c];
+      g1 += part[(long long)(i + 4) * 2 * cols + c];
+      b1 += part[(long long)(i + 4) * 2 * cols + cols + c];
     }
-    if (i < nblk) {
+    if (i < i1) {
       g0 += part[(long long)i * 2 * cols + c];
       b0 += part[(long long)i * 2 * cols + cols + c];
     }
@@ -119,18 +138,20 @@ __global__ __launch_bounds__(256) void ln_dparam_finish_kernel(const LnFinishArg
   red[1][rl][cl] = b0 + b1;
   __syncthreads();
   if (rl == 0 && c < cols) {
-    float g = 0.f, b = 0.f;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      g += red[0][r][cl];
-      b += red[1][r][cl];
+    float g = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+    float b = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+    if constexpr (!FINAL) {
+      float* out = a.part[s] + (long long)(nblk + blockIdx.y) * 2 * cols;
+      out[c] = g;
+      out[cols + c] = b;
+    } else {
+      if (a.accumulate[s]) {
+        g += bf2f(a.dgamma[s][c]);
+        b += bf2f(a.dbeta[s][c]);
+      }
+      a.dgamma[s][c] = f2bf(g);
+      a.dbeta[s][c] = f2bf(b);
     }
-    if (a.accumulate[s]) {
-      g += bf2f(a.dgamma[s][c]);
-      b += bf2f(a.dbeta[s][c]);
-    }
-    a.dgamma[s][c] = f2bf(g);
-    a.dbeta[s][c] = f2bf(b);
   }
 }
 
@@ -189,9 +210,11 @@ extern "C" int mpv_vit_compose_bwd_finish(const void* dwc_wpT, const void* dbc, 
                                           int D, hipStream_t stream) {
   MPV_REQUIRE(dwc_wpT && dbc && bp && wf && dwf && dbp, MPV_E_ARG, "mpv_vit_compose_bwd_finish: null pointer");
   MPV_REQUIRE(D > 0, MPV_E_SHAPE, "mpv_vit_compose_bwd_finish: empty problem");
-  const unsigned g = (unsigned)((D + 63) / 64);
-  hipLaunchKernelGGL(compose_finish_kernel, dim3(g, g + 1), dim3(256), 0, stream, (const bf16*)dwc_wpT, (const bf16*)dbc, (const bf16*)bp,
-                     (const bf16*)wf, (bf16*)dwf, (bf16*)dbp, D);
+  MPV_REQUIRE(D % 8 == 0 && (((uintptr_t)dwc_wpT | (uintptr_t)bp | (uintptr_t)dwf) & 15) == 0, MPV_E_ALIGN,
+              "mpv_vit_compose_bwd_finish: D must be a multiple of 8 and the matrices 16-byte aligned");
+  const int nrank = (int)(((long long)D * (D / 8) + 255) / 256);
+  hipLaunchKernelGGL(compose_finish_kernel, dim3((unsigned)(nrank + (D + 63) / 64)), dim3(256), 0, stream, (const bf16*)dwc_wpT, (const bf16*)dbc,
+                     (const bf16*)bp, (const bf16*)wf, (bf16*)dwf, (bf16*)dbp, D, nrank);
   return mpv_check_launch("mpv_vit_compose_bwd_finish");
 }
 
@@ -216,14 +239,16 @@ extern "C" int mpv_layernorm_dparam_finish(const float* const* partials, const i
                   "mpv_layernorm_dparam_finish: bad entry %d", base + i);
       for (int j = 0; j < i; ++j)
         MPV_REQUIRE(a.dgamma[j] != (bf16*)dgamma[base + i], MPV_E_ARG, "mpv_layernorm_dparam_finish: two entries of one launch share a dgamma");
-      a.part[i] = partials[base + i];
+      a.part[i] = const_cast<float*>(partials[base + i]);
       a.nblk[i] = nblk[base + i];
       a.dgamma[i] = (bf16*)dgamma[base + i];
       a.dbeta[i] = (bf16*)dbeta[base + i];
       a.accumulate[i] = accumulate[base + i];
     }
     a.cols = (int)cols;
-    hipLaunchKernelGGL(ln_dparam_finish_kernel, dim3((unsigned)((cols + 31) / 32), (unsigned)m), dim3(256), 0, stream, a);
+    const unsigned gx = (unsigned)((cols + 63) / 64);
+    hipLaunchKernelGGL(ln_dparam_finish_kernel<false>, dim3(gx, LNF_SLICES, (unsigned)m), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(ln_dparam_finish_kernel<true>, dim3(gx, 1, (unsigned)m), dim3(256), 0, stream, a);
   }
   return mpv_check_launch("mpv_layernorm_dparam_finish");
 }

@@ -174,11 +174,11 @@ __device__ __forceinline__ T mpv_gelu_grad_poly(T w) {
     return mpv_fma_t(q, w, mpv_splat<T>(7.975339890e-01f));
   }
 }
-// GELU(x) = x~ * (1/2 + xc * P(xc^2)), xc = clamp(x), x~ = max(x, -6).  Left of the clamp the bracket is frozen at Phi~(-4) =
-// 3e-5 (not 0), so the multiplier is held at -6 there: the far negative tail returns >= -2e-4 where the true value is -0
-// (with the raw x it grew linearly: -3e-3 at x = -100; CLIP towers do produce such pre-activations).
-__device__ __forceinline__ float mpv_tail_t(float x) { return fmaxf(x, -6.0f); }
-__device__ __forceinline__ f32x2 mpv_tail_t(f32x2 x) { return f32x2{fmaxf(x[0], -6.0f), fmaxf(x[1], -6.0f)}; }
+// GELU(x) = x~ * (1/2 + xc * P(xc^2)), xc = clamp(x, -4, 4), x~ = max(x, -4).  Left of the clamp the bracket is frozen at
+// Phi~(-4) = 3e-5 +- 2e-5 (not 0), so the multiplier is frozen there too: the far negative tail returns >= -2.2e-4 where the
+// true value is -0 (with the raw x it grew linearly: -3e-3 at x = -100; CLIP towers do produce such pre-activations).
+__device__ __forceinline__ float mpv_tail_t(float x) { return fmaxf(x, -MPV_GELU_CLAMP); }
+__device__ __forceinline__ f32x2 mpv_tail_t(f32x2 x) { return f32x2{fmaxf(x[0], -MPV_GELU_CLAMP), fmaxf(x[1], -MPV_GELU_CLAMP)}; }
 template <int KIND, typename T>
 __device__ __forceinline__ T mpv_gelu_t(T x) {
   const T xc = mpv_clamp_t(x);

@@ -118,7 +118,7 @@ LN_DPARAM_DEFER = 2      # include/mpv.h: MPV_LN_DPARAM_DEFER
 
 
 class LnDparamBatch:
-    """dgamma / dbeta reductions of several LayerNorm backward calls in ONE launch (mpv_layernorm_dparam_finish).
+    """dgamma / dbeta reductions of several LayerNorm backward calls batched into one two-launch finish (mpv_layernorm_dparam_finish).
     Pass it as `defer=` to layernorm_bwd: the call then leaves its per-workgroup partials in a buffer of this batch (kept
     and reused across steps) instead of launching its own two reduce kernels; finish() folds every pending entry on the
     current stream.  Entries of one batch must target distinct parameters."""
