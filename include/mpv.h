@@ -127,6 +127,21 @@ int mpv_layernorm_bwd(const void* dy, const void* x, const void* gamma, const fl
                       int64_t ldy, int x_group, int x_stride, int x_offset, int y_group, int y_stride, int y_offset,
                       void* workspace, size_t workspace_bytes, mpv_stream_t stream);
 
+/* The decoder's residual stream in fp32 (models/modeling_distributed_gpt3.py:1038-1078: h + dropout(sublayer(LN(h)) + bias), twice
+ * per layer).  The reference adds in bf16; 48 such roundings over 24 layers are what separates a bf16 run from the fp32 function
+ * by 1.2e-2 in the logits (tools/parity_bisect.py), so here the sum lives in fp32:
+ *   h_out[hmap(r)] = h_in[hmap(r)] + add[amap(r)]   (fp32; skipped when add == NULL),   y[ymap(r)] = LN(h_out row) in bf16.
+ * h_in is fp32 [.,ldh], or bf16 when h_in_bf16 (the first LayerNorm behind the embedding); add is a sublayer output in bf16 with
+ * bias and dropout already applied by its GEMM.  mpv_ln_stream_bwd is mpv_layernorm_bwd (no parameter gradients: frozen
+ * decoder) with x read from the fp32 stream; dy / dres / dx / dx_drop stay bf16 and share x's row map. */
+int mpv_ln_stream_fwd(const void* h_in, int h_in_bf16, const void* add, float* h_out, const void* gamma, const void* beta, void* y,
+                      float* mean, float* rstd, int64_t rows, int64_t cols, int64_t ldh, int64_t lda, int64_t ldy, float eps,
+                      int h_group, int h_stride, int h_offset, int a_group, int a_stride, int a_offset, int y_group, int y_stride,
+                      int y_offset, mpv_stream_t stream);
+int mpv_ln_stream_bwd(const void* dy, const float* x, const void* gamma, const float* mean, const float* rstd, const void* dres,
+                      void* dx, void* dx_drop, float drop_p, uint64_t seed, uint64_t offset, int64_t rows, int64_t cols, int64_t ldx,
+                      int64_t ldy, int x_group, int x_stride, int x_offset, int y_group, int y_stride, int y_offset, mpv_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fused attention (scores never materialised), exact two-pass softmax in fp32, MFMA QK^T / PV.
  * Replaces: ViT Attention core (models/vision_transformer.py:179-204: q*scale rounded to bf16,

@@ -172,6 +172,30 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, rows, cols, *, dres=None, dx=None, d
     return dx
 
 
+def ln_stream_fwd(h_in, add, gamma, beta, eps, rows, cols, *, h_out=None, out=None, hmap=IDENT, amap=IDENT, ymap=IDENT, out_rows=None,
+                  h_rows=None):
+    if out is None:
+        out = torch.zeros((out_rows if out_rows is not None else rows, cols), dtype=BF)
+    hr = _rows(hmap, rows)
+    v = _rd(h_in, hr, cols, cols)                      # fp32 (or bf16 for the first LayerNorm) -> fp32
+    if add is not None:
+        v = v + _rd(add, _rows(amap, rows), cols, cols)
+        if h_out is None:
+            h_out = torch.zeros((h_rows if h_rows is not None else h_in.shape[0], cols), dtype=torch.float32)
+        _wr(h_out, hr, cols, v)
+    mu = v.mean(1)
+    rs = torch.rsqrt(((v - mu[:, None]) ** 2).mean(1) + eps)
+    _wr(out, _rows(ymap, rows), cols, (v - mu[:, None]) * rs[:, None] * gamma.float()[None, :] + beta.float()[None, :])
+    return out, (h_out if add is not None else None), mu, rs
+
+
+def ln_stream_bwd(dy, x, gamma, mean, rstd, rows, cols, *, dres=None, dx=None, dx_drop=None, dropout_p=0.0, seed=0, offset=0, xmap=IDENT,
+                  ymap=IDENT, dx_rows=None):
+    assert x.dtype == torch.float32
+    return layernorm_bwd(dy, x, gamma, mean, rstd, rows, cols, dres=dres, dx=dx, dx_drop=dx_drop, dropout_p=dropout_p, seed=seed, offset=offset,
+                         xmap=xmap, ymap=ymap, dx_rows=dx_rows)
+
+
 class AttnLayout:
     def __init__(self, q, k, v, o):
         self.q, self.k, self.v, self.o = q, k, v, o
@@ -463,7 +487,7 @@ def decode_step(self, tokens, query_embeds=None):
     return gemm(xf, lm.embedding.word_embeddings.weight, B, V, H)
 
 
-NAMES = ["LnDparamBatch", "accum_f32", "f32_to_bf16", "copy_segments", "vit_compose_bwd_finish", "caption_targets", "gather_rows_ld", "logprob_topk", "add", "gather_rows", "scatter_rows", "l2norm_fwd", "l2norm_bwd", "soft_target_ce", "gemm", "layernorm_fwd", "layernorm_bwd", "AttnLayout", "attn_fwd", "attn_bwd", "temporal_attn_fwd", "temporal_attn_bwd",
+NAMES = ["ln_stream_fwd", "ln_stream_bwd", "LnDparamBatch", "accum_f32", "f32_to_bf16", "copy_segments", "vit_compose_bwd_finish", "caption_targets", "gather_rows_ld", "logprob_topk", "add", "gather_rows", "scatter_rows", "l2norm_fwd", "l2norm_bwd", "soft_target_ce", "gemm", "layernorm_fwd", "layernorm_bwd", "AttnLayout", "attn_fwd", "attn_bwd", "temporal_attn_fwd", "temporal_attn_bwd",
          "im2col_patches", "vit_embed_assemble_fwd", "vit_embed_assemble_bwd", "vit_cls_fix_fwd", "vit_cls_merge_bwd_inplace",
          "copy_rows", "colsum", "gpt_embed_fwd", "gpt_embed_bwd", "cross_entropy"]
 

@@ -695,3 +695,42 @@ def test_gelu_tails(dev):
             ref = F.gelu(z, approximate=approx)
             assert ((out - ref).abs() <= 4e-3 + 8e-3 * ref.abs()).all().item(), (approx, hint, (out - ref).abs().max().item())
             assert out[:, z[0] < -8].abs().max().item() <= 2.5e-4, "negative tail must stay at ~0"
+
+
+@pytest.mark.parametrize("rows,cols", [(5120, 2048), (300, 2560), (77, 768)])
+def test_ln_stream_fwd_bwd(dev, rows, cols):
+    """The decoder's fp32 residual stream (mpv_ln_stream_fwd / _bwd): h' = h + a in fp32, y = LN(h'); backward with x in fp32;
+    with and without the add, bf16 and fp32 stream input, and through row maps (the loss window of the top layer)."""
+    from youku_mplug_amd import ops
+    g = torch.Generator().manual_seed(rows + cols)
+    h32 = (torch.randn(rows, cols, generator=g) * 3).to(dev)
+    a = rn(rows, cols, dev=dev, seed=5)
+    gam, bet = rn(cols, dev=dev, seed=6), rn(cols, dev=dev, seed=7)
+    eps = 1e-5
+    for h_in in (h32, h32.to(torch.bfloat16)):
+        for add in (a, None):
+            y, h_out, m, r = ops.ln_stream_fwd(h_in, add, gam, bet, eps, rows, cols)
+            ref_h = h_in.float() + (add.float() if add is not None else 0.0)
+            if add is not None:
+                assert torch.equal(h_out, ref_h), "the stream sum is exact fp32"
+            else:
+                assert h_out is None
+            close(y, F.layer_norm(ref_h, (cols,), gam.float(), bet.float(), eps), 1e-2, "LN(h + a)")
+            close(m, ref_h.mean(1), 1e-4, "mean")
+    # row maps: window rows of the stream (group 3 of every 10 rows, offset 4), compact add / y
+    grp, stride, off = 3, 10, 4
+    nb = rows // stride
+    n = nb * grp
+    win = (torch.arange(n, device=dev) // grp) * stride + torch.arange(n, device=dev) % grp + off
+    h_out = torch.zeros_like(h32)
+    y, h2, m, r = ops.ln_stream_fwd(h32, a, gam, bet, eps, n, cols, hmap=(grp, stride, off), h_out=h_out)
+    assert torch.equal(h2[win], h32[win] + a[:n].float()) and h2.abs().sum() == h2[win].abs().sum()
+    close(y[:n], F.layer_norm(h2[win], (cols,), gam.float(), bet.float(), eps), 1e-2, "mapped LN")
+    # backward: x in fp32 against autograd, plus the residual gradient and the row maps
+    dy, dres = rn(n, cols, dev=dev, seed=8), rn(rows, cols, dev=dev, seed=9)
+    x = h2[win].clone().requires_grad_(True)
+    F.layer_norm(x, (cols,), gam.float(), bet.float(), eps).backward(dy.float())
+    dx = torch.zeros(rows, cols, dtype=torch.bfloat16, device=dev)
+    ops.ln_stream_bwd(dy, h2, gam, m, r, n, cols, dres=dres, dx=dx, xmap=(grp, stride, off))
+    close(dx[win], x.grad + dres[win].float(), 1e-2, "dx through the fp32 stream")
+    assert dx.float().abs().sum() == dx[win].float().abs().sum()

@@ -54,6 +54,9 @@ _SIGS = {
     "mpv_layernorm_bwd_workspace_size": (c_size_t, [c_int64]),
     "mpv_layernorm_bwd": (c_int, [c_void_p] * 8 + [c_float, c_uint64, c_uint64, c_void_p, c_void_p, c_int] +
                           [c_int64] * 4 + _RM + _RM + [c_void_p, c_size_t, c_void_p]),
+    "mpv_ln_stream_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int64] * 5 +
+                          [c_float] + _RM + _RM + _RM + [c_void_p]),
+    "mpv_ln_stream_bwd": (c_int, [c_void_p] * 8 + [c_float, c_uint64, c_uint64] + [c_int64] * 4 + _RM + _RM + [c_void_p]),
     "mpv_attn_fwd": (c_int, [C.POINTER(AttnDesc), c_void_p]),
     "mpv_attn_bwd": (c_int, [C.POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mpv_temporal_attn_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int64, c_int64, c_int, c_int, c_int,

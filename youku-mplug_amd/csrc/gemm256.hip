@@ -66,7 +66,7 @@ __device__ __forceinline__ bf16x8 lds_read_tr8(const char* p) {
 }
 
 
-enum EpKind { EP_PLAIN, EP_ERF_PRE, EP_TANH_PRE, EP_BWD_ERF, EP_BWD_TANH, EP_RES, EP_DROP_RES, EP_GENERIC };
+enum EpKind { EP_PLAIN, EP_ERF_PRE, EP_TANH_PRE, EP_BWD_ERF, EP_BWD_TANH, EP_RES, EP_DROP_RES, EP_DROP, EP_GENERIC };
 
 template <int ACT>
 __device__ __forceinline__ f32x8 apply_act(f32x8 v) {
@@ -163,6 +163,9 @@ __device__ __forceinline__ void finish_rows(const GemmArgs& p, const EpExt<KIND,
         const uint64_t base = p.drop_offset + (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
         const f32x8 v = mpv_dropout_vec<f32x8, 8>(cvt8(zb), p.seed, base, p.drop_thr, p.drop_scale);
         *(bf16x8*)cp = cvt8(v + cvt8(ex));
+      } else if constexpr (KIND == EP_DROP) {       // dropout(acc + bias): the decoder's sublayer outputs (the residual add is the next LayerNorm's, in fp32)
+        const uint64_t base = p.drop_offset + (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
+        *(bf16x8*)cp = cvt8(mpv_dropout_vec<f32x8, 8>(cvt8(zb), p.seed, base, p.drop_thr, p.drop_scale));
       } else {
         f32x8 v = cvt8(zb);
         if (p.tap_out && m % p.tap_group == 0) *(bf16x8*)(p.tap_out + (long long)(m / p.tap_group) * p.N + n) = zb;
@@ -596,6 +599,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   else if (cfg == 2 && p.act_bwd == MPV_ACT_GELU_TANH) epilogue(IC<EP_BWD_TANH>{});
   else if (cfg == 8) epilogue(IC<EP_RES>{});
   else if (cfg == (4 | 8)) epilogue(IC<EP_DROP_RES>{});
+  else if (cfg == 4) epilogue(IC<EP_DROP>{});
   else epilogue(IC<EP_GENERIC>{});
 }
 

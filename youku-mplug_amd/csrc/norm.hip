@@ -276,7 +276,8 @@ __global__ __launch_bounds__(256) void ln_fwd8_kernel(const LnFwdArgs p) {
 // No parameter gradients (the frozen decoder's LayerNorms, one row per wave at 5120 x 2048): the residual gradient is read after
 // the reductions, interleaved with the stores -- measured 19.9 us against 23.0 us for the single-round-trip form below on that
 // shape (5.3 TB/s: reads and writes alternating suit the HBM better than a read burst followed by a write burst).
-template <int MAXC>
+// XF32: x is the decoder's fp32 residual stream (mpv_ln_stream_bwd); dy / dres / dx stay bf16.
+template <int MAXC, bool XF32 = false>
 __global__ __launch_bounds__(256) void ln_bwd8_plain_kernel(const LnBwdArgs p) {
   constexpr bool DPARAM = false;
   __shared__ float red[DPARAM ? 2 * MAXC * 512 : 1];
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(256) void ln_bwd8_plain_kernel(const LnBwdArgs p) {
   for (long long r = (long long)blockIdx.x * 4 + wave; r < p.rows; r += (long long)gridDim.x * 4) {
     const long long xrow = map_row(p.xmap, r);
     const bf16* xr = p.x + xrow * p.ldx;
+    const float* xr32 = (const float*)p.x + xrow * p.ldx;
     const bf16* dyr = p.dy + map_row(p.ymap, r) * p.ldy;
     const float mu = p.mean[r], rs = p.rstd[r];
     f32x8 xh[MAXC], g[MAXC];
@@ -302,7 +304,9 @@ __global__ __launch_bounds__(256) void ln_bwd8_plain_kernel(const LnBwdArgs p) {
     for (int i = 0; i < MAXC; ++i) {
       const int c = lane + 64 * i;
       if (c < nchunk) {
-        const f32x8 xv = cvt8(*(const bf16x8*)(xr + c * 8));
+        f32x8 xv;
+        if constexpr (XF32) xv = *(const f32x8*)(xr32 + c * 8);
+        else xv = cvt8(*(const bf16x8*)(xr + c * 8));
         const f32x8 dv = cvt8(*(const bf16x8*)(dyr + c * 8));
         const f32x8 gm = cvt8(*(const bf16x8*)(p.gamma + c * 8));
 #pragma unroll
@@ -531,6 +535,99 @@ __global__ __launch_bounds__(256) void ln_dparam_reduce(const float* __restrict_
   }
 }
 
+// ---- the decoder's residual stream in fp32 -----------------------------------------------------------------------------
+// h' = h + a (a = a sublayer's bf16 output: bias and dropout already applied by its GEMM), y = LN(h') in ONE pass: the add that
+// the GEMM's residual epilogue used to do in bf16 happens here in fp32, and the sum is kept in fp32 for the next sublayer.
+// 48 bf16 roundings of the 24-layer stream were what put the logits 1.2e-2 from the fp32 function (tools/parity_bisect.py:
+// every sublayer in bf16 but this stream in fp32 -> 0.87e-2; the reference's own bf16 run: 1.25e-2).
+// h_in is fp32, or bf16 for the first LayerNorm behind the embedding (INBF); a == NULL: plain LN of h_in, no h_out.
+struct LnStreamArgs {
+  const void* h_in;
+  const bf16* add;
+  float* h_out;
+  const bf16 *gamma, *beta;
+  bf16* y;
+  float *mean, *rstd;
+  long long rows;
+  int cols;
+  long long ldh, lda, ldy;
+  float eps;
+  RowMap hmap, amap, ymap;
+};
+template <int MAXC, bool INBF>
+__global__ __launch_bounds__(256) void ln_stream_fwd_kernel(const LnStreamArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nchunk = p.cols >> 3;
+  const float inv_n = 1.0f / (float)p.cols;
+  bf16x8 gmb[MAXC], btb[MAXC];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    gmb[i] = c < nchunk ? *(const bf16x8*)(p.gamma + c * 8) : bf16x8{};
+    btb[i] = c < nchunk ? *(const bf16x8*)(p.beta + c * 8) : bf16x8{};
+  }
+  for (long long r = (long long)blockIdx.x * 4 + wave; r < p.rows; r += (long long)gridDim.x * 4) {
+    const long long hrow = map_row(p.hmap, r);
+    f32x8 v[MAXC];
+    bf16x8 av[MAXC];
+    const bf16* ar = p.add ? p.add + map_row(p.amap, r) * p.lda : nullptr;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {      // everything of the row requested before anything is reduced
+      const int c = lane + 64 * i;
+      const bool ok = c < nchunk;
+      if constexpr (INBF) v[i] = ok ? cvt8(*(const bf16x8*)((const bf16*)p.h_in + hrow * p.ldh + c * 8)) : f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      else v[i] = ok ? *(const f32x8*)((const float*)p.h_in + hrow * p.ldh + c * 8) : f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      av[i] = ok && ar ? *(const bf16x8*)(ar + c * 8) : bf16x8{};
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      if (ar) v[i] += cvt8(av[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[i][e];
+    }
+    if (ar) {
+      float* hr = p.h_out + hrow * p.ldh;
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i)
+        if (lane + 64 * i < nchunk) *(f32x8*)(hr + (lane + 64 * i) * 8) = v[i];
+    }
+    const float mu = wave_sum(s) * inv_n;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+      if (lane + 64 * i < nchunk)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = v[i][e] - mu;
+          s2 += d * d;
+        }
+    const float rs = rsqrtf(wave_sum(s2) * inv_n + p.eps);
+    bf16* yr = p.y + map_row(p.ymap, r) * p.ldy;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        const f32x8 g = cvt8(gmb[i]), b = cvt8(btb[i]);
+        f32x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mu) * rs * g[e] + b[e];
+        *(bf16x8*)(yr + c * 8) = cvt8(o);
+      }
+    }
+    if (lane == 0) {
+      if (p.mean) p.mean[r] = mu;
+      if (p.rstd) p.rstd[r] = rs;
+    }
+  }
+}
+template <int MAXC>
+void launch_stream_fwd(const LnStreamArgs& a, bool inbf, int grid, hipStream_t s) {
+  if (inbf) hipLaunchKernelGGL((ln_stream_fwd_kernel<MAXC, true>), dim3(grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((ln_stream_fwd_kernel<MAXC, false>), dim3(grid), dim3(256), 0, s, a);
+}
+
 constexpr int LN_BWD_MAX_BLOCKS = 1024;   // measured at 50432 x 768 with dgamma/dbeta: 2048 blocks 82 us, 1024 blocks 73 us, 512 blocks 95 us
 constexpr int LN_L1_ROWS = (LN_BWD_MAX_BLOCKS + 63) / 64;
 
@@ -665,4 +762,62 @@ extern "C" int mpv_layernorm_bwd(const void* dy, const void* x, const void* gamm
     }
   }
   return mpv_check_launch("mpv_layernorm_bwd");
+}
+
+extern "C" int mpv_ln_stream_fwd(const void* h_in, int h_in_bf16, const void* add, float* h_out, const void* gamma, const void* beta, void* y,
+                                 float* mean, float* rstd, int64_t rows, int64_t cols, int64_t ldh, int64_t lda, int64_t ldy, float eps,
+                                 int h_group, int h_stride, int h_offset, int a_group, int a_stride, int a_offset, int y_group, int y_stride,
+                                 int y_offset, hipStream_t stream) {
+  MPV_REQUIRE(h_in && gamma && beta && y, MPV_E_ARG, "mpv_ln_stream_fwd: null pointer");
+  MPV_REQUIRE((add == nullptr) == (h_out == nullptr), MPV_E_ARG, "mpv_ln_stream_fwd: add and h_out come together");
+  MPV_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= 4096 && ldh % 8 == 0 && lda % 8 == 0 && ldy % 8 == 0, MPV_E_SHAPE,
+              "mpv_ln_stream_fwd: cols=%lld and the leading dims must be multiples of 8, cols <= 4096", (long long)cols);
+  MPV_REQUIRE((((uintptr_t)h_in | (uintptr_t)h_out) & 31) == 0 || h_in_bf16, MPV_E_ALIGN, "mpv_ln_stream_fwd: the fp32 stream must be 32-byte aligned");
+  if (rows == 0) return MPV_OK;
+  LnStreamArgs a = {h_in, (const bf16*)add, h_out, (const bf16*)gamma, (const bf16*)beta, (bf16*)y, mean, rstd, rows, (int)cols, ldh, lda, ldy, eps,
+                    RowMap{h_group, h_stride, h_offset}, RowMap{a_group, a_stride, a_offset}, RowMap{y_group, y_stride, y_offset}};
+  const int grid = (int)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);
+  const int n8 = (int)((cols / 8 + 63) / 64);
+  if (n8 <= 2) launch_stream_fwd<2>(a, h_in_bf16 != 0, grid, stream);
+  else if (n8 <= 4) launch_stream_fwd<4>(a, h_in_bf16 != 0, grid, stream);
+  else if (n8 <= 5) launch_stream_fwd<5>(a, h_in_bf16 != 0, grid, stream);
+  else launch_stream_fwd<8>(a, h_in_bf16 != 0, grid, stream);
+  return mpv_check_launch("mpv_ln_stream_fwd");
+}
+
+extern "C" int mpv_ln_stream_bwd(const void* dy, const float* x, const void* gamma, const float* mean, const float* rstd, const void* dres,
+                                 void* dx, void* dx_drop, float drop_p, uint64_t seed, uint64_t offset, int64_t rows, int64_t cols,
+                                 int64_t ldx, int64_t ldy, int x_group, int x_stride, int x_offset, int y_group, int y_stride, int y_offset,
+                                 hipStream_t stream) {
+  MPV_REQUIRE(dy && x && gamma && mean && rstd && dx, MPV_E_ARG, "mpv_ln_stream_bwd: null pointer");
+  MPV_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= 4096 && ldx % 8 == 0 && ldy % 8 == 0, MPV_E_SHAPE,
+              "mpv_ln_stream_bwd: cols=%lld and the leading dims must be multiples of 8, cols <= 4096", (long long)cols);
+  MPV_REQUIRE(drop_p >= 0.f && drop_p < 1.f, MPV_E_ARG, "mpv_ln_stream_bwd: bad dropout_p");
+  if (rows == 0) return MPV_OK;
+  LnBwdArgs a = {};
+  a.dy = (const bf16*)dy;
+  a.x = (const bf16*)x;      // read as fp32 by the XF32 instances
+  a.gamma = (const bf16*)gamma;
+  a.mean = mean;
+  a.rstd = rstd;
+  a.dres = (const bf16*)dres;
+  a.dx = (bf16*)dx;
+  a.dx_drop = (bf16*)dx_drop;
+  a.drop_thr = drop_p > 0.f ? mpv_drop_threshold(drop_p) : 0;
+  a.drop_scale = 1.0f / (1.0f - drop_p);
+  a.seed = seed;
+  a.offset = offset;
+  a.rows = rows;
+  a.cols = (int)cols;
+  a.ldx = ldx;
+  a.ldy = ldy;
+  a.xmap = RowMap{x_group, x_stride, x_offset};
+  a.ymap = RowMap{y_group, y_stride, y_offset};
+  const int grid = (int)((rows + 3) / 4 < LN_BWD_MAX_BLOCKS ? (rows + 3) / 4 : LN_BWD_MAX_BLOCKS);
+  const int n8 = (int)((cols / 8 + 63) / 64);
+  if (n8 <= 2) hipLaunchKernelGGL((ln_bwd8_plain_kernel<2, true>), dim3(grid), dim3(256), 0, stream, a);
+  else if (n8 <= 4) hipLaunchKernelGGL((ln_bwd8_plain_kernel<4, true>), dim3(grid), dim3(256), 0, stream, a);
+  else if (n8 <= 5) hipLaunchKernelGGL((ln_bwd8_plain_kernel<5, true>), dim3(grid), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((ln_bwd8_plain_kernel<8, true>), dim3(grid), dim3(256), 0, stream, a);
+  return mpv_check_launch("mpv_ln_stream_bwd");
 }

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import json
 import math
+import os
 from typing import Optional
 
 import torch
@@ -144,6 +145,13 @@ class GPT3Model(nn.Module):
 
 _SITE_EMBED, _SITE_ATTN, _SITE_DROP1, _SITE_DROP2 = 0, 1, 2, 3
 
+# The residual stream of the decoder is kept in fp32 (ops.ln_stream_fwd: the add of a sublayer's output happens inside the
+# LayerNorm that follows it, in fp32, instead of in the GEMM's bf16 residual epilogue).  The reference adds in bf16
+# (models/modeling_distributed_gpt3.py:1059-1078); 48 such roundings are what put a 24-layer bf16 run 1.2e-2 from the fp32
+# function in the logits (tools/parity_bisect.py: 0.87e-2 with the fp32 stream).  MPV_DECODER_STREAM=bf16 (measurement knob)
+# restores the bf16 stream with the residual adds in the GEMM epilogues.
+FP32_STREAM = os.environ.get("MPV_DECODER_STREAM", "fp32") != "bf16"
+
 
 def _offset(layer: int, site: int) -> int:
     return (layer * 4 + site) << 36
@@ -206,6 +214,89 @@ class DistributedGPT3(nn.Module):
                 window = (w0, wl)
         nl = len(lm.encoder.layers)
         layers = []
+        if FP32_STREAM:
+            # stream = the residual stream (bf16 straight out of the embedding, fp32 from the first add on); `pending` = the last
+            # sublayer output (bias + dropout applied by its GEMM) that the next LayerNorm adds into the stream in fp32
+            stream, pending, pmap = h, None, ops.IDENT
+            smap = ops.IDENT               # rows of `stream` the current layer works on (the loss window in the top layer)
+            for li, layer in enumerate(lm.encoder.layers):
+                ln = li + 1
+                att, mlp = layer.self_attention, layer.mlp
+                l1 = layer.input_layernorm
+                x1, nxt, m1, r1 = ops.ln_stream_fwd(stream, pending, l1.weight, l1.bias, l1.eps, R, H, amap=pmap)
+                stream = nxt if nxt is not None else stream
+                h_in = stream                                                   # x of LayerNorm 1 (for its backward)
+                qkv = ops.gemm(x1, att.query_key_value.weight, R, 3 * H, H, bias=att.query_key_value.bias)
+                ctx = torch.empty((R, H), dtype=torch.bfloat16, device=h.device)
+                lse = ops.attn_fwd(qkv, qkv[:, hn:], qkv[:, 2 * hn:], ctx, lay, B, np_, S, S, hn, causal=True, scale=scale,
+                                   dropout_p=p_a, seed=seed, offset=_offset(ln, _SITE_ATTN))
+                top = window is not None and li == nl - 1
+                # Top layer under a loss window: nothing downstream reads its hidden states outside the window (they feed only the
+                # LM head, which runs on the window), and everything after the attention is row-wise -- the projection, LN2, the MLP
+                # and their residual adds run on the B * wl window rows (a row map on the [B*S, H] stream; the sublayer outputs are
+                # compact).  K/V of all rows are still needed by the window's queries, so LN1, qkv and the attention stay whole.
+                tm = (window[1], S, window[0]) if top else ops.IDENT
+                Rl = B * window[1] if top else R
+                a1 = ops.gemm(ctx, att.dense.weight, Rl, H, H, bias=att.dense.bias, dropout_p=p_h, seed=seed,
+                              offset=_offset(ln, _SITE_DROP1), amap=tm)                            # compact [Rl, H]
+                l2 = layer.post_attention_layernorm
+                x2, h1, m2, r2 = ops.ln_stream_fwd(stream, a1, l2.weight, l2.bias, l2.eps, Rl, H, hmap=tm, h_rows=R)
+                F4 = mlp.dense_h_to_4h.out_features
+                z = torch.empty((Rl, F4), dtype=torch.bfloat16, device=h.device)
+                g = ops.gemm(x2, mlp.dense_h_to_4h.weight, Rl, F4, H, bias=mlp.dense_h_to_4h.bias, act=ACT_GELU_TANH, preact_out=z)
+                pending = ops.gemm(g, mlp.dense_4h_to_h.weight, Rl, H, F4, bias=mlp.dense_4h_to_h.bias, dropout_p=p_h, seed=seed,
+                                   offset=_offset(ln, _SITE_DROP2))                                # compact [Rl, H]
+                ent = dict(h=h_in, s1=(m1, r1), qkv=qkv, ctx=ctx, lse=lse, h1=h1, s2=(m2, r2), z=z)
+                if top:
+                    ent["rows"] = tm
+                layers.append(ent)
+                stream, smap = h1, tm
+            fl = lm.encoder.final_layernorm
+            Rf = B * window[1] if window is not None else R
+            xf, h, mf, rf = ops.ln_stream_fwd(stream, pending, fl.weight, fl.bias, fl.eps, Rf, H, hmap=smap, h_rows=R)
+        else:
+            h, xf, mf, rf = self._layers_bf16_stream(h, lay, scale, window, layers, seed, p_h, p_a, B, S, R, H, np_, hn)
+        if hidden_only:     # only last_hidden_state is consumed (models/distributed_gpt3.py:958, 583-584, 1149-1150)
+            tape.update(B=B, Q=Q, L=L, S=S, layers=layers, h_last=h, sf=(mf, rf), dlogits=None, lm_window=None, lay=lay, scale=scale,
+                        seed=seed, p_h=p_h, p_a=p_a)
+            return dict(last_hidden_state=xf.view(B, S, H))
+        # masked mean of per-token CE over positions 0..S-2 (:1615-1617)
+        if window is not None and window_targets is not None:
+            Rw = B * window[1]
+            logits = ops.gemm(xf, lm.embedding.word_embeddings.weight, Rw, V, H)       # xf is already the window's rows
+            _, loss = ops.cross_entropy(logits, window_targets[0], window_targets[1], Rw, V, dlogits=logits)
+            tape.update(B=B, Q=Q, L=L, S=S, layers=layers, h_last=h, sf=(mf, rf), dlogits=logits, lm_window=window, lay=lay, scale=scale,
+                        seed=seed, p_h=p_h, p_a=p_a)
+            return dict(loss=loss, losses=None, last_hidden_state=None)
+        lmf = loss_mask.to(torch.float32)
+        denom = lmf.sum()
+        w = torch.zeros((B, S), dtype=torch.float32, device=h.device)
+        w[:, :S - 1] = lmf / denom
+        if window is not None:
+            w0, wl = window
+            Rw = B * wl
+            logits = ops.gemm(xf, lm.embedding.word_embeddings.weight, Rw, V, H)       # xf is already the window's rows
+            losses_w, loss = ops.cross_entropy(logits, labels[:, w0:w0 + wl].contiguous().view(-1),
+                                               w[:, w0:w0 + wl].contiguous().view(-1), Rw, V, dlogits=logits)
+            losses = torch.zeros((B, S), dtype=torch.float32, device=h.device)
+            losses[:, w0:w0 + wl] = losses_w.view(B, wl)
+            keep_logits = None
+        else:
+            logits = ops.gemm(xf, lm.embedding.word_embeddings.weight, R, V, H)          # tied LM head (:1348-1350)
+            keep_logits = logits.clone() if want_logits else None
+            losses, loss = ops.cross_entropy(logits, labels.contiguous().view(-1), w.view(-1), R, V, dlogits=logits)
+        tape.update(B=B, Q=Q, L=L, S=S, layers=layers, h_last=h, sf=(mf, rf), dlogits=logits, lm_window=window, lay=lay, scale=scale,
+                    seed=seed, p_h=p_h, p_a=p_a)
+        # under a loss window the top layer and the final LayerNorm exist on the window rows only: no full last_hidden_state
+        out = dict(loss=loss, losses=losses.view(B, S)[:, :S - 1], last_hidden_state=xf.view(B, S, H) if window is None else None)
+        if want_logits:
+            out["logits"] = keep_logits.view(B, S, V)
+        return out
+
+    def _layers_bf16_stream(self, h, lay, scale, window, layers, seed, p_h, p_a, B, S, R, H, np_, hn):
+        """The layer stack with the reference's bf16 residual stream (residual adds in the GEMM epilogues): MPV_DECODER_STREAM=bf16."""
+        lm = self.dist_model.language_model
+        nl = len(lm.encoder.layers)
         for li, layer in enumerate(lm.encoder.layers):
             ln = li + 1
             att, mlp = layer.self_attention, layer.mlp
@@ -253,42 +344,7 @@ class DistributedGPT3(nn.Module):
             xf, mf, rf = ops.layernorm_fwd(h, fl.weight, fl.bias, fl.eps, B * window[1], H, xmap=(window[1], S, window[0]))
         else:
             xf, mf, rf = ops.layernorm_fwd(h, fl.weight, fl.bias, fl.eps, R, H)
-        if hidden_only:     # only last_hidden_state is consumed (models/distributed_gpt3.py:958, 583-584, 1149-1150)
-            tape.update(B=B, Q=Q, L=L, S=S, layers=layers, h_last=h, sf=(mf, rf), dlogits=None, lm_window=None, lay=lay, scale=scale,
-                        seed=seed, p_h=p_h, p_a=p_a)
-            return dict(last_hidden_state=xf.view(B, S, H))
-        # masked mean of per-token CE over positions 0..S-2 (:1615-1617)
-        if window is not None and window_targets is not None:
-            Rw = B * window[1]
-            logits = ops.gemm(xf, lm.embedding.word_embeddings.weight, Rw, V, H)       # xf is already the window's rows
-            _, loss = ops.cross_entropy(logits, window_targets[0], window_targets[1], Rw, V, dlogits=logits)
-            tape.update(B=B, Q=Q, L=L, S=S, layers=layers, h_last=h, sf=(mf, rf), dlogits=logits, lm_window=window, lay=lay, scale=scale,
-                        seed=seed, p_h=p_h, p_a=p_a)
-            return dict(loss=loss, losses=None, last_hidden_state=None)
-        lmf = loss_mask.to(torch.float32)
-        denom = lmf.sum()
-        w = torch.zeros((B, S), dtype=torch.float32, device=h.device)
-        w[:, :S - 1] = lmf / denom
-        if window is not None:
-            w0, wl = window
-            Rw = B * wl
-            logits = ops.gemm(xf, lm.embedding.word_embeddings.weight, Rw, V, H)       # xf is already the window's rows
-            losses_w, loss = ops.cross_entropy(logits, labels[:, w0:w0 + wl].contiguous().view(-1),
-                                               w[:, w0:w0 + wl].contiguous().view(-1), Rw, V, dlogits=logits)
-            losses = torch.zeros((B, S), dtype=torch.float32, device=h.device)
-            losses[:, w0:w0 + wl] = losses_w.view(B, wl)
-            keep_logits = None
-        else:
-            logits = ops.gemm(xf, lm.embedding.word_embeddings.weight, R, V, H)          # tied LM head (:1348-1350)
-            keep_logits = logits.clone() if want_logits else None
-            losses, loss = ops.cross_entropy(logits, labels.contiguous().view(-1), w.view(-1), R, V, dlogits=logits)
-        tape.update(B=B, Q=Q, L=L, S=S, layers=layers, h_last=h, sf=(mf, rf), dlogits=logits, lm_window=window, lay=lay, scale=scale,
-                    seed=seed, p_h=p_h, p_a=p_a)
-        # under a loss window the top layer and the final LayerNorm exist on the window rows only: no full last_hidden_state
-        out = dict(loss=loss, losses=losses.view(B, S)[:, :S - 1], last_hidden_state=xf.view(B, S, H) if window is None else None)
-        if want_logits:
-            out["logits"] = keep_logits.view(B, S, V)
-        return out
+        return h, xf, mf, rf
 
     def _window_zero_pair(self, R, H, rows, device):
         key = (R, H, tuple(rows), str(device), torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0)
@@ -312,6 +368,14 @@ class DistributedGPT3(nn.Module):
             ent = (weight._version, weight.data_ptr(), weight.detach().t().contiguous())
             cache[key] = ent
         return ops.gemm(dy, ent[2], R, n_in, n_out, **kw)
+
+    @staticmethod
+    def _ln_bwd(dy, x, gamma, mean, rstd, rows, cols, **kw):
+        """LayerNorm backward of the frozen decoder: x is the fp32 residual stream (ops.ln_stream_bwd), or bf16 -- the embedding
+        output in front of layer 0, and everything under MPV_DECODER_STREAM=bf16."""
+        if x.dtype == torch.float32:
+            return ops.ln_stream_bwd(dy, x, gamma, mean, rstd, rows, cols, **kw)
+        return ops.layernorm_bwd(dy, x, gamma, mean, rstd, rows, cols, **kw)
 
     def backward_lm(self, tape: dict, grad_loss: Optional[torch.Tensor] = None, d_last_hidden: Optional[torch.Tensor] = None):
         """-> d(query_features) [B*Q, H] (dgrad only: the decoder is frozen).  The seed is the loss (grad_loss scales the
@@ -344,10 +408,10 @@ class DistributedGPT3(nn.Module):
         dh_m = torch.empty((R, H), dtype=torch.bfloat16, device=dxf.device) if drop else None
         if tm is not None:      # window rows of the [B*S, H] stream (the other rows of dh / dh_m are never read)
             dh = torch.empty((R, H), dtype=torch.bfloat16, device=dxf.device)
-            ops.layernorm_bwd(dxf, tape["h_last"], fl.weight, *tape["sf"], B * tm[0], H, dx=dh, dx_drop=dh_m, dropout_p=p_h, seed=seed,
+            self._ln_bwd(dxf, tape["h_last"], fl.weight, *tape["sf"], B * tm[0], H, dx=dh, dx_drop=dh_m, dropout_p=p_h, seed=seed,
                               offset=_offset(nl, _SITE_DROP2), xmap=tm)
         else:
-            dh = ops.layernorm_bwd(dxf, tape["h_last"], fl.weight, *tape["sf"], R, H, dx_drop=dh_m, dropout_p=p_h, seed=seed,
+            dh = self._ln_bwd(dxf, tape["h_last"], fl.weight, *tape["sf"], R, H, dx_drop=dh_m, dropout_p=p_h, seed=seed,
                                    offset=_offset(nl, _SITE_DROP2))
         for li in range(nl - 1, -1, -1):
             layer, s = lm.encoder.layers[li], tape["layers"][li]
@@ -366,7 +430,7 @@ class DistributedGPT3(nn.Module):
                 # are ever written), instead of two activation-sized clears per step
                 dh1, dctx = self._window_zero_pair(R, H, rm, dh.device)
                 dh1_m = torch.empty((R, H), dtype=torch.bfloat16, device=dh.device) if drop else None
-                ops.layernorm_bwd(dx2, s["h1"], layer.post_attention_layernorm.weight, *s["s2"], Rw, H, dres=dh, dx=dh1, dx_drop=dh1_m,
+                self._ln_bwd(dx2, s["h1"], layer.post_attention_layernorm.weight, *s["s2"], Rw, H, dres=dh, dx=dh1, dx_drop=dh1_m,
                                   dropout_p=p_h, seed=seed, offset=_offset(ln, _SITE_DROP1), xmap=rm)
                 da = dh1_m if drop else dh1
                 self._dgrad(da, att.dense.weight, Rw, H, H, amap=rm, cmap=rm, out=dctx)
@@ -374,7 +438,7 @@ class DistributedGPT3(nn.Module):
                 dz = self._dgrad(do, mlp.dense_4h_to_h.weight, R, F4, H, act_bwd_z=s["z"], act_bwd=ACT_GELU_TANH)
                 dx2 = self._dgrad(dz, mlp.dense_h_to_4h.weight, R, H, F4)
                 dh1_m = torch.empty((R, H), dtype=torch.bfloat16, device=dh.device) if drop else None
-                dh1 = ops.layernorm_bwd(dx2, s["h1"], layer.post_attention_layernorm.weight, *s["s2"], R, H, dres=dh, dx_drop=dh1_m,
+                dh1 = self._ln_bwd(dx2, s["h1"], layer.post_attention_layernorm.weight, *s["s2"], R, H, dres=dh, dx_drop=dh1_m,
                                         dropout_p=p_h, seed=seed, offset=_offset(ln, _SITE_DROP1))
                 da = dh1_m if drop else dh1
                 dctx = self._dgrad(da, att.dense.weight, R, H, H)
@@ -386,7 +450,7 @@ class DistributedGPT3(nn.Module):
             prev_off = _offset(li, _SITE_DROP2) if li > 0 else 0
             want_mask = drop and li > 0
             dh_m = torch.empty((R, H), dtype=torch.bfloat16, device=dh.device) if want_mask else None
-            dh = ops.layernorm_bwd(dx1, s["h"], layer.input_layernorm.weight, *s["s1"], R, H, dres=dh1, dx_drop=dh_m,
+            dh = self._ln_bwd(dx1, s["h"], layer.input_layernorm.weight, *s["s1"], R, H, dres=dh1, dx_drop=dh_m,
                                    dropout_p=p_h if want_mask else 0.0, seed=seed, offset=prev_off)
             tape["layers"][li] = None
         if Q == 0:

@@ -183,6 +183,37 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, rows: int, cols: int, *, dres=None, 
     return dx
 
 
+def ln_stream_fwd(h_in, add, gamma, beta, eps: float, rows: int, cols: int, *, h_out=None, out=None, hmap: RowMap = IDENT,
+                  amap: RowMap = IDENT, ymap: RowMap = IDENT, out_rows: Optional[int] = None, h_rows: Optional[int] = None):
+    """The decoder's residual stream in fp32 (include/mpv.h: mpv_ln_stream_fwd): h' = h_in + add in fp32, y = LN(h') in bf16.
+    h_in is the fp32 stream, or the bf16 embedding output for the first LayerNorm; add None: plain LN of h_in.
+    -> (y, h' (fp32, None without add), mean, rstd)."""
+    _need_cuda(h_in, gamma, beta)
+    if out is None:
+        out = torch.empty((out_rows if out_rows is not None else rows, cols), dtype=torch.bfloat16, device=h_in.device)
+    if add is not None and h_out is None:
+        h_out = torch.empty((h_rows if h_rows is not None else h_in.shape[0], cols), dtype=torch.float32, device=h_in.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=h_in.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=h_in.device)
+    check(_lib.lib().mpv_ln_stream_fwd(h_in.data_ptr(), int(h_in.dtype == torch.bfloat16), _p(add), _p(h_out) if add is not None else None,
+                                       gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, cols,
+                                       cols, cols, cols, eps, *hmap, *amap, *ymap, _stream()), "mpv_ln_stream_fwd")
+    return out, (h_out if add is not None else None), mean, rstd
+
+
+def ln_stream_bwd(dy, x, gamma, mean, rstd, rows: int, cols: int, *, dres=None, dx=None, dx_drop=None, dropout_p: float = 0.0,
+                  seed: int = 0, offset: int = 0, xmap: RowMap = IDENT, ymap: RowMap = IDENT, dx_rows: Optional[int] = None):
+    """LayerNorm backward of the frozen decoder with x read from the fp32 stream (no parameter gradients)."""
+    _need_cuda(dy, x, gamma)
+    assert x.dtype == torch.float32
+    if dx is None:
+        dx = torch.empty((dx_rows if dx_rows is not None else rows, cols), dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().mpv_ln_stream_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(dres), dx.data_ptr(),
+                                       _p(dx_drop), dropout_p, seed, offset, rows, cols, cols, cols, *xmap, *ymap, _stream()),
+          "mpv_ln_stream_bwd")
+    return dx
+
+
 class AttnLayout:
     """Strides (in elements) of q/k/v/o for mpv_attn_*: (batch, head, row)."""
 
