@@ -258,6 +258,35 @@ def test_entrypoint_loop_on_standins(tmp_path, monkeypatch):
         dist.destroy_process_group()
 
 
+def test_retrieval_entrypoint_on_standins(tmp_path, monkeypatch):
+    """downstream/run_retrieval_distributed_gpt3.py (train loop with padding='longest' titles, evaluation, itm_eval, checkpoint, log
+    line, --evaluate_only --resume with re-fitted temporal embeddings) on CPU / gloo through the stand-ins -- the assertions of the
+    GPU test (tests/test_entrypoint_gpu.py)."""
+    import json
+    import test_entrypoint_gpu as t
+    from test_engine_cpu import _stub_optimizer_kernels
+    orig = t._write_configs
+
+    def write(d, update_freq=1):
+        path = orig(d, update_freq)
+        cfg = json.load(open(os.path.join(d, "txt.json")))
+        cfg.update(hidden_dropout=0.0, attention_dropout=0.0)
+        json.dump(cfg, open(os.path.join(d, "txt.json"), "w"))
+        return path
+    monkeypatch.setattr(t, "_write_configs", write)
+    _stub_optimizer_kernels(monkeypatch)
+    monkeypatch.setenv("MASTER_PORT", str(27500 + os.getpid() % 2000))
+    t.test_retrieval_entrypoint_train_eval_resume(tmp_path, _on_cpu(monkeypatch))
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def test_itm_eval_on_cpu():
+    import test_entrypoint_gpu as t
+    t.test_itm_eval_recall_metrics()
+
+
 def test_kv_cache_decode_on_standins(monkeypatch):
     """generation.DecodeState (prefill + single-token steps + beam re-order over the KV caches) against one full causal forward,
     host logic on the stand-ins (the C decode step restated in tests/standin_ops.decode_step)."""
