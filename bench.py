@@ -264,7 +264,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
         with _StdoutToStderr():
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            from youku_mplug_amd.engine import init_process_group_for_dp      # RCCL on a high-priority stream (engine.py)
+            init_process_group_for_dp("nccl", rank=rank, world_size=world, device_id=dev)
             dist.barrier()                                               # brings the communicator (and its banner) up now
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
 

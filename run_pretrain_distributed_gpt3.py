@@ -44,8 +44,7 @@ def init_distributed(args):
     if torch.cuda.is_available():
         torch.cuda.set_device(args.gpu)
     if not dist.is_initialized():
-        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo", init_method=args.dist_url,
-                                world_size=args.world_size, rank=args.rank)
+        mpv_engine.init_process_group_for_dp(init_method=args.dist_url, world_size=args.world_size, rank=args.rank)
     dist.barrier()
 
 

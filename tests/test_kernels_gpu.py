@@ -724,7 +724,9 @@ def test_ln_stream_fwd_bwd(dev, rows, cols):
     win = (torch.arange(n, device=dev) // grp) * stride + torch.arange(n, device=dev) % grp + off
     h_out = torch.zeros_like(h32)
     y, h2, m, r = ops.ln_stream_fwd(h32, a, gam, bet, eps, n, cols, hmap=(grp, stride, off), h_out=h_out)
-    assert torch.equal(h2[win], h32[win] + a[:n].float()) and h2.abs().sum() == h2[win].abs().sum()
+    outside = torch.ones(rows, dtype=torch.bool, device=dev)
+    outside[win] = False
+    assert torch.equal(h2[win], h32[win] + a[:n].float()) and h2[outside].abs().max().item() == 0
     close(y[:n], F.layer_norm(h2[win], (cols,), gam.float(), bet.float(), eps), 1e-2, "mapped LN")
     # backward: x in fp32 against autograd, plus the residual gradient and the row maps
     dy, dres = rn(n, cols, dev=dev, seed=8), rn(rows, cols, dev=dev, seed=9)
@@ -733,4 +735,4 @@ def test_ln_stream_fwd_bwd(dev, rows, cols):
     dx = torch.zeros(rows, cols, dtype=torch.bfloat16, device=dev)
     ops.ln_stream_bwd(dy, h2, gam, m, r, n, cols, dres=dres, dx=dx, xmap=(grp, stride, off))
     close(dx[win], x.grad + dres[win].float(), 1e-2, "dx through the fp32 stream")
-    assert dx.float().abs().sum() == dx[win].float().abs().sum()
+    assert dx[outside].float().abs().max().item() == 0

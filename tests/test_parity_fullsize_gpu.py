@@ -84,11 +84,11 @@ def _pretrain_case(name, cfg, dev, B, L, wseed, grad_keys, logits_gate, hidden_g
     assert worst <= 8e-2, worst
 
 
-# Gates on deviation (1), as numbers.  A 24-layer (32-layer) decoder whose hidden states are stored in bf16 sits at 1.2e-2
-# (1.6e-2) from the fp32 function -- the oracle run in bf16 does too, column (2) -- so these gates are set from what the measured
-# implementation achieves with margin for box-to-box variation, NOT from north_star's 1e-2; the report states all three columns.
-LOGITS_GATE_B, HIDDEN_GATE_B = 1.6e-2, 2.6e-2
-LOGITS_GATE_D, HIDDEN_GATE_D = 2.0e-2, 3.0e-2
+# Gates on deviation (1), as numbers: north_star's 1e-2 for the logits, at every full-depth shape.  With the decoder's residual
+# stream in fp32 (gpt3.FP32_STREAM) the measured deviations are 6.6e-3 (config B), 7.7e-3 (S = 208) and 7.9e-3 (config D, 32
+# layers); the reference's own bf16 execution -- column (2) -- sits at 1.3-1.6e-2, and so does column (3), which is dominated by it.
+LOGITS_GATE_B, HIDDEN_GATE_B = 1.0e-2, 1.0e-2
+LOGITS_GATE_D, HIDDEN_GATE_D = 1.0e-2, 1.2e-2
 
 GRAD_KEYS = ["visual_fc.weight", "learnable_queries", "visual_encoder.blocks.0.attn.qkv.weight", "visual_encoder.blocks.11.mlp.fc2.weight",
              "visual_encoder.blocks.5.temporal_fc.weight", "visual_encoder.pos_embed", "visual_encoder.norm.weight"]

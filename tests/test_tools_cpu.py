@@ -1,0 +1,45 @@
+"""CPU tests of the measurement tools that cannot be exercised on the 1-GPU boxes: the all-reduce / backward overlap analysis
+(tools/rocpd_overlap.py) on a synthetic kernel trace, so that it works first time when an N >= 2 trace exists."""
+import os
+import sqlite3
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def _trace():
+    # (name, queue, stream, start ns, end ns): compute on queue 1 (and a second compute queue 3), RCCL on queue 2
+    return [("gemm256_kernel<false,false,false,4>(GemmArgs)", 1, 1, 0, 1000),
+            ("ln_bwd8_kernel<2,true>(LnBwdArgs)", 1, 1, 1000, 1500),
+            ("gemm256_kernel<true,true,false,4>(GemmArgs)", 3, 3, 1200, 1800),            # overlaps the LN on the main queue
+            ("ncclDevKernel_Generic(ncclDevKernelArgs)", 2, 2, 500, 1700),                 # 1200 ns: [500,1000) + [1000,1500) + [1200,1700) -> fully covered
+            ("ncclDevKernel_Generic(ncclDevKernelArgs)", 2, 2, 2000, 3000),                # 1000 ns: compute only on [2500, 2750)
+            ("adamw_grouped_kernel", 1, 1, 2500, 2750),
+            ("rcclSomething", 2, 2, 4000, 4100)]                                           # nothing beside it
+
+
+def test_overlap_report_on_synthetic_trace():
+    import rocpd_overlap as ro
+    assert ro.covered(0, 10, [(2, 4), (3, 6), (8, 20), (-5, 1)]) == 4 + 2 + 1
+    lines, share = ro.overlap_report(_trace())
+    assert "3 RCCL kernel launches on queues [2]" in lines[0] and "4 compute launches on queues [1, 3]" in lines[0]
+    assert abs(share - (1200 + 250 + 0) / (1200 + 1000 + 100)) < 1e-9
+    rows = [l for l in lines if l.startswith("| `")]
+    assert "100 %" in rows[0] and "25 %" in rows[1] and " 0 %" in rows[2]
+    _, none = ro.overlap_report([k for k in _trace() if "ccl" not in k[0].lower()])
+    assert none is None
+
+
+def test_overlap_tool_reads_a_rocpd_database(tmp_path):
+    db = str(tmp_path / "t.db")
+    c = sqlite3.connect(db)
+    c.execute("create table kernels (name text, queue_id int, stream_id int, start int, end int)")
+    c.executemany("insert into kernels values (?,?,?,?,?)", _trace())
+    c.commit()
+    c.close()
+    out = str(tmp_path / "o.md")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocpd_overlap.py"), db, out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "under compute kernels of another queue: 63 %" in open(out).read()

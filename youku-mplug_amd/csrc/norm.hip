@@ -622,6 +622,68 @@ __global__ __launch_bounds__(256) void ln_stream_fwd_kernel(const LnStreamArgs p
     }
   }
 }
+// One WORKGROUP per row, one 16-byte chunk (8 columns) per lane: the decoder's streams are few rows (5120 at config B) of many
+// columns, and a wave-per-row kernel holds a whole fp32 row in registers (161 VGPRs at 2048 columns: 3 waves per SIMD, two
+// rounds of workgroups).  Here a lane holds 8 fp32 values; the two row reductions go through LDS (one float per wave).
+template <bool INBF>
+__global__ __launch_bounds__(1024) void ln_stream_fwd_wg_kernel(const LnStreamArgs p) {
+  __shared__ float red[2][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int nchunk = p.cols >> 3;
+  const bool ok = tid < nchunk;
+  const float inv_n = 1.0f / (float)p.cols;
+  for (long long r = blockIdx.x; r < p.rows; r += gridDim.x) {
+    const long long hrow = map_row(p.hmap, r);
+    f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bf16x8 av = {}, gm = {}, bt = {};
+    if (ok) {
+      if constexpr (INBF) v = cvt8(*(const bf16x8*)((const bf16*)p.h_in + hrow * p.ldh + tid * 8));
+      else v = *(const f32x8*)((const float*)p.h_in + hrow * p.ldh + tid * 8);
+      if (p.add) av = *(const bf16x8*)(p.add + map_row(p.amap, r) * p.lda + tid * 8);
+      gm = *(const bf16x8*)(p.gamma + tid * 8);
+      bt = *(const bf16x8*)(p.beta + tid * 8);
+    }
+    if (p.add) {
+      v += cvt8(av);
+      if (ok) *(f32x8*)(p.h_out + hrow * p.ldh + tid * 8) = v;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += v[e];
+    s = wave_sum(s);
+    if (lane == 0) red[0][wave] = s;
+    __syncthreads();
+    float tot = 0.f;
+    for (int w = 0; w < nwaves; ++w) tot += red[0][w];
+    const float mu = tot * inv_n;
+    float s2 = 0.f;
+    if (ok)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[e] - mu;
+        s2 += d * d;
+      }
+    s2 = wave_sum(s2);
+    if (lane == 0) red[1][wave] = s2;
+    __syncthreads();
+    float tot2 = 0.f;
+    for (int w = 0; w < nwaves; ++w) tot2 += red[1][w];
+    const float rs = rsqrtf(tot2 * inv_n + p.eps);
+    if (ok) {
+      const f32x8 g = cvt8(gm), b = cvt8(bt);
+      f32x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (v[e] - mu) * rs * g[e] + b[e];
+      *(bf16x8*)(p.y + map_row(p.ymap, r) * p.ldy + tid * 8) = cvt8(o);
+    }
+    if (tid == 0) {
+      if (p.mean) p.mean[r] = mu;
+      if (p.rstd) p.rstd[r] = rs;
+    }
+    __syncthreads();      // red[] is reused by the next row of this workgroup
+  }
+}
+
 template <int MAXC>
 void launch_stream_fwd(const LnStreamArgs& a, bool inbf, int grid, hipStream_t s) {
   if (inbf) hipLaunchKernelGGL((ln_stream_fwd_kernel<MAXC, true>), dim3(grid), dim3(256), 0, s, a);
@@ -776,6 +838,13 @@ extern "C" int mpv_ln_stream_fwd(const void* h_in, int h_in_bf16, const void* ad
   if (rows == 0) return MPV_OK;
   LnStreamArgs a = {h_in, (const bf16*)add, h_out, (const bf16*)gamma, (const bf16*)beta, (bf16*)y, mean, rstd, rows, (int)cols, ldh, lda, ldy, eps,
                     RowMap{h_group, h_stride, h_offset}, RowMap{a_group, a_stride, a_offset}, RowMap{y_group, y_stride, y_offset}};
+  if (cols >= 1024) {      // wide rows: a workgroup per row
+    const int threads = (int)((cols / 8 + 63) / 64 * 64);
+    const int g = (int)(rows < 65536 ? rows : 65536);
+    if (h_in_bf16) hipLaunchKernelGGL((ln_stream_fwd_wg_kernel<true>), dim3(g), dim3(threads), 0, stream, a);
+    else hipLaunchKernelGGL((ln_stream_fwd_wg_kernel<false>), dim3(g), dim3(threads), 0, stream, a);
+    return mpv_check_launch("mpv_ln_stream_fwd");
+  }
   const int grid = (int)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);
   const int n8 = (int)((cols / 8 + 63) / 64);
   if (n8 <= 2) launch_stream_fwd<2>(a, h_in_bf16 != 0, grid, stream);

@@ -109,13 +109,21 @@ class DPReducer:
     """Bucketed gradient all-reduce over contiguous slices of FlatParams.grads (sum; the 1/world
     average is folded into the optimizer's grad_scale).  Device-agnostic: RCCL on GPU, gloo on CPU."""
 
-    def __init__(self, flat: FlatParams, process_group=None):
+    def __init__(self, flat: FlatParams, process_group=None, comm_dtype: Optional[str] = None):
         self.flat = flat
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.pending = []
         self.launched = set()
         self.always = False      # run the collectives even on a 1-rank group (single-GPU validation of the exchange path)
+        # Wire dtype of the gradient sum.  "bf16" (default): the flat bf16 slices are reduced in place, as DeepSpeed's bf16 engine
+        # communicates in the model dtype -- a ring all-reduce over 8 ranks then rounds every element up to 7 times (measured on
+        # CPU, world 8: 3e-3 of the gradient norm, tests/test_engine_cpu.py::test_bf16_bucket_sum_error_world8_gloo).  "fp32"
+        # (MPV_DP_COMM_DTYPE=fp32): every bucket is widened into an fp32 staging slice, summed in fp32 and rounded to bf16 once
+        # (twice the wire bytes: 520 MB per step at config B, still far below the backward it hides under).
+        self.comm_dtype = comm_dtype or os.environ.get("MPV_DP_COMM_DTYPE", "bf16")
+        assert self.comm_dtype in ("bf16", "fp32"), self.comm_dtype
+        self._stage32: Dict[str, torch.Tensor] = {}
 
     def stage_ready(self, name: str):
         if getattr(self, "hold", False):
@@ -124,15 +132,27 @@ class DPReducer:
             return
         a, b = self.flat.stage_slices[name]
         self.launched.add(name)
-        self.pending.append(dist.all_reduce(self.flat.grads[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        if self.comm_dtype == "fp32":
+            from . import ops
+            st = self._stage32.get(name)
+            if st is None or st.numel() != b - a:
+                st = self._stage32[name] = torch.empty(b - a, dtype=torch.float32, device=self.flat.device)
+            ops.accum_f32(st, self.flat.grads[a:b], first=True)          # widen (slices start on 256-element tiles: aligned)
+            self.pending.append((dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), name))
+        else:
+            self.pending.append((dist.all_reduce(self.flat.grads[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True), name))
 
     def finish(self):
         """Launch whatever was not announced, then make the current stream wait for every bucket."""
         if self.world > 1 or self.always:
             for name in self.flat.stage_slices:
                 self.stage_ready(name)
-            for w in self.pending:
+            for w, name in self.pending:
                 w.wait()
+                if self.comm_dtype == "fp32":
+                    from . import ops
+                    a, b = self.flat.stage_slices[name]
+                    ops.f32_to_bf16(self._stage32[name], self.flat.grads[a:b])     # one rounding of the fp32 sum
         self.pending.clear()
         self.launched.clear()
 
@@ -184,6 +204,25 @@ class FlatAdamW:
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_count = sd["step"]
         self.flat.params.copy_(self.master)
+
+
+def init_process_group_for_dp(backend: Optional[str] = None, **kw):
+    """torch.distributed.init_process_group with the one choice that matters for overlapping the gradient all-reduce with this
+    backward: RCCL's kernels go on a HIGH-PRIORITY HIP stream.  The 256x256 GEMM workgroup owns a whole CU (160 KiB of LDS and all
+    512 registers of every SIMD), so a communication workgroup can never be co-resident with one -- it gets a CU only when a tile
+    retires, and with equal priority the next GEMM tile of the same launch is just as likely to take it.  At high priority the
+    (few, long-lived) RCCL workgroups win that arbitration once and keep their CUs for the bucket's duration, while the GEMM grid
+    flows around them.  (A static CU reservation for communication was considered and rejected: it costs its share of the chip
+    for the whole step, not for the ~1-3 ms a step's buckets are on the wire.)  Falls back to default options where the backend
+    has no such knob (gloo)."""
+    backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+    if backend == "nccl":
+        try:
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            return dist.init_process_group(backend, pg_options=opts, **kw)
+        except (AttributeError, TypeError, RuntimeError):
+            pass
+    return dist.init_process_group(backend, **kw)
 
 
 def broadcast_module_state(model: nn.Module, flat: Optional["FlatParams"], process_group=None, src: int = 0):
