@@ -53,13 +53,13 @@ def gemm_source_digest():
 
 def algorithmic_train_flops(B, T, L, s=Shapes):
     """forward FLOPs (mul-add = 2), x3 for trainable parts, x2 for the frozen GPT.  EXECUTED work:
-    the BACKWARD of temporal_attn.proj + temporal_fc is one composed projection here (one token-row dgrad and one wgrad plus
-    D^3 weight products per block instead of two of each: that pair counts its forward only, 1/3 of the x3), the LM head and the top decoder layer's row-wise part run on the
-    loss window."""
+    temporal_attn.proj + temporal_fc run as ONE composed projection in both directions (one token-row product forward, one dgrad
+    and one wgrad plus three D^3 weight products per block instead of two token-row products of each kind), the LM head and the
+    top decoder layer's row-wise part run on the loss window."""
     D, N, Q, H, V, Lyr = s.vit_dim, (s.img_size // s.patch_size) ** 2, s.num_queries, s.hidden, s.vocab, s.layers
     M = B * T * N
     S = Q + L
-    vit = 2 * M * D * D + s.vit_depth * (M * 2 * D * (2304 + 768 + 768 * (1.0 / 3.0) + 2304 + 768) * (D / 768) ** 0 + 2 * D * D * D + (M + B) * 4 * D * 4 * D
+    vit = 2 * M * D * D + s.vit_depth * (M * 2 * D * (2304 + 768 + 2304 + 768) + 2 * D * D * D + (M + B) * 4 * D * 4 * D
                                          + B * T * 2 * D * 4 * D + B * T * 8 * 4 * (N + 1) ** 2 * (D // s.vit_heads) * s.vit_heads / 8
                                          + B * N * 8 * 4 * T * T * (D // s.vit_heads) * s.vit_heads / 8)
     Sk = 1 + T * N
@@ -80,7 +80,7 @@ def algorithmic_train_flops_E(B, T, L, s=Shapes, E=256):
     (nothing trainable sits below its hidden state), plus the two projection heads and the similarity products."""
     D, N, H, Lyr = s.vit_dim, (s.img_size // s.patch_size) ** 2, s.hidden, s.layers
     M = B * T * N
-    vit = 2 * M * D * D + s.vit_depth * (M * 2 * D * (2304 + 768 + 768 * (1.0 / 3.0) + 2304 + 768) + 2 * D * D * D + (M + B) * 4 * D * 4 * D
+    vit = 2 * M * D * D + s.vit_depth * (M * 2 * D * (2304 + 768 + 2304 + 768) + 2 * D * D * D + (M + B) * 4 * D * 4 * D
                                          + B * T * 2 * D * 4 * D + B * T * 4 * (N + 1) ** 2 * D + B * N * 4 * T * T * D)
     gpt = Lyr * 2 * B * L * H * (3 * H + H + 2 * s.ffn) + Lyr * 4 * B * L * L * H
     heads = 3.0 * (2 * B * D * E + 2 * B * H * E) + 3.0 * 2 * 2 * B * B * E

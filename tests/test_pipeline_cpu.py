@@ -71,8 +71,9 @@ def test_pipelines_on_standins_vs_reference_golden(monkeypatch):
 
 
 def test_composed_temporal_backward_matches_two_launch_backward(monkeypatch):
-    """TimeSformer.backward_features: proj + temporal_fc as one composed projection vs the reference's two dgrads and two
-    wgrads -- the same gradients up to bf16 rounding of the intermediate products, for every parameter."""
+    """TimeSformer.forward_features / backward_features: proj + temporal_fc as one composed projection vs the reference's two
+    products, two dgrads and two wgrads -- the same loss and gradients up to bf16 rounding of the intermediate products, for
+    every parameter."""
     from youku_mplug_amd import vision
     g = torch.load(os.path.join(GOLD, "tiny.pt"))
     meta = g["meta"]
@@ -91,7 +92,7 @@ def test_composed_temporal_backward_matches_two_launch_backward(monkeypatch):
         loss, _ = model(video, text)
         loss.backward()
         res[compose] = (loss.item(), _grads(model))
-    assert res[True][0] == res[False][0], "the forward is the same code in both modes"
+    assert abs(res[True][0] - res[False][0]) <= 2e-3 * abs(res[False][0]), "composed forward (Wc = Wf Wp rounded) vs two products (proj(a) rounded)"
     for n, ga in res[True][1].items():
         gb = res[False][1][n]
         e = (ga - gb).abs().max().item() / (gb.abs().max().item() + 1e-12)

@@ -184,8 +184,8 @@ class _WgradLane:
             torch.cuda.current_stream().wait_stream(self.side)
 
 
-# MPV_VIT_COMPOSE=0: measurement knob -- backward of temporal_attn.proj / temporal_fc as the reference's two dgrads + two wgrads
-# instead of the composed projection (TimeSformer.backward_features)
+# MPV_VIT_COMPOSE=0: measurement knob -- temporal_attn.proj / temporal_fc as the reference's two products (forward) and two dgrads +
+# two wgrads (backward) instead of the composed projection (TimeSformer.forward_features / backward_features)
 COMPOSE_TEMPORAL_OUT = os.environ.get("MPV_VIT_COMPOSE", "1") != "0"
 _SMALL_TILE = int(os.environ.get("MPV_VIT_SMALL_TILE", "128"))    # tile kernel of the [D, D] chain-rule products: 36 tiles of 128x128 beat 9 of 256x256 (same-box 78.5 -> 78.35 ms per step)
 
@@ -296,10 +296,23 @@ class TimeSformer(nn.Module):
                              amap=tok, cmap=tok, out_rows=R)
             at = torch.empty((R, D), dtype=torch.bfloat16, device=x.device)
             ops.temporal_attn_fwd(qkv_t, at, B, T * N1, N, 1, N1, T, heads, hd, blk.temporal_attn.scale)
-            pt = ops.gemm(at, blk.temporal_attn.proj.weight, Rt, D, D, bias=blk.temporal_attn.proj.bias, amap=tok, cmap=tok,
-                          out_rows=R)
             xt = torch.empty_like(x)
-            ops.gemm(pt, blk.temporal_fc.weight, Rt, D, D, bias=blk.temporal_fc.bias, residual=x, amap=tok, cmap=tok, out=xt)
+            if COMPOSE_TEMPORAL_OUT:
+                # temporal_attn.proj followed by temporal_fc (:199-200 then :250; proj_drop = 0, only a rearrange between them) is ONE
+                # linear map: xt = x + a Wc^T + bc with Wc = Wf Wp, bc = Wf bp + bf.  One product over the 50176 token rows instead
+                # of two, at the price of a [D, D] product and a matrix-vector product per block per step (the weights move every
+                # step).  The reference rounds proj(a) to bf16 between the two; here Wc is what is rounded -- the same size of
+                # perturbation, checked against the reference goldens (forward values and every gradient).
+                wf, wp = blk.temporal_fc.weight.detach(), blk.temporal_attn.proj.weight.detach()
+                wc = ops.gemm(wf, wp, D, D, D, trans_b=True, tile_hint=_SMALL_TILE)                      # Wc = Wf Wp
+                bc = ops.gemm(blk.temporal_attn.proj.bias.detach().view(1, D), wf, 1, D, D, bias=blk.temporal_fc.bias)   # bc = Wf bp + bf
+                ops.gemm(at, wc, Rt, D, D, bias=bc, residual=x, amap=tok, cmap=tok, out=xt)
+                pt = None
+                s["wc"] = wc
+            else:
+                pt = ops.gemm(at, blk.temporal_attn.proj.weight, Rt, D, D, bias=blk.temporal_attn.proj.bias, amap=tok, cmap=tok,
+                              out_rows=R)
+                ops.gemm(pt, blk.temporal_fc.weight, Rt, D, D, bias=blk.temporal_fc.bias, residual=x, amap=tok, cmap=tok, out=xt)
             ops.copy_rows(x, xt, B * T, D, smap=(1, N1, 0), dmap=(1, N1, 0))          # cls slots pass through
             # ---- spatial branch on all rows (:254-267)
             l1, s["m1"], s["r1"] = ops.layernorm_fwd(xt, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, R, D)
@@ -394,10 +407,9 @@ class TimeSformer(nn.Module):
                 # between them) as ONE linear map: xt = x + a Wc^T + bc with Wc = Wf Wp, bc = Wf bp + bf.  One dgrad
                 # d(a) = d(xt) Wc and one wgrad dWc = d(xt)^T a over the 50176 token rows instead of two of each; the chain
                 # rule through the composition runs on [D, D] operands (768^3 products): dWf = dWc Wp^T + d(bc) bp^T,
-                # dWp = Wf^T dWc, d(bp) = Wf^T d(bc), d(bf) = d(bc).  The forward keeps the reference's two launches and its
-                # bf16 rounding of proj(a): forward values are untouched, gradients agree to rounding (golden tests).
+                # dWp = Wf^T dWc, d(bp) = Wf^T d(bc), d(bf) = d(bc).  (The forward is composed the same way: forward_features.)
                 wf, wp = blk.temporal_fc.weight.detach(), blk.temporal_attn.proj.weight.detach()
-                wc = ops.gemm(wf, wp, D, D, D, trans_b=True, tile_hint=_SMALL_TILE)                # Wc = Wf Wp
+                wc = s["wc"]                                                                       # Wc = Wf Wp, from the forward
 
                 def _temporal_out_wgrad(dxt=dxt, wf=wf, wp=wp):
                     dbc = grad_of(blk.temporal_fc.bias)                                   # d(bf) = d(bc) = colsum d(xt)
