@@ -233,7 +233,8 @@ def cpu_baseline(threads):
     dt = (time.time() - t0) / n
     return {"value": round(2.0 / dt, 5), "unit": "samples/s", "cores": threads, "kind": "port",
             "sample": f"{n} full steps of the config-B per-sample shape at batch 2 (T=8, L=32, 1.3B dims, bf16; fwd + bwd + AdamW) = {dt * n:.1f} s on {threads} threads, "
-                      f"{dt:.2f} s per step"}
+                      f"{dt:.2f} s per step; calibration against the reference's own modules (build container, config A, same cores): the port's "
+                      "step takes 0.74x the reference modules' (profiles/r03_cpu_baseline_calibration.txt), i.e. this figure flatters the CPU by ~1.35x"}
 
 
 def main():
