@@ -217,7 +217,7 @@ def main(args, config):
         data_loader, val_loader, test_loader = create_loader(datasets, samplers, batch_size=[args.batch_size] * 3, num_workers=[args.num_workers] * 3,
                                                              is_trains=[True, False, False], collate_fns=[None, None, None])
         tokenizer = DistributedGPT3Tokenizer(config["text_decoder"])
-    steps_per_epoch = len(data_loader) // args.update_freq
+    steps_per_epoch = len(data_loader)      # as the reference (:383): the tables cover len(data_loader) steps per epoch whatever --update_freq is
     model = DistributedGPT3_Retrieval(config=config, tokenizer=tokenizer, device=device)
     n_parameters = sum(p.numel() for p in model.parameters() if p.requires_grad)
     print("number of params (B):", n_parameters / 1e9)

@@ -148,7 +148,10 @@ def main(args, config):
         data_loader = create_loader(datasets, samplers, batch_size=[config["batch_size"]], num_workers=[config["num_workers"]],
                                     is_trains=[True], collate_fns=[None])[0]
         tokenizer = DistributedGPT3Tokenizer(model_dir=config["text_decoder"])
-    steps_per_epoch = len(data_loader) // args.update_freq
+    # The reference builds its schedule tables with len(data_loader) steps per epoch whatever --update_freq is (:230, 286-291), and
+    # the loop then indexes them with data_iter_step // update_freq (:82-88): under accumulation only the first 1 / update_freq of an
+    # epoch's segment is walked.  Kept as is (drop-in: same lr at the same iteration); see INTEGRATION.md section 1.
+    steps_per_epoch = len(data_loader)
     model = DistributedGPT3_Pretrain(config=config, tokenizer=tokenizer, device=device)
     n_parameters = sum(p.numel() for p in model.parameters() if p.requires_grad)
     print("number of params (B):", n_parameters / 1e9)
