@@ -1385,11 +1385,56 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TempArgs p) {
   float* ps = (BWD ? dos + T * ld : dos);           // [T][T+1] probabilities
   float* dss = ps + T * (T + 1);                    // BWD only: dS [T][T+1]
   const long long nprob = (long long)p.n_outer * p.n_inner * p.heads;
-  for (long long pr = (long long)blockIdx.x * 4 + wave; pr < nprob; pr += (long long)gridDim.x * 4) {
-    const int h = (int)(pr % p.heads);
+  const long long pstride = (long long)gridDim.x * 4;
+  // The operands of a wave's NEXT problem are requested (into registers) before the current one is computed: a problem is a
+  // load -> LDS -> three dependent LDS phases -> store chain, and with 12-16 waves per CU the memory system saw the loads of
+  // one phase at a time (4.1-4.5 TB/s); compile-time instances only (the register arrays need constant trip counts).
+  constexpr bool PF = TC > 0 && HDC > 0;
+  constexpr int NX = PF ? (TC * (HDC / 4) + 63) / 64 : 1;
+  bf16x4 rq[NX], rk[NX], rv[NX], rd[BWD ? NX : 1];
+  auto row_of = [&](long long pr, int& h) {
+    h = (int)(pr % p.heads);
     const long long seq = pr / p.heads;
     const long long o = seq / p.n_inner, i = seq % p.n_inner;
-    const long long row0 = o * p.outer_stride + p.inner_offset + i;
+    return o * p.outer_stride + p.inner_offset + i;
+  };
+  auto request = [&](long long pr) {
+    int h;
+    const long long row0 = row_of(pr, h);
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int x = lane + 64 * j;
+      if (x < T * H4) {
+        const int t = x / H4, c4 = x - t * H4;
+        const bf16* src = p.qkv + (row0 + t * p.t_stride) * (3LL * D) + h * hd + c4 * 4;
+        rq[j] = *(const bf16x4*)src;
+        rk[j] = *(const bf16x4*)(src + D);
+        rv[j] = *(const bf16x4*)(src + 2 * D);
+        if constexpr (BWD) rd[j] = *(const bf16x4*)(p.dout + (row0 + t * p.t_stride) * (long long)D + h * hd + c4 * 4);
+      }
+    }
+  };
+  long long pr0 = (long long)blockIdx.x * 4 + wave;
+  if (PF && pr0 < nprob) request(pr0);
+  for (long long pr = pr0; pr < nprob; pr += pstride) {
+    int h;
+    const long long row0 = row_of(pr, h);
+    if constexpr (PF) {
+#pragma unroll
+      for (int j = 0; j < NX; ++j) {
+        const int x = lane + 64 * j;
+        if (x < T * H4) {
+          const int t = x / H4, c4 = x - t * H4;
+          f32x4 qv = cvt4(rq[j]) * p.scale;
+          qv = cvt4(cvt4(qv));                                      // q*scale rounds to bf16 (reference :179)
+          *(f32x4*)(qs + t * ld + c4 * 4) = qv;
+          *(f32x4*)(ks + t * ld + c4 * 4) = cvt4(rk[j]);
+          *(f32x4*)(vs + t * ld + c4 * 4) = cvt4(rv[j]);
+          if constexpr (BWD) *(f32x4*)(dos + t * ld + c4 * 4) = cvt4(rd[j]);
+        }
+      }
+      if (pr + pstride < nprob) request(pr + pstride);
+    } else {
 #pragma unroll
     for (int x = lane; x < T * H4; x += 64) {
       const int t = x / H4, c4 = x - t * H4;
@@ -1401,6 +1446,7 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TempArgs p) {
       *(f32x4*)(vs + t * ld + c4 * 4) = cvt4(*(const bf16x4*)(src + 2 * D));
       if constexpr (BWD)
         *(f32x4*)(dos + t * ld + c4 * 4) = cvt4(*(const bf16x4*)(p.dout + (row0 + t * p.t_stride) * (long long)D + h * hd + c4 * 4));
+    }
     }
     WAVE_SYNC();
 #pragma unroll
