@@ -284,6 +284,31 @@ class TimeSformer(nn.Module):
         else:
             x = x0
         blocks: List[dict] = []
+        composed = None
+        if COMPOSE_TEMPORAL_OUT:
+            # Wc = Wf Wp and bc = Wf bp + bf of every block depend on parameters only: all 24 small products go to the second
+            # stream now and run beside the patch embedding and the first block's products (36 workgroups each, they fit between
+            # the tiles of the big launches); the main stream waits for them once, before block 0 uses its pair.  On the
+            # critical path they were 12 x (18 + 7) us per step.
+            wl = _WgradLane(video.device) if not hasattr(self, "_wgrad_lane") else self._wgrad_lane
+            self._wgrad_lane = wl
+            composed = []
+
+            def _compose_all():
+                main = torch.cuda.current_stream() if wl.on else None
+                for blk in self.blocks:
+                    wf, wp = blk.temporal_fc.weight.detach(), blk.temporal_attn.proj.weight.detach()
+                    wc = ops.gemm(wf, wp, D, D, D, trans_b=True, tile_hint=_SMALL_TILE)                      # Wc = Wf Wp
+                    bc = ops.gemm(blk.temporal_attn.proj.bias.detach().view(1, D), wf, 1, D, D, bias=blk.temporal_fc.bias)   # bc = Wf bp + bf
+                    composed.append((wc, bc))
+            if wl.on:
+                main = torch.cuda.current_stream()
+                wl(_compose_all)
+                for wc, bc in composed:       # allocated on the second stream, consumed on the main one
+                    wc.record_stream(main)
+                    bc.record_stream(main)
+            else:
+                _compose_all()
         if not hasattr(self, "_qkv_bias_pack"):
             self._qkv_bias_pack = _PackedQkvBias()
         qkv_b = self._qkv_bias_pack.refresh([a for blk in self.blocks for a in (blk.temporal_attn, blk.attn)])
@@ -303,9 +328,9 @@ class TimeSformer(nn.Module):
                 # of two, at the price of a [D, D] product and a matrix-vector product per block per step (the weights move every
                 # step).  The reference rounds proj(a) to bf16 between the two; here Wc is what is rounded -- the same size of
                 # perturbation, checked against the reference goldens (forward values and every gradient).
-                wf, wp = blk.temporal_fc.weight.detach(), blk.temporal_attn.proj.weight.detach()
-                wc = ops.gemm(wf, wp, D, D, D, trans_b=True, tile_hint=_SMALL_TILE)                      # Wc = Wf Wp
-                bc = ops.gemm(blk.temporal_attn.proj.bias.detach().view(1, D), wf, 1, D, D, bias=blk.temporal_fc.bias)   # bc = Wf bp + bf
+                if bi == 0:
+                    self._wgrad_lane.sync()                     # the composed weights of all blocks (second stream, see above)
+                wc, bc = composed[bi]
                 ops.gemm(at, wc, Rt, D, D, bias=bc, residual=x, amap=tok, cmap=tok, out=xt)
                 pt = None
                 s["wc"] = wc
