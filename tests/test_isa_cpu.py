@@ -78,7 +78,7 @@ def test_streaming_kernels_keep_their_waves(kernels):
 def test_attention_kernels_budgets(kernels):
     ks, _ = kernels
     for n, k in ks.items():
-        if "attn_" not in n or "temporal" in n:
+        if "attn_" not in n or "temporal" in n or "pair64" in n:      # the paired-block kernels have their own test below
             continue
         lean = "ELi320ELi3EE" in n                               # <..., 320, 3>: GPT instances, two 5-wave workgroups per CU, 3 waves per SIMD
         assert k["vgpr"] + (0 if "attn_bwd_dkv_kernel" in n else k["agpr"]) <= (170 if lean else 512), (n, k)

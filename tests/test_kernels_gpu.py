@@ -206,6 +206,14 @@ ATTN_CASES = [  # B, H, Sq, Sk, hd, causal, scale_q_bf16
     (20, 16, 208, 208, 64, True, False),    # decoder at the YAML-as-shipped geometry (S = 128 + 80)
     (17, 16, 160, 160, 80, True, False),    # 2.7B decoder heads; batch not a multiple of 8 (padding items are skipped)
     (36, 8, 100, 100, 64, False, False),    # ragged tile (100 = 3 * 32 + 4): tile over-reads cross into the other operand set
+    # paired-block causal kernels (csrc/attention_pair.inc: head_dim 64, causal, sq == sk <= 224): odd / even block counts, ragged
+    # last tiles (over-reads past the allocation), a single block, the largest size, pre-scaled q
+    (3, 4, 33, 33, 64, True, False),
+    (5, 2, 100, 100, 64, True, False),
+    (2, 2, 8, 8, 64, True, False),
+    (9, 4, 224, 224, 64, True, False),
+    (2, 2, 129, 129, 64, True, True),
+    (33, 32, 160, 160, 64, True, False),    # config B exactly: 1056 items, four per CU
 ]
 
 
@@ -244,6 +252,8 @@ def test_attention_fwd_bwd(dev, B, H, Sq, Sk, hd, causal, sqb):
         # q' = bf16(q*scale) is non-differentiable through the rounding; compare against the smooth scale path
         q2 = qt.float().requires_grad_(True)
         s2 = (q2 * scale) @ kt.float().transpose(-1, -2)
+        if causal:
+            s2 = s2.masked_fill(~m, float("-inf"))
         (s2.softmax(-1) @ vt.float()).backward(do.permute(0, 2, 1, 3).float())
         close(dq.permute(0, 2, 1, 3), q2.grad, 3e-2, "dQ (pre-scaled q)")
 

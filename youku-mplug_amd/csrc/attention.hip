@@ -1611,6 +1611,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
   if (tid == 0 && p.lse) p.lse[bh] = mx + __logf(l);
 }
 
+#include "attention_pair.inc"
+
 // waves per workgroup: cover a whole sequence with one workgroup when it has <= 256 rows (no idle
 // waves: 160 rows -> 5 waves, 197 -> 7), otherwise 8 waves = 256 rows per workgroup
 int waves_for(int rows) {
@@ -1731,6 +1733,23 @@ static void res_attr_once() {
   done = true;
 }
 
+// ---- paired-block causal kernels (attention_pair.inc): host side ----
+// MPV_ATTN_PAIR (measurement knob, read once): 0 = the one-shot resident kernels; 1 = paired kernels with the dQ and dK/dV roles
+// as two launches; 2 (default) = paired forward + ONE fused backward launch
+static int pair_mode() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("MPV_ATTN_PAIR");
+    mode = e ? atoi(e) : 2;
+  }
+  return mode;
+}
+constexpr int PAIR_MAX_ROWS = 224;
+static bool pair_ok(const mpv_attn_desc* d) {
+  return pair_mode() > 0 && d->head_dim == 64 && d->causal && d->sq == d->sk && d->sk <= PAIR_MAX_ROWS;
+}
+static size_t pair_lds(int rows) { return 2 * (size_t)((rows + 31) / 32) * 32 * 128; }      // two images of whole 32-row tiles (z_region)
+
 extern "C" int mpv_attn_fwd(const mpv_attn_desc* d, hipStream_t stream) {
   int rc = check_desc(d, "mpv_attn_fwd");
   if (rc) return rc;
@@ -1747,6 +1766,13 @@ extern "C" int mpv_attn_fwd(const mpv_attn_desc* d, hipStream_t stream) {
     const int nw = waves_for(d->sq);
     const int gy = (d->batch + 7) / 8 * 8 * d->heads;   // decode_bh() needs whole groups of 8 sequences
     dim3 grid((d->sq + 32 * nw - 1) / (32 * nw), gy), block(64 * nw);
+    if (pair_ok(d)) {
+      const int nb = (d->sk + 31) / 32;
+      const dim3 pg(1, gy), pb(64 * ((nb + 1) / 2));
+      if (nb <= 5) hipLaunchKernelGGL((attn_fwd_pair64_kernel<5, 192, 3>), pg, pb, pair_lds(d->sk), stream, a);
+      else hipLaunchKernelGGL((attn_fwd_pair64_kernel<7, 256, 2>), pg, pb, pair_lds(d->sk), stream, a);
+      return mpv_check_launch("mpv_attn_fwd");
+    }
     const int hdc = d->head_dim <= 64 ? 64 : d->head_dim <= 80 ? 80 : 96;
     const size_t plds = 2 * (pres_region_h(d->sk, pres_pitch_r(hdc)) + pres_region_h(d->sk, pres_pitch_c(hdc)));
     if (grid.x == 1 && plds <= PRES_LDS_MAX && pres_wanted(gy) && pres_offsets_ok(d) && pres_fwd_has(hdc, d)) {
@@ -1800,6 +1826,24 @@ extern "C" int mpv_attn_bwd(const mpv_attn_desc* d, const void* dO, void* dq, vo
     res_attr_once();
     const int nw = waves_for(d->sq);
     const int gy = (d->batch + 7) / 8 * 8 * d->heads;
+    if (pair_ok(d)) {
+      const int nb = (d->sk + 31) / 32;
+      const dim3 pg(1, gy), pb(64 * ((nb + 1) / 2));
+      const size_t pl = pair_lds(d->sk);
+      if (pair_mode() >= 2) {
+        if (nb <= 5) hipLaunchKernelGGL((attn_bwd_pair64_kernel<3, 192, 3>), pg, pb, pl, stream, a);
+        else hipLaunchKernelGGL((attn_bwd_pair64_kernel<3, 256, 3>), pg, pb, pl, stream, a);
+      } else {
+        if (nb <= 5) {
+          hipLaunchKernelGGL((attn_bwd_pair64_kernel<1, 192, 3>), pg, pb, pl, stream, a);
+          hipLaunchKernelGGL((attn_bwd_pair64_kernel<2, 192, 3>), pg, pb, pl, stream, a);
+        } else {
+          hipLaunchKernelGGL((attn_bwd_pair64_kernel<1, 256, 3>), pg, pb, pl, stream, a);
+          hipLaunchKernelGGL((attn_bwd_pair64_kernel<2, 256, 3>), pg, pb, pl, stream, a);
+        }
+      }
+      return mpv_check_launch("mpv_attn_bwd");
+    }
     const int nwk = waves_for(d->sk);
     dim3 gq((d->sq + 32 * nw - 1) / (32 * nw), gy), gk((d->sk + 32 * nwk - 1) / (32 * nwk), gy);
     const size_t lq = res_lds_bytes(d->sk, false), lk = res_lds_bytes(d->sq, true) + (d->head_dim > 64 ? res_region(d->sk, ROWB) : 0);

@@ -187,6 +187,7 @@ class _WgradLane:
 # MPV_VIT_COMPOSE=0: measurement knob -- temporal_attn.proj / temporal_fc as the reference's two products (forward) and two dgrads +
 # two wgrads (backward) instead of the composed projection (TimeSformer.forward_features / backward_features)
 COMPOSE_TEMPORAL_OUT = os.environ.get("MPV_VIT_COMPOSE", "1") != "0"
+_COMPOSE_ON_LANE = os.environ.get("MPV_VIT_COMPOSE_LANE", "1") != "0"    # measurement knob: 0 = the composed weights are built on the main stream
 _SMALL_TILE = int(os.environ.get("MPV_VIT_SMALL_TILE", "128"))    # tile kernel of the [D, D] chain-rule products: 36 tiles of 128x128 beat 9 of 256x256 (same-box 78.5 -> 78.35 ms per step)
 
 
@@ -295,13 +296,12 @@ class TimeSformer(nn.Module):
             composed = []
 
             def _compose_all():
-                main = torch.cuda.current_stream() if wl.on else None
                 for blk in self.blocks:
                     wf, wp = blk.temporal_fc.weight.detach(), blk.temporal_attn.proj.weight.detach()
                     wc = ops.gemm(wf, wp, D, D, D, trans_b=True, tile_hint=_SMALL_TILE)                      # Wc = Wf Wp
                     bc = ops.gemm(blk.temporal_attn.proj.bias.detach().view(1, D), wf, 1, D, D, bias=blk.temporal_fc.bias)   # bc = Wf bp + bf
                     composed.append((wc, bc))
-            if wl.on:
+            if wl.on and _COMPOSE_ON_LANE:
                 main = torch.cuda.current_stream()
                 wl(_compose_all)
                 for wc, bc in composed:       # allocated on the second stream, consumed on the main one
