@@ -86,6 +86,17 @@ def test_attention_kernels_budgets(kernels):
         assert k["scratch"] <= (32 if ("attn_bwd_dq_res_kernelILi96ELi7E" in n or "attn_bwd_dkv_res_kernelILi64ELi320E" in n) else 0), (n, k)
 
 
+def test_paired_causal_attention_kernels_fit_four_items_per_cu(kernels):
+    """csrc/attention_pair.inc: 3 waves and 40 KiB per (batch, head) item at S = 160 -> four items per CU only if a wave stays
+    within the registers of 3 waves per SIMD (170) and nothing spills."""
+    ks, _ = kernels
+    pair = _sel(ks, "pair64_kernel")
+    assert len(pair) == 4, sorted(pair)          # forward x {5, 7 blocks}, dQ x {3, 4 waves}
+    for n, k in pair.items():
+        limit = 256 if "ILi7ELi256ELi2EE" in n else 170      # the 7-block forward keeps 7 score tiles: two waves per SIMD
+        assert k["scratch"] == 0 and k["vgpr"] + k["agpr"] <= limit and k["lds"] == 0, (n, k)
+
+
 def test_persistent_attention_kernels_never_touch_scratch(kernels):
     """attn_*_pres_kernel: a scratch reload waits with s_waitcnt vmcnt(0), which would also drain the next item's LDS-DMA in the
     middle of the current item; every shipped instance must fit 256 registers (two waves per SIMD) without scratch, and the

@@ -43,3 +43,13 @@ def test_overlap_tool_reads_a_rocpd_database(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocpd_overlap.py"), db, out], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "under compute kernels of another queue: 63 %" in open(out).read()
+
+
+def test_zimage_layout_simulation():
+    """The permuted 128-byte-row LDS image of csrc/attention_pair.inc: every fragment address returns its logical element and the
+    hardware lane groups are bank-conflict-free (host simulation, tools/probe/sim_zimage_layout.py)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sim_zimage_layout", os.path.join(ROOT, "tools", "probe", "sim_zimage_layout.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.check(160, verbose=False) and mod.check(224, verbose=False) and mod.check(32, verbose=False)

@@ -1,7 +1,7 @@
 """Decoder attention at the config-B shape (32 x 32 heads x 160 x 64, causal, probability dropout 0.1, the packed qkv layout of
 models/modeling_distributed_gpt3.py:895-902): forward / backward time per launch, 50 back-to-back launches between events.
 MPV_ATTN_PAIR is read once per process: run it once per mode.
-  for m in 0 1 2; do MPV_ATTN_PAIR=$m python tools/attn_pair_ab.py; done"""
+  for m in 0 1; do MPV_ATTN_PAIR=$m python tools/attn_pair_ab.py; done"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1734,13 +1734,12 @@ static void res_attr_once() {
 }
 
 // ---- paired-block causal kernels (attention_pair.inc): host side ----
-// MPV_ATTN_PAIR (measurement knob, read once): 0 = the one-shot resident kernels; 1 = paired kernels with the dQ and dK/dV roles
-// as two launches; 2 (default) = paired forward + ONE fused backward launch
+// MPV_ATTN_PAIR (measurement knob, read once): 0 = the one-shot resident kernels; 1 (default) = the paired forward and dQ kernels
 static int pair_mode() {
   static int mode = -1;
   if (mode < 0) {
     const char* e = getenv("MPV_ATTN_PAIR");
-    mode = e ? atoi(e) : 2;
+    mode = e ? atoi(e) : 1;
   }
   return mode;
 }
@@ -1826,24 +1825,6 @@ extern "C" int mpv_attn_bwd(const mpv_attn_desc* d, const void* dO, void* dq, vo
     res_attr_once();
     const int nw = waves_for(d->sq);
     const int gy = (d->batch + 7) / 8 * 8 * d->heads;
-    if (pair_ok(d)) {
-      const int nb = (d->sk + 31) / 32;
-      const dim3 pg(1, gy), pb(64 * ((nb + 1) / 2));
-      const size_t pl = pair_lds(d->sk);
-      if (pair_mode() >= 2) {
-        if (nb <= 5) hipLaunchKernelGGL((attn_bwd_pair64_kernel<3, 192, 3>), pg, pb, pl, stream, a);
-        else hipLaunchKernelGGL((attn_bwd_pair64_kernel<3, 256, 3>), pg, pb, pl, stream, a);
-      } else {
-        if (nb <= 5) {
-          hipLaunchKernelGGL((attn_bwd_pair64_kernel<1, 192, 3>), pg, pb, pl, stream, a);
-          hipLaunchKernelGGL((attn_bwd_pair64_kernel<2, 192, 3>), pg, pb, pl, stream, a);
-        } else {
-          hipLaunchKernelGGL((attn_bwd_pair64_kernel<1, 256, 3>), pg, pb, pl, stream, a);
-          hipLaunchKernelGGL((attn_bwd_pair64_kernel<2, 256, 3>), pg, pb, pl, stream, a);
-        }
-      }
-      return mpv_check_launch("mpv_attn_bwd");
-    }
     const int nwk = waves_for(d->sk);
     dim3 gq((d->sq + 32 * nw - 1) / (32 * nw), gy), gk((d->sk + 32 * nwk - 1) / (32 * nwk), gy);
     const size_t lq = res_lds_bytes(d->sk, false), lk = res_lds_bytes(d->sq, true) + (d->head_dim > 64 ? res_region(d->sk, ROWB) : 0);
@@ -1851,7 +1832,12 @@ extern "C" int mpv_attn_bwd(const mpv_attn_desc* d, const void* dO, void* dq, vo
     const bool small64 = hdc == 64 && d->sk <= 160 && d->sq <= 160 && nw <= 5 && nwk <= 5;     // two workgroups per CU (see attn_fwd_res_kernel)
     const bool vit7 = hdc == 96 && !d->causal && d->dropout_p == 0.f && (d->sk + 31) / 32 == 7;
     // dQ first: it also stores delta = rowsum(dO * O), which the dK/dV kernel reads
-    {
+    if (pair_ok(d)) {      // paired-block dQ role (attention_pair.inc); the dK/dV role stays with the one-shot kernel below
+      const int nb = (d->sk + 31) / 32;
+      const dim3 pg(1, gy), pb(64 * ((nb + 1) / 2));
+      if (nb <= 5) hipLaunchKernelGGL((attn_bwd_dq_pair64_kernel<192, 3>), pg, pb, pair_lds(d->sk), stream, a);
+      else hipLaunchKernelGGL((attn_bwd_dq_pair64_kernel<256, 3>), pg, pb, pair_lds(d->sk), stream, a);
+    } else {
       switch (hdc) {
         case 64:
           if (small64) hipLaunchKernelGGL((attn_bwd_dq_res_kernel<64, 0, 320, 3>), gq, dim3(64 * nw), lq, stream, a);
