@@ -47,6 +47,27 @@ def t(fn, n=50, rep=5):
     return best
 
 
+if os.environ.get("AB_VIT"):      # ViT-B/16 spatial attention at config B: 256 images x 8 heads x 197 x 96, pre-scaled q, no dropout
+    B, S, H, hn = 256, 197, 8, 96
+    Hh = H * hn
+    qkv = (torch.randn(B, S, 3, H, hn, device=dev) * 0.5).to(torch.bfloat16)
+    do = torch.randn(B, S, Hh, device=dev).to(torch.bfloat16)
+    o = torch.empty(B, S, Hh, dtype=torch.bfloat16, device=dev)
+    dqkv = torch.empty_like(qkv)
+    st = (S * 3 * Hh, hn, 3 * Hh)
+    lay = ops.AttnLayout(st, st, st, (S * Hh, hn, Hh))
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    dq_, dk_, dv_ = dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2]
+    kw = dict(causal=False, scale=hn ** -0.5, scale_q_bf16=True)
+
+    def fwd():
+        return ops.attn_fwd(q, k, v, o, lay, B, H, S, S, hn, **kw)
+
+    lse = fwd()
+
+    def bwd():
+        ops.attn_bwd(q, k, v, o, lse, do, dq_, dk_, dv_, lay, B, H, S, S, hn, **kw)
+
 for _ in range(3):
     fwd(); bwd()
 print(f"MPV_ATTN_PAIR={os.environ.get('MPV_ATTN_PAIR', '(default)')} B={B} S={S}: fwd {t(fwd):.1f} us  bwd {t(bwd):.1f} us   "

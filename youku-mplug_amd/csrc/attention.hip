@@ -885,16 +885,18 @@ __global__ __launch_bounds__(THREADS, WPE) void attn_bwd_dq_res_kernel(const Att
         s[e + 1] = ds[1];
       }
     } else {
+      const uint64_t rb = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qrow) * (uint64_t)p.sk;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
+      for (int e = 0; e < 16; e += 2) {      // registers e, e+1 hold keys k, k+1 with k even: one hash word per pair (attn_keep)
         const int key = kt * 32 + acc_row(e, lane);
-        const float pr = key <= my_last ? fexp2(s[e] * c2 - lse2) : 0.f;
-        float dpe = dp[e];
-        if (NTC == 0 && p.drop_thr) {
-          const uint64_t rb = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qrow) * (uint64_t)p.sk;
-          dpe = attn_keep(p.seed, rb, key, p.drop_thr) ? dpe * p.drop_scale : 0.f;
-        }
-        s[e] = key <= my_last ? pr * (dpe - dl) : 0.f;
+        uint32_t r = 0xffffffffu;
+        if (NTC == 0 && p.drop_thr) r = mpv_rand_pair(p.seed, rb + (uint64_t)key);
+        const float p0 = key <= my_last ? fexp2(s[e] * c2 - lse2) : 0.f;
+        const float p1 = key + 1 <= my_last ? fexp2(s[e + 1] * c2 - lse2) : 0.f;
+        const float d0 = (r & 0xffffu) >= p.drop_thr ? dp[e] * p.drop_scale : 0.f;      // drop_thr = 0: kept, drop_scale = 1
+        const float d1 = (r >> 16) >= p.drop_thr ? dp[e + 1] * p.drop_scale : 0.f;
+        s[e] = key <= my_last ? p0 * (d0 - dl) : 0.f;
+        s[e + 1] = key + 1 <= my_last ? p1 * (d1 - dl) : 0.f;
       }
     }
 #pragma unroll
