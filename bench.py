@@ -309,9 +309,13 @@ def main():
     idx = torch.arange(B, device=dev) + rank * B                      # retrieval: one positive per (video, title) pair across the global batch
     flops_fn = algorithmic_train_flops_E if args.config == "E" else algorithmic_train_flops
 
-    def step(i):
+    use_graph = os.environ.get("MPV_GRAPH", "0") == "1"              # the step as one replayed HIP graph (engine.graph_step)
+
+    def step(i, eager=False):
         for g in opt.param_groups:                                   # run_pretrain_distributed_gpt3.py:88-96
             g["lr"] = lr_sched[i] * g["lr_scale"]
+        if use_graph and not eager:
+            return engine.graph_step(video, text, idx) if args.config == "E" else engine.graph_step(video, text)
         if args.config == "E":
             loss = engine(video, text, idx)                          # downstream/run_retrieval_distributed_gpt3.py:137
         else:
@@ -337,14 +341,26 @@ def main():
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     fence()
     t0 = time.perf_counter()
+    c0 = time.thread_time()
     marks[0].record()
     for i in range(args.steps):
         loss = step(args.warmup + i)
         marks[i + 1].record()
     t_enq = time.perf_counter() - t0            # host time to ENQUEUE the timed steps (no device sync inside a step)
+    t_cpu = time.thread_time() - c0             # CPU time this thread spent doing it (the wall time above includes waiting on a full launch queue)
     fence()
     dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-    log(f"host enqueue time {t_enq / args.steps * 1e3:.1f} ms/step (launch-bound if this approaches the step time)")
+    log(f"host enqueue time {t_enq / args.steps * 1e3:.1f} ms/step wall, {t_cpu / args.steps * 1e3:.1f} ms/step CPU (launch-bound if the CPU figure approaches the step time)" +
+        (" [MPV_GRAPH=1: graph replay]" if use_graph else ""))
+    # the same on an IDLE queue (nothing to wait for): what the host really spends to launch one step
+    t_idle = []
+    for i in range(3):
+        torch.cuda.synchronize()
+        t1, c1 = time.perf_counter(), time.thread_time()
+        step(total - 1)
+        t_idle.append((time.perf_counter() - t1, time.thread_time() - c1))
+    torch.cuda.synchronize()
+    log(f"host time to launch one step on an idle queue: {min(t[0] for t in t_idle) * 1e3:.1f} ms wall, {min(t[1] for t in t_idle) * 1e3:.1f} ms CPU")
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     if dist_on:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
@@ -365,7 +381,7 @@ def main():
             lane.on = False
         with GemmTimer() as gt:
             for i in range(nroof):
-                step(total + i)
+                step(total + i, eager=True)
         tot = gt.summary()
         if os.environ.get("MPV_BENCH_BY_SHAPE"):
             gt.by_shape(os.environ["MPV_BENCH_BY_SHAPE"], nroof)

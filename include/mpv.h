@@ -44,6 +44,13 @@ typedef struct ihipStream_t* mpv_stream_t; /* == hipStream_t */
 #define MPV_ACT_GELU_TANH 2 /* megatron bias_gelu_impl, models/modeling_distributed_gpt3.py:586-588 */
 #define MPV_ACT_RELU 3      /* nn.ReLU of cls_head, models/distributed_gpt3.py:526-530, 1081-1085 */
 
+/* Dropout seeds.  Every `seed` argument / field of this header is a 64-bit value.  A seed with bit 63 CLEAR is the seed itself.
+ * A seed with bit 63 SET (MPV_SEED_FROM_DEVICE(ptr)) carries in its low 63 bits the device address of a uint64_t that holds the
+ * seed; the kernel reads it when it RUNS.  Kernel arguments are frozen when a training step is captured into a HIP graph: the
+ * indirect form is what lets each replay draw fresh masks (the host rewrites the 8 bytes before launching the graph).  Both forms
+ * of the same value produce the same masks. */
+#define MPV_SEED_FROM_DEVICE(ptr) ((uint64_t)(uintptr_t)(ptr) | (1ull << 63))
+
 int mpv_version(void);
 const char* mpv_last_error(void);
 /* 0 if the current device is gfx950, MPV_E_ARCH otherwise */
@@ -215,6 +222,10 @@ int mpv_add(const void* a, const void* b, void* out, int64_t n, mpv_stream_t str
 /* acc (fp32) += g (bf16), n elements: the gradient-accumulation window sum (DeepSpeed's bf16 optimizer keeps it in fp32,
  * run_pretrain_distributed_gpt3.py:46-53 with --update_freq); mpv_f32_to_bf16 rounds the window sum once at the boundary */
 int mpv_accum_f32(float* acc, const void* g, int64_t n, int first, mpv_stream_t stream);
+/* dst[0..n) <- words[0..n) (32-bit, n <= 32), the values travelling BY VALUE in the launch: the host's way to hand per-step
+ * scalars (MPV_SEED_FROM_DEVICE seeds, mpv_adamw_step_grouped_dev's hyper_dev) to the device without a host buffer that must
+ * outlive an asynchronous copy.  Stream-ordered like every other entry point. */
+int mpv_store_words(void* dst, const uint32_t* words, int n, mpv_stream_t stream);
 int mpv_f32_to_bf16(const float* src, void* dst, int64_t n, mpv_stream_t stream);
 /* n independent bf16 copies dst[i][0:count[i]] = src[i][0:count[i]] in ONE launch (host arrays of device pointers): the
  * q / v halves of the packed qkv bias (models/vision_transformer.py:173) of every attention of the tower, and the
@@ -335,6 +346,16 @@ int mpv_adamw_step_grouped(void* param_bf16, float* master, float* exp_avg, floa
                            int64_t n, const uint8_t* tile_group, const float* lrs, const float* wds, int ngroups,
                            float beta1, float beta2, float eps, int step, float grad_scale, const float* sumsq,
                            float max_norm, mpv_stream_t stream);
+
+/* The same step with every STEP-DEPENDENT hyper-parameter read from device memory at kernel run time: hyper_dev[18] =
+ * { lr[8], weight_decay[8], 1 / (1 - beta1^step), 1 / sqrt(1 - beta2^step) }, as written by mpv_adamw_hyper_pack (host; the
+ * bias corrections are computed exactly as mpv_adamw_step_grouped computes them, so both entry points update bit-identically).
+ * Kernel arguments are frozen when a training step is captured into a HIP graph; with this entry point a replay applies the
+ * learning rate of ITS step (the host rewrites the 72 bytes before each replay). */
+int mpv_adamw_hyper_pack(const float* lrs, const float* wds, int ngroups, float beta1, float beta2, int step, float* out18);
+int mpv_adamw_step_grouped_dev(void* param_bf16, float* master, float* exp_avg, float* exp_avg_sq, const void* grad_bf16,
+                               int64_t n, const uint8_t* tile_group, const float* hyper_dev, float beta1, float beta2, float eps,
+                               float grad_scale, const float* sumsq, float max_norm, mpv_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -76,6 +76,8 @@ def train_one_epoch(model, tokenizer, data_loader, optimizer, device, epoch, num
     model.micro_steps = 0
     sums, count = {}, 0
     world = dist.get_world_size()
+    use_graph = os.environ.get("MPV_GRAPH", "0") == "1" and update_freq == 1 and device.type == "cuda" and \
+        (world == 1 or os.environ.get("MPV_GRAPH_DP") == "1")
     for data_iter_step, (video, text) in enumerate(data_loader):
         t0 = time.time()
         step = data_iter_step // update_freq
@@ -93,7 +95,13 @@ def train_one_epoch(model, tokenizer, data_loader, optimizer, device, epoch, num
             text = tokenizer(text, padding="max_length", truncation=True, max_length=args.max_length, return_tensors="pt",
                              add_special_tokens=True)
         text = types.SimpleNamespace(input_ids=text.input_ids.to(device), attention_mask=text.attention_mask.to(device))
-        loss_caption, loss_ita = model(video, text)
+        if use_graph:
+            # MPV_GRAPH=1: forward + backward + optimizer step as ONE replayed HIP graph (engine.graph_step).  The loss is known
+            # only after the step it belongs to has been applied; a non-finite one is handled as below (reload the last checkpoint
+            # or stop), which discards that step either way.
+            loss_caption, loss_ita = model.graph_step(video, text), torch.zeros((), device=device)
+        else:
+            loss_caption, loss_ita = model(video, text)
         loss = loss_caption + loss_ita
         loss_value = loss.item()
         gathered = [torch.zeros_like(loss) for _ in range(world)]
@@ -105,9 +113,10 @@ def train_one_epoch(model, tokenizer, data_loader, optimizer, device, epoch, num
                 model.load_checkpoint(args.output_dir)
                 continue
             raise SystemExit(1)
-        loss = loss / update_freq
-        model.backward(loss)
-        model.step()
+        if not use_graph:
+            loss = loss / update_freq
+            model.backward(loss)
+            model.step()
         grad_norm = optimizer._global_grad_norm
         if device.type == "cuda":
             torch.cuda.synchronize()

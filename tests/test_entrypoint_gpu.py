@@ -86,6 +86,40 @@ def test_entrypoint_three_steps_from_yaml(tmp_path, dev):
     assert torch.equal(seen["engine"].flat.params, e.flat.params) and seen["opt"].step_count == 6
 
 
+def test_entrypoint_graph_mode_matches_eager(tmp_path, dev, monkeypatch):
+    """MPV_GRAPH=1: the entrypoint's loop drives engine.graph_step (one replayed HIP graph per step) -- same per-epoch statistics and
+    bit-identical final parameters as the eager loop from the same seed."""
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(24000 + os.getpid() % 2000))
+    import run_pretrain_distributed_gpt3 as entry
+    from youku_mplug_amd import engine as eng
+    cfg = _write_configs(str(tmp_path))
+    got = {}
+    orig_init = eng.initialize
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MPV_GRAPH", mode)
+        out = str(tmp_path / f"out{mode}")
+        args, config = entry.get_args(["--config", cfg, "--output_dir", out, "--bf16", "--enable_deepspeed", "--synthetic_steps", "4", "--seed", "9"])
+        seen = {}
+
+        def spy(**kw):
+            r = orig_init(**kw)
+            seen["engine"] = r[0]
+            return r
+        eng.initialize, entry.mpv_engine.initialize = spy, spy
+        try:
+            stats = entry.main(args, config)
+        finally:
+            eng.initialize = entry.mpv_engine.initialize = orig_init
+        got[mode] = (stats, seen["engine"].flat.params.clone(), seen["engine"])
+    assert got["1"][2]._graph is not None and got["0"][2]._graph is None
+    # (the gradient norm is a sum of atomically added partial sums: equal to rounding, not to the bit, between ANY two runs)
+    assert got["0"][0]["loss"] == got["1"][0]["loss"] and got["0"][0]["grad_norm"] == pytest.approx(got["1"][0]["grad_norm"], rel=1e-5), (got["0"][0], got["1"][0])
+    assert torch.equal(got["0"][1], got["1"][1])
+    assert got["1"][2].global_steps == got["0"][2].global_steps == 8
+
+
 def test_forward_input_embeds_matches_tokens_path(dev):
     """models/modeling_distributed_gpt3.py:1578-1618 / :652-657: input_embeds = word_embeddings(ids) (with the visual
     queries in front, as models/distributed_gpt3.py:155-166 builds them) gives the logits of the tokens + query_embeds call."""

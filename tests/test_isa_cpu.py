@@ -82,8 +82,8 @@ def test_attention_kernels_budgets(kernels):
             continue
         lean = "ELi320ELi3EE" in n                               # <..., 320, 3>: GPT instances, two 5-wave workgroups per CU, 3 waves per SIMD
         assert k["vgpr"] + (0 if "attn_bwd_dkv_kernel" in n else k["agpr"]) <= (170 if lean else 512), (n, k)
-        # known small spills outside the tile loops (20 / 32 bytes); anything larger is a regression
-        assert k["scratch"] <= (32 if ("attn_bwd_dq_res_kernelILi96ELi7E" in n or "attn_bwd_dkv_res_kernelILi64ELi320E" in n) else 0), (n, k)
+        # known small spill outside the tile loop of the 3-waves-per-SIMD dK/dV instance (48 bytes); anything larger is a regression
+        assert k["scratch"] <= (48 if "attn_bwd_dkv_res_kernelILi64ELi320E" in n else 0), (n, k)
 
 
 def test_paired_causal_attention_kernels_fit_four_items_per_cu(kernels):

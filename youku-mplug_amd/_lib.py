@@ -75,6 +75,7 @@ _SIGS = {
     "mpv_colsum": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64] + _RM + [c_int, c_void_p, c_size_t, c_void_p]),
     "mpv_add": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mpv_accum_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "mpv_store_words": (c_int, [c_void_p, C.POINTER(C.c_uint32), c_int, c_void_p]),
     "mpv_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "mpv_copy_segments": (c_int, [C.POINTER(c_void_p), C.POINTER(c_void_p), C.POINTER(c_int64), c_int, c_void_p]),
     "mpv_vit_compose_bwd_finish": (c_int, [c_void_p] * 6 + [c_int, c_void_p]),
@@ -96,6 +97,9 @@ _SIGS = {
     "mpv_soft_target_ce": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "mpv_grad_sumsq": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "mpv_adamw_step": (c_int, [c_void_p] * 5 + [c_int64] + [c_float] * 5 + [c_int, c_float, c_void_p, c_float, c_void_p]),
+    "mpv_adamw_hyper_pack": (c_int, [C.POINTER(c_float), C.POINTER(c_float), c_int, c_float, c_float, c_int, C.POINTER(c_float)]),
+    "mpv_adamw_step_grouped_dev": (c_int, [c_void_p] * 5 + [c_int64, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_void_p,
+                                           c_float, c_void_p]),
     "mpv_adamw_step_grouped": (c_int, [c_void_p] * 5 + [c_int64, c_void_p, C.POINTER(c_float), C.POINTER(c_float), c_int,
                                        c_float, c_float, c_float, c_int, c_float, c_void_p, c_float, c_void_p]),
 }

@@ -221,6 +221,7 @@ __device__ __forceinline__ int last_visible_key(const AttnArgs& p, int qrow) {
 // =========================================================================== forward
 template <int HD>
 __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs p) {
+  const uint64_t seed_r = p.drop_thr ? mpv_resolve_seed(p.seed) : 0;      // (bit 63 set: the seed lives in device memory, mpv_common.h)
   constexpr int NS = HD / 16;
   constexpr int NDT = (HD + 31) / 32;
   __shared__ __attribute__((aligned(16))) char smem[4 * CHUNK_BYTES];  // [buf][K|V]
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs p) {
         float pr = key <= my_last ? __expf(s[e] * sc - m) * inv_l : 0.f;
         if (p.drop_thr) {
           const uint64_t rb = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qrow) * (uint64_t)p.sk;
-          pr = attn_keep(p.seed, rb, key, p.drop_thr) ? pr * p.drop_scale : 0.f;
+          pr = attn_keep(seed_r, rb, key, p.drop_thr) ? pr * p.drop_scale : 0.f;
         }
         s[e] = pr;
       }
@@ -382,6 +383,7 @@ __device__ __forceinline__ float row_delta(const bf16x8 (&dof)[HD / 16], const b
 // =========================================================================== backward: dQ
 template <int HD>
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttnArgs p) {
+  const uint64_t seed_r = p.drop_thr ? mpv_resolve_seed(p.seed) : 0;      // (bit 63 set: the seed lives in device memory, mpv_common.h)
   constexpr int NS = HD / 16;
   constexpr int NDT = (HD + 31) / 32;
   __shared__ __attribute__((aligned(16))) char smem[4 * CHUNK_BYTES];
@@ -452,7 +454,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttnArgs p) {
         float dpe = dp[e];
         if (p.drop_thr) {
           const uint64_t rb = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qrow) * (uint64_t)p.sk;
-          dpe = attn_keep(p.seed, rb, key, p.drop_thr) ? dpe * p.drop_scale : 0.f;
+          dpe = attn_keep(seed_r, rb, key, p.drop_thr) ? dpe * p.drop_scale : 0.f;
         }
         s[e] = pr * (dpe - dl);
       }
@@ -490,6 +492,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttnArgs p) {
 // =========================================================================== backward: dK, dV
 template <int HD>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
+  const uint64_t seed_r = p.drop_thr ? mpv_resolve_seed(p.seed) : 0;      // (bit 63 set: the seed lives in device memory, mpv_common.h)
   constexpr int NS = HD / 16;
   constexpr int NDT = (HD + 31) / 32;
   // [buf][Q|dO] chunks + [buf][lse|delta] rows
@@ -584,7 +587,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
         float keep = 1.0f;
         if (p.drop_thr) {
           const uint64_t rb = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qr) * (uint64_t)p.sk;
-          keep = attn_keep(p.seed, rb, krow, p.drop_thr) ? p.drop_scale : 0.f;
+          keep = attn_keep(seed_r, rb, krow, p.drop_thr) ? p.drop_scale : 0.f;
         }
         pd[e] = pr * keep;
         s[e] = pr * (dp[e] * keep - sl[CH + ql_]);
@@ -684,6 +687,7 @@ __device__ __forceinline__ int region_bytes(int rows, int pitch) { return (((row
 // left the kernel latency-bound: MFMA pipe 4 % busy).
 template <int HD, int NTC = 0, int NTMAX = 8, int THREADS = 512, int WPE = 1>
 __global__ __launch_bounds__(THREADS, WPE) void attn_fwd_res_kernel(const AttnArgs p) {
+  const uint64_t seed_r = p.drop_thr ? mpv_resolve_seed(p.seed) : 0;      // (bit 63 set: the seed lives in device memory, mpv_common.h)
   constexpr int NS = HD / 16;
   constexpr int NDT = (HD + 31) / 32;
   extern __shared__ __attribute__((aligned(1024))) char rsm[];
@@ -774,7 +778,7 @@ __global__ __launch_bounds__(THREADS, WPE) void attn_fwd_res_kernel(const AttnAr
         const uint64_t rb = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qrow) * (uint64_t)p.sk;
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {      // registers e, e+1 hold keys k, k+1 with k even: one hash per pair
-          const uint32_t r = mpv_rand_pair(p.seed, rb + (uint64_t)(kt * 32 + acc_row(e, lane)));
+          const uint32_t r = mpv_rand_pair(seed_r, rb + (uint64_t)(kt * 32 + acc_row(e, lane)));
           pr[e] = (r & 0xffffu) >= p.drop_thr ? pr[e] * p.drop_scale : 0.f;
           pr[e + 1] = (r >> 16) >= p.drop_thr ? pr[e + 1] * p.drop_scale : 0.f;
         }
@@ -811,6 +815,7 @@ __global__ __launch_bounds__(THREADS, WPE) void attn_fwd_res_kernel(const AttnAr
 // NTC as in the forward kernel: compile-time key-tile count (non-causal, no dropout) -> straight-line tile loop.
 template <int HD, int NTC = 0, int THREADS = 512, int WPE = 1>
 __global__ __launch_bounds__(THREADS, WPE) void attn_bwd_dq_res_kernel(const AttnArgs p) {
+  const uint64_t seed_r = p.drop_thr ? mpv_resolve_seed(p.seed) : 0;      // (bit 63 set: the seed lives in device memory, mpv_common.h)
   constexpr int NS = HD / 16;
   constexpr int NDT = (HD + 31) / 32;
   extern __shared__ __attribute__((aligned(1024))) char rsm[];
@@ -890,7 +895,7 @@ __global__ __launch_bounds__(THREADS, WPE) void attn_bwd_dq_res_kernel(const Att
       for (int e = 0; e < 16; e += 2) {      // registers e, e+1 hold keys k, k+1 with k even: one hash word per pair (attn_keep)
         const int key = kt * 32 + acc_row(e, lane);
         uint32_t r = 0xffffffffu;
-        if (NTC == 0 && p.drop_thr) r = mpv_rand_pair(p.seed, rb + (uint64_t)key);
+        if (NTC == 0 && p.drop_thr) r = mpv_rand_pair(seed_r, rb + (uint64_t)key);
         const float p0 = key <= my_last ? fexp2(s[e] * c2 - lse2) : 0.f;
         const float p1 = key + 1 <= my_last ? fexp2(s[e + 1] * c2 - lse2) : 0.f;
         const float d0 = (r & 0xffffu) >= p.drop_thr ? dp[e] * p.drop_scale : 0.f;      // drop_thr = 0: kept, drop_scale = 1
@@ -937,6 +942,7 @@ __global__ __launch_bounds__(THREADS, WPE) void attn_bwd_dq_res_kernel(const Att
 // form on the GPT shape)
 template <int HD, int THREADS, int WPE = 1>
 __global__ __launch_bounds__(THREADS, WPE) void attn_bwd_dkv_res_kernel(const AttnArgs p) {
+  const MpvSeedKeys seed_k = mpv_seed_keys(p.drop_thr ? mpv_resolve_seed(p.seed) : 0);      // (bit 63 set: the seed lives in device memory, mpv_common.h)
   constexpr int NS = HD / 16;
   constexpr int NDT = (HD + 31) / 32;
   extern __shared__ __attribute__((aligned(1024))) char rsm[];
@@ -1068,7 +1074,8 @@ __global__ __launch_bounds__(THREADS, WPE) void attn_bwd_dkv_res_kernel(const At
             float keep = 1.0f;
             if (p.drop_thr) {
               const uint64_t rb = p.offset + ((uint64_t)bh * p.sq + (uint64_t)qr) * (uint64_t)p.sk;
-              keep = attn_keep(p.seed, rb, krow, p.drop_thr) ? p.drop_scale : 0.f;
+              const uint32_t rw = mpv_rand_pair_k(seed_k, rb + (uint64_t)(krow & ~1));      // (= attn_keep)
+              keep = ((krow & 1) ? rw >> 16 : rw & 0xffffu) >= p.drop_thr ? p.drop_scale : 0.f;
             }
             pr8[4 * qh + j] = vis ? pr * keep : 0.f;
             ds8[4 * qh + j] = vis ? pr * (dp[e] * keep - d4[j]) : 0.f;

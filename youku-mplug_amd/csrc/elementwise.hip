@@ -278,6 +278,7 @@ __global__ void gpt_embed_fwd_kernel(const bf16* __restrict__ query, const int64
                                      float drop_scale, uint32_t thr, uint64_t seed, uint64_t offset) {
   const int H8 = H / 8, S = Q + L;
   const long long total = (long long)B * S * H8;
+  const uint64_t seed_r = thr ? mpv_resolve_seed(seed) : 0;      // (bit 63 set: the seed lives in device memory, mpv_common.h)
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const int c8 = (int)(idx % H8);
     const long long row = idx / H8;
@@ -289,7 +290,7 @@ __global__ void gpt_embed_fwd_kernel(const bf16* __restrict__ query, const int64
     if (thr) {
       v = cvt8(cvt8(v));
       const uint64_t base = offset + (uint64_t)row * (uint64_t)H + (uint64_t)(c8 * 8);
-      v = mpv_dropout_vec<f32x8, 8>(v, seed, base, thr, drop_scale);
+      v = mpv_dropout_vec<f32x8, 8>(v, seed_r, base, thr, drop_scale);
     }
     *(bf16x8*)(h + row * H + c8 * 8) = cvt8(v);
   }
@@ -298,6 +299,7 @@ __global__ void gpt_embed_bwd_kernel(const bf16* __restrict__ dh, bf16* __restri
                                      float drop_scale, uint32_t thr, uint64_t seed, uint64_t offset) {
   const int H8 = H / 8, S = Q + L;
   const long long total = (long long)B * Q * H8;
+  const uint64_t seed_r = thr ? mpv_resolve_seed(seed) : 0;      // (bit 63 set: the seed lives in device memory, mpv_common.h)
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const int c8 = (int)(idx % H8);
     const long long qrow = idx / H8;
@@ -307,7 +309,7 @@ __global__ void gpt_embed_bwd_kernel(const bf16* __restrict__ dh, bf16* __restri
     f32x8 v = cvt8(*(const bf16x8*)(dh + row * H + c8 * 8));
     if (thr) {
       const uint64_t base = offset + (uint64_t)row * (uint64_t)H + (uint64_t)(c8 * 8);
-      v = mpv_dropout_vec<f32x8, 8>(v, seed, base, thr, drop_scale);
+      v = mpv_dropout_vec<f32x8, 8>(v, seed_r, base, thr, drop_scale);
     }
     *(bf16x8*)(dquery + qrow * H + c8 * 8) = cvt8(v);
   }

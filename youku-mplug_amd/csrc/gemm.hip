@@ -99,6 +99,7 @@ struct Loader {
 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
+  const uint64_t seed_r = p.drop_thr ? mpv_resolve_seed(p.seed) : 0;      // (bit 63 set: the seed lives in device memory, mpv_common.h)
   __shared__ __attribute__((aligned(1024))) char smem[4 * TILE_BYTES];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
         }
         if (p.drop_thr) {
           const uint64_t base = p.drop_offset + (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
-          v = mpv_dropout_vec<f32x8, 8>(v, p.seed, base, p.drop_thr, p.drop_scale);
+          v = mpv_dropout_vec<f32x8, 8>(v, seed_r, base, p.drop_thr, p.drop_scale);
         }
         if (p.residual) v += cvt8(*(const bf16x8*)(p.residual + crow * p.ldr + n));
         bf16* cp = (bf16*)p.C + crow * p.ldc + n;

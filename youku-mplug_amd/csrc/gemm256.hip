@@ -131,6 +131,7 @@ __device__ __forceinline__ void finish_rows(const GemmArgs& p, const EpExt<KIND,
   constexpr int JW = NIT % 4 == 0 ? 4 : 2, HN = NIT / JW;      // rolled outer loop x unrolled inner loop (code size)
   static_assert(HN >= 3 && HN <= 5, "nested selects below");
   const bf16x8* ext = x.v;
+  const uint64_t seed_r = p.drop_thr ? mpv_resolve_seed(p.seed) : 0;      // (bit 63 set: the seed lives in device memory, mpv_common.h)
 #pragma unroll 1
   for (int h = 0; h < HN; ++h)
 #pragma unroll
@@ -161,11 +162,11 @@ __device__ __forceinline__ void finish_rows(const GemmArgs& p, const EpExt<KIND,
         *(bf16x8*)cp = cvt8(cvt8(zb) + cvt8(ex));
       } else if constexpr (KIND == EP_DROP_RES) {
         const uint64_t base = p.drop_offset + (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
-        const f32x8 v = mpv_dropout_vec<f32x8, 8>(cvt8(zb), p.seed, base, p.drop_thr, p.drop_scale);
+        const f32x8 v = mpv_dropout_vec<f32x8, 8>(cvt8(zb), seed_r, base, p.drop_thr, p.drop_scale);
         *(bf16x8*)cp = cvt8(v + cvt8(ex));
       } else if constexpr (KIND == EP_DROP) {       // dropout(acc + bias): the decoder's sublayer outputs (the residual add is the next LayerNorm's, in fp32)
         const uint64_t base = p.drop_offset + (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
-        *(bf16x8*)cp = cvt8(mpv_dropout_vec<f32x8, 8>(cvt8(zb), p.seed, base, p.drop_thr, p.drop_scale));
+        *(bf16x8*)cp = cvt8(mpv_dropout_vec<f32x8, 8>(cvt8(zb), seed_r, base, p.drop_thr, p.drop_scale));
       } else {
         f32x8 v = cvt8(zb);
         if (p.tap_out && m % p.tap_group == 0) *(bf16x8*)(p.tap_out + (long long)(m / p.tap_group) * p.N + n) = zb;
@@ -180,7 +181,7 @@ __device__ __forceinline__ void finish_rows(const GemmArgs& p, const EpExt<KIND,
         }
         if (p.drop_thr) {
           const uint64_t base = p.drop_offset + (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
-          v = mpv_dropout_vec<f32x8, 8>(v, p.seed, base, p.drop_thr, p.drop_scale);
+          v = mpv_dropout_vec<f32x8, 8>(v, seed_r, base, p.drop_thr, p.drop_scale);
         }
         if (p.residual) v += cvt8(*(const bf16x8*)(p.residual + crow * p.ldr + n));
         if (p.accumulate) v += cvt8(*(const bf16x8*)cp);

@@ -169,6 +169,17 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
 }
 unsigned stream_grid(long long n8) { return (unsigned)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192); }
 
+// up to WORDS_MAX 32-bit words, passed BY VALUE in the kernel arguments, to device memory: how the host hands a step's
+// scalars (dropout seeds, AdamW hyper-parameters) to kernels that read them from memory (mpv_store_words).  No host buffer
+// has to outlive the call, unlike an asynchronous copy from pinned memory issued by a host that runs steps ahead of the device.
+constexpr int WORDS_MAX = 32;
+struct WordArgs {
+  uint32_t w[WORDS_MAX];
+};
+__global__ void store_words_kernel(uint32_t* __restrict__ dst, WordArgs a, int n) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = a.w[threadIdx.x];
+}
+
 }  // namespace
 
 extern "C" int mpv_accum_f32(float* acc, const void* g, int64_t n, int first, hipStream_t stream) {
@@ -187,6 +198,14 @@ extern "C" int mpv_f32_to_bf16(const float* src, void* dst, int64_t n, hipStream
   if (n == 0) return MPV_OK;
   hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(stream_grid(n / 8)), dim3(256), 0, stream, src, (bf16*)dst, (long long)(n / 8));
   return mpv_check_launch("mpv_f32_to_bf16");
+}
+
+extern "C" int mpv_store_words(void* dst, const uint32_t* words, int n, hipStream_t stream) {
+  MPV_REQUIRE(dst && words && n >= 1 && n <= WORDS_MAX && ((uintptr_t)dst & 3) == 0, MPV_E_ARG, "mpv_store_words: 1..%d words to a 4-byte aligned address", WORDS_MAX);
+  WordArgs a = {};
+  for (int i = 0; i < n; ++i) a.w[i] = words[i];
+  hipLaunchKernelGGL(store_words_kernel, dim3(1), dim3(64), 0, stream, (uint32_t*)dst, a, n);
+  return mpv_check_launch("mpv_store_words");
 }
 
 extern "C" int mpv_copy_segments(const void* const* src, void* const* dst, const int64_t* count, int n, hipStream_t stream) {

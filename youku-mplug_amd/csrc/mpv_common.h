@@ -83,6 +83,30 @@ __host__ __device__ __forceinline__ uint32_t mpv_rand_pair(uint64_t seed, uint64
   const uint32_t ka = mpv_mix32((uint32_t)seed), kb = mpv_mix32((uint32_t)(seed >> 32) ^ 0x85ebca6bu);
   return mpv_mix32(((uint32_t)ctr + ka) ^ ((uint32_t)(ctr >> 32) + kb));
 }
+// Indirect seeds (include/mpv.h, "dropout seeds"): a seed argument with bit 63 set carries the DEVICE address of the 64-bit seed in
+// its low 63 bits; the kernel reads it when it runs.  Kernel arguments are frozen when a step is captured into a HIP graph --
+// this is what lets a replay draw fresh masks (the engine rewrites the 8 bytes before every replay).  Wave-uniform: one scalar load.
+#define MPV_SEED_INDIRECT_BIT (1ull << 63)
+__device__ __forceinline__ uint64_t mpv_resolve_seed(uint64_t s) {
+#ifdef MPV_AB_DIRECT_SEED      // measurement build only (cost of the indirection: tools/ab_same_box.sh lib ...)
+  return s;
+#else
+  if (!(s & MPV_SEED_INDIRECT_BIT)) return s;
+  return *(const uint64_t*)(uintptr_t)(s & ~MPV_SEED_INDIRECT_BIT);
+#endif
+}
+// The seed's two hashed halves, for kernels that keep them in SCALAR registers over a long loop (readfirstlane: the value is
+// wave-uniform, but the compiler does not always know it and parks it in VGPRs of kernels that have none to spare).
+struct MpvSeedKeys {
+  uint32_t ka, kb;
+};
+__device__ __forceinline__ MpvSeedKeys mpv_seed_keys(uint64_t seed) {
+  return MpvSeedKeys{(uint32_t)__builtin_amdgcn_readfirstlane((int)mpv_mix32((uint32_t)seed)),
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)mpv_mix32((uint32_t)(seed >> 32) ^ 0x85ebca6bu))};
+}
+__device__ __forceinline__ uint32_t mpv_rand_pair_k(MpvSeedKeys k, uint64_t ctr) {      // == mpv_rand_pair(seed, ctr)
+  return mpv_mix32(((uint32_t)ctr + k.ka) ^ ((uint32_t)(ctr >> 32) + k.kb));
+}
 // keep-threshold on 16 bits: keep iff r16 >= p * 2^16
 __host__ __device__ __forceinline__ uint32_t mpv_drop_threshold(float p) {
   return (uint32_t)(p * 65536.0f + 0.5f);

@@ -98,6 +98,7 @@ struct LnBwdArgs {
 
 template <int MAXC, bool DPARAM>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p) {
+  const uint64_t seed_r = p.drop_thr ? mpv_resolve_seed(p.seed) : 0;      // (bit 63 set: the seed lives in device memory, mpv_common.h)
   __shared__ float red[DPARAM ? 2 * MAXC * 256 : 1];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p) {
         if (ddr) {
           const f32x4 of = cvt4(ob);
           const uint64_t base = p.offset + (uint64_t)r * (uint64_t)p.cols + (uint64_t)(c * 4);
-          const f32x4 od = p.drop_thr ? mpv_dropout_vec<f32x4, 4>(of, p.seed, base, p.drop_thr, p.drop_scale) : of * p.drop_scale;
+          const f32x4 od = p.drop_thr ? mpv_dropout_vec<f32x4, 4>(of, seed_r, base, p.drop_thr, p.drop_scale) : of * p.drop_scale;
           *(bf16x4*)(ddr + c * 4) = cvt4(od);
         }
       }
@@ -279,6 +280,7 @@ __global__ __launch_bounds__(256) void ln_fwd8_kernel(const LnFwdArgs p) {
 // XF32: x is the decoder's fp32 residual stream (mpv_ln_stream_bwd); dy / dres / dx stay bf16.
 template <int MAXC, bool XF32 = false>
 __global__ __launch_bounds__(256) void ln_bwd8_plain_kernel(const LnBwdArgs p) {
+  const uint64_t seed_r = p.drop_thr ? mpv_resolve_seed(p.seed) : 0;      // (bit 63 set: the seed lives in device memory, mpv_common.h)
   constexpr bool DPARAM = false;
   __shared__ float red[DPARAM ? 2 * MAXC * 512 : 1];
   const int lane = threadIdx.x & 63;
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(256) void ln_bwd8_plain_kernel(const LnBwdArgs p) {
         if (ddr) {
           const f32x8 of = cvt8(ob);
           const uint64_t base = p.offset + (uint64_t)r * (uint64_t)p.cols + (uint64_t)(c * 8);
-          const f32x8 od = p.drop_thr ? mpv_dropout_vec<f32x8, 8>(of, p.seed, base, p.drop_thr, p.drop_scale) : of * p.drop_scale;
+          const f32x8 od = p.drop_thr ? mpv_dropout_vec<f32x8, 8>(of, seed_r, base, p.drop_thr, p.drop_scale) : of * p.drop_scale;
           *(bf16x8*)(ddr + c * 8) = cvt8(od);
         }
       }
@@ -382,6 +384,7 @@ __global__ __launch_bounds__(256) void ln_bwd8_plain_kernel(const LnBwdArgs p) {
 // waves per SIMD the register allocation is held to: 4 (128 VGPRs) where that fits without scratch
 template <int MAXC, bool DPARAM>
 __global__ __launch_bounds__(256, MAXC <= 2 ? 4 : MAXC <= 3 ? 2 : 1) void ln_bwd8_kernel(const LnBwdArgs p) {
+  const uint64_t seed_r = p.drop_thr ? mpv_resolve_seed(p.seed) : 0;      // (bit 63 set: the seed lives in device memory, mpv_common.h)
   __shared__ float red[DPARAM ? 2 * MAXC * 512 : 1];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: row pointers and statistics live in SGPRs
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(256, MAXC <= 2 ? 4 : MAXC <= 3 ? 2 : 1) void ln_bwd
         if (ddr) {
           const f32x8 of = cvt8(ob);
           const uint64_t base = p.offset + (uint64_t)r * (uint64_t)p.cols + (uint64_t)(c * 8);
-          const f32x8 od = p.drop_thr ? mpv_dropout_vec<f32x8, 8>(of, p.seed, base, p.drop_thr, p.drop_scale) : of * p.drop_scale;
+          const f32x8 od = p.drop_thr ? mpv_dropout_vec<f32x8, 8>(of, seed_r, base, p.drop_thr, p.drop_scale) : of * p.drop_scale;
           *(bf16x8*)(ddr + c * 8) = cvt8(od);
         }
       }

@@ -65,7 +65,17 @@ __global__ __launch_bounds__(256) void adamw_grouped_kernel(bf16* __restrict__ p
                                                             float* __restrict__ v, const bf16* __restrict__ g, long long ntiles,
                                                             const uint8_t* __restrict__ tile_group, GroupHyper hp, float b1,
                                                             float b2, float eps, float inv_bc1, float inv_sqrt_bc2,
-                                                            float grad_scale, const float* __restrict__ sumsq, float max_norm) {
+                                                            float grad_scale, const float* __restrict__ sumsq, float max_norm,
+                                                            const float* __restrict__ hyper_dev) {
+  if (hyper_dev) {      // step-dependent hyper-parameters from device memory (mpv_adamw_step_grouped_dev): lr[8], wd[8], 1/bc1, 1/sqrt(bc2)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      hp.lr[i] = hyper_dev[i];
+      hp.wd[i] = hyper_dev[8 + i];
+    }
+    inv_bc1 = hyper_dev[16];
+    inv_sqrt_bc2 = hyper_dev[17];
+  }
   float gs = grad_scale;
   if (sumsq && max_norm > 0.f) {
     const float norm = sqrtf(*sumsq) * grad_scale;
@@ -119,8 +129,38 @@ extern "C" int mpv_adamw_step_grouped(void* param_bf16, float* master, float* ex
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(adamw_grouped_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (bf16*)param_bf16, master, exp_avg,
                      exp_avg_sq, (const bf16*)grad_bf16, ntiles, tile_group, hp, beta1, beta2, eps, (float)(1.0 / bc1),
-                     (float)(1.0 / sqrt(bc2)), grad_scale, sumsq, max_norm);
+                     (float)(1.0 / sqrt(bc2)), grad_scale, sumsq, max_norm, (const float*)nullptr);
   return mpv_check_launch("mpv_adamw_step_grouped");
+}
+
+extern "C" int mpv_adamw_hyper_pack(const float* lrs, const float* wds, int ngroups, float beta1, float beta2, int step, float* out18) {
+  MPV_REQUIRE(lrs && wds && out18 && ngroups >= 1 && ngroups <= 8 && step >= 1, MPV_E_ARG, "mpv_adamw_hyper_pack: bad argument");
+  for (int i = 0; i < 8; ++i) {
+    out18[i] = i < ngroups ? lrs[i] : 0.f;
+    out18[8 + i] = i < ngroups ? wds[i] : 0.f;
+  }
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);      // exactly as mpv_adamw_step_grouped
+  out18[16] = (float)(1.0 / bc1);
+  out18[17] = (float)(1.0 / sqrt(bc2));
+  return MPV_OK;
+}
+
+extern "C" int mpv_adamw_step_grouped_dev(void* param_bf16, float* master, float* exp_avg, float* exp_avg_sq,
+                                          const void* grad_bf16, int64_t n, const uint8_t* tile_group, const float* hyper_dev,
+                                          float beta1, float beta2, float eps, float grad_scale, const float* sumsq,
+                                          float max_norm, hipStream_t stream) {
+  MPV_REQUIRE(param_bf16 && master && exp_avg && exp_avg_sq && grad_bf16 && tile_group && hyper_dev, MPV_E_ARG,
+              "mpv_adamw_step_grouped_dev: null pointer");
+  MPV_REQUIRE(n >= 0 && n % 256 == 0, MPV_E_SHAPE, "mpv_adamw_step_grouped_dev: n (%lld) must be a multiple of the 256-element tile", (long long)n);
+  if (n == 0) return MPV_OK;
+  GroupHyper hp = {};
+  const long long ntiles = n / 256;
+  long long blocks = (ntiles + 3) / 4;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(adamw_grouped_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (bf16*)param_bf16, master, exp_avg,
+                     exp_avg_sq, (const bf16*)grad_bf16, ntiles, tile_group, hp, beta1, beta2, eps, 1.0f, 1.0f, grad_scale, sumsq,
+                     max_norm, hyper_dev);
+  return mpv_check_launch("mpv_adamw_step_grouped_dev");
 }
 
 extern "C" int mpv_grad_sumsq(const void* grad, int64_t n, float* sumsq, hipStream_t stream) {

@@ -177,22 +177,37 @@ class FlatAdamW:
         self.step_count = 0
         self.cur_scale = self.loss_scale = 1.0
         self._grad_scale = 1.0
+        self.hyper_dev = None      # MplugEngine.enable_device_step_state(): float32[18] device tensor
 
     @property
     def _global_grad_norm(self):
         return math.sqrt(max(float(self.sumsq.item()), 0.0)) * self._grad_scale
 
-    def step(self, grad_scale: float = 1.0):
+    def step(self, grad_scale: float = 1.0, upload: bool = True):
         from . import ops
         self.step_count += 1
         self._grad_scale = grad_scale
         self.sumsq.zero_()
         ops.grad_sumsq(self.flat.grads, self.sumsq)
         g0 = self.param_groups[0]
+        if self.hyper_dev is not None:
+            if upload:                                     # (not while a graph is being captured: the values would be frozen with it)
+                self.upload_hyper()
+            ops.adamw_step_grouped_dev(self.flat.params, self.master, self.exp_avg, self.exp_avg_sq, self.flat.grads, self.flat.tile_group,
+                                       self.hyper_dev, float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]), grad_scale,
+                                       self.sumsq, float(self.clip_grad or 0.0))
+            return
         ops.adamw_step_grouped(self.flat.params, self.master, self.exp_avg, self.exp_avg_sq, self.flat.grads, self.flat.tile_group,
                                [float(g["lr"]) for g in self.param_groups], [float(g["weight_decay"]) for g in self.param_groups],
                                float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]), self.step_count, grad_scale,
                                self.sumsq, float(self.clip_grad or 0.0))
+
+    def upload_hyper(self):
+        """this step's lr / weight decay (param_groups, mutated by the training loop) and bias corrections (step_count) -> device"""
+        from . import ops
+        g0 = self.param_groups[0]
+        ops.adamw_hyper_upload([float(g["lr"]) for g in self.param_groups], [float(g["weight_decay"]) for g in self.param_groups],
+                               float(g0["betas"][0]), float(g0["betas"][1]), self.step_count, self.hyper_dev)
 
     def state_dict(self):
         return {"master": self.master, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count,
@@ -265,6 +280,9 @@ class MplugEngine(nn.Module):
         self._window_fill = 0                 # micro-batches summed into the current accumulation window
         self.micro_batches_seen = 0           # never reset, saved with the optimizer state: drives the dropout seed
         self.global_steps = 0
+        self._upload_seeds = True
+        self._graph = None                    # graph_step(): (torch.cuda.CUDAGraph, static inputs, static loss)
+        self._graph_calls = 0
         self._set_dropout_seed()              # rank-distinct masks from the very first micro-batch on
         ve = getattr(model, "visual_encoder", None)
         if ve is not None and hasattr(ve, "on_block_grads_ready"):
@@ -308,7 +326,11 @@ class MplugEngine(nn.Module):
             x ^= x >> 27
             x = (x * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
             x ^= x >> 31
-            td.step_seed = x & 0x7FFFFFFFFFFFFFFF
+            td.step_seed = x & 0x3FFFFFFFFFFFFFFF      # bit 63 clear also after the per-pass stride is added (bit 63 set = indirect seed)
+            if getattr(td, "seed_dev", None) is not None and self._upload_seeds:
+                from . import ops
+                from .gpt3 import SEED_PASS_STRIDE
+                ops.store_u64(td.seed_dev, [td.step_seed + k * SEED_PASS_STRIDE for k in range(td.seed_dev.numel())])
 
     def step(self):
         if not self.is_gradient_accumulation_boundary():
@@ -323,6 +345,90 @@ class MplugEngine(nn.Module):
 
     def zero_grad(self):
         pass      # every gradient is overwritten (never accumulated) by the next backward
+
+    # ---- the step as ONE replayed HIP graph (MPV_GRAPH=1 in bench.py / the entrypoints) -------------------------------------
+    def enable_device_step_state(self):
+        """From here on the scalars that change from step to step are read by the kernels from DEVICE memory instead of travelling
+        in the launches: the dropout seeds (include/mpv.h: MPV_SEED_FROM_DEVICE) and AdamW's learning rates / weight decays / bias
+        corrections (mpv_adamw_step_grouped_dev).  The host writes them before each step with mpv_store_words.  Same values, same
+        arithmetic: an eager step in this mode is bit-identical to one without it -- and it is the precondition for capturing the
+        step into a graph, whose kernel arguments are frozen."""
+        td = getattr(self.module, "text_decoder", None)
+        dev = self.flat.device
+        if td is not None and hasattr(td, "step_seed") and getattr(td, "seed_dev", None) is None:
+            td.seed_dev = torch.zeros(4, dtype=torch.int64, device=dev)
+        if self.optimizer.hyper_dev is None:
+            self.optimizer.hyper_dev = torch.zeros(18, dtype=torch.float32, device=dev)
+        self._set_dropout_seed()
+
+    def graph_step(self, *inputs):
+        """forward + backward + optimizer step of one micro-batch; from the third call on a replay of a captured HIP graph.
+        Call 1 runs eagerly (every lazily created buffer and kernel attribute exists afterwards), call 2 captures the step and
+        replays it, later calls copy the inputs into the captured buffers, write the step's scalars and replay.  Shapes must
+        not change between calls (pre-training: they do not).  Returns the loss tensor of the step (a static buffer from call
+        2 on).  No gradient accumulation; world size 1 unless MPV_GRAPH_DP=1 says the collectives may be captured too."""
+        assert self.gas == 1, "graph_step: no gradient accumulation"
+        assert self.reducer.world == 1 or os.environ.get("MPV_GRAPH_DP") == "1", "graph_step: data-parallel capture is opt-in (MPV_GRAPH_DP=1)"
+        self.enable_device_step_state()
+        self._graph_calls += 1
+
+        assert hasattr(self.module, "forward_backward"), "graph_step needs the model's autograd-free forward_backward()"
+
+        def run(args):
+            self.reducer.hold = False
+            loss = self.module.forward_backward(*args)       # (not module(...) + loss.backward(): see forward_backward)
+            self.reducer.finish()
+            self.optimizer.step(grad_scale=1.0 / self.reducer.world, upload=False)
+            return loss
+
+        def after():
+            self.micro_steps += 1
+            self.micro_batches_seen += 1
+            self.global_steps += 1
+            self._set_dropout_seed()           # next step's seeds -> device (stream-ordered behind this step)
+
+        def clone_in(x):
+            if torch.is_tensor(x):
+                return x.clone()
+            if hasattr(x, "__dict__"):
+                return type(x)(**{k: clone_in(v) for k, v in vars(x).items()})
+            return x
+
+        def copy_in(dst, src):
+            if torch.is_tensor(dst):
+                dst.copy_(src, non_blocking=True)
+            elif hasattr(dst, "__dict__"):
+                for k, v in vars(dst).items():
+                    copy_in(v, getattr(src, k))
+
+        if self._graph_calls == 1:
+            self.optimizer.step_count += 1
+            self.optimizer.upload_hyper()
+            self.optimizer.step_count -= 1
+            loss = run(inputs)
+            after()
+            return loss
+        if self._graph is None:
+            static_in = tuple(clone_in(x) for x in inputs)
+            counters = (self.optimizer.step_count,)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            self._upload_seeds = False
+            try:
+                with torch.cuda.graph(g):
+                    static_loss = run(static_in)
+            finally:
+                self._upload_seeds = True
+            (self.optimizer.step_count,) = counters          # the capture executed nothing
+            self._graph = (g, static_in, static_loss)
+        g, static_in, static_loss = self._graph
+        for d, s_ in zip(static_in, inputs):
+            copy_in(d, s_)
+        self.optimizer.step_count += 1
+        self.optimizer.upload_hyper()                        # this step's lr / bias corrections -> device
+        g.replay()
+        after()
+        return static_loss
 
     # ---- DeepSpeed-layout checkpoints: <dir>/<tag>/mp_rank_00_model_states.pt with key 'module' (utils.py:476-480)
     def save_checkpoint(self, save_dir, tag=None, client_state=None):

@@ -28,6 +28,8 @@ from .ops import ACT_GELU_TANH
 from .vision import Linear, _param
 
 
+SEED_PASS_STRIDE = 0x51ED2705      # seed of decoder pass k of a step = step_seed + k * SEED_PASS_STRIDE
+
 class GPT3Config:
     """Field names of configs/models/config_gpt3_*.json; every GPT3Config default (:463-496) overridable."""
 
@@ -175,6 +177,7 @@ class DistributedGPT3(nn.Module):
                 self.dist_model.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()})
         self.inference_params = None
         self.step_seed = 0        # bumped by the engine every step -> fresh dropout masks
+        self.seed_dev = None      # engine.enable_device_step_state(): int64[4] device tensor, seed of decoder pass k of this step
 
     # -------------------------------------------------------------- explicit forward / backward
     def forward_lm(self, query_features: Optional[torch.Tensor], ids: torch.Tensor, labels: Optional[torch.Tensor],
@@ -199,7 +202,10 @@ class DistributedGPT3(nn.Module):
         train = self.training
         p_h = cfg.hidden_dropout if train else 0.0
         p_a = cfg.attention_dropout if train else 0.0
-        seed = self.step_seed + 0x51ED2705 * pass_index     # a second decoder pass of one step draws its own dropout masks
+        seed = self.step_seed + SEED_PASS_STRIDE * pass_index     # a second decoder pass of one step draws its own dropout masks
+        if self.seed_dev is not None:       # the same value, read by the kernels from device memory (include/mpv.h: MPV_SEED_FROM_DEVICE)
+            assert pass_index < self.seed_dev.numel()
+            seed = (self.seed_dev.data_ptr() + 8 * pass_index) | (1 << 63)
         ids_dev = ids.contiguous() if L > 0 else torch.zeros(1, dtype=torch.long, device=ids.device)   # never dereferenced when L == 0
         h = ops.gpt_embed_fwd(query_features, ids_dev, lm.embedding.word_embeddings.weight,
                               lm.embedding.position_embeddings.weight, B, Q, L, H, dropout_p=p_h, seed=seed,

@@ -419,6 +419,36 @@ def adamw_step_grouped(p16, master, m, v, g16, tile_group, lrs, wds, beta1, beta
                                             grad_scale, _p(sumsq), max_norm, _stream()), "mpv_adamw_step_grouped")
 
 
+def store_words(dst: torch.Tensor, words):
+    """dst (device, 4-byte aligned) <- up to 32 32-bit words, by value in the launch (include/mpv.h: mpv_store_words)"""
+    n = len(words)
+    check(_lib.lib().mpv_store_words(dst.data_ptr(), (C.c_uint32 * n)(*words), n, _stream()), "mpv_store_words")
+
+
+def store_u64(dst: torch.Tensor, values):
+    words = []
+    for v in values:
+        v &= 0xFFFFFFFFFFFFFFFF
+        words += [v & 0xFFFFFFFF, v >> 32]
+    store_words(dst, words)
+
+
+def adamw_hyper_upload(lrs, wds, beta1, beta2, step, hyper_dev: torch.Tensor):
+    """hyper_dev (device float32[18]) <- lr[8], wd[8], 1/(1-beta1^step), 1/sqrt(1-beta2^step), exactly as the by-value entry computes them"""
+    n = len(lrs)
+    arr = (C.c_float * n)
+    out = (C.c_float * 18)()
+    check(_lib.lib().mpv_adamw_hyper_pack(arr(*lrs), arr(*wds), n, beta1, beta2, step, out), "mpv_adamw_hyper_pack")
+    store_words(hyper_dev, list((C.c_uint32 * 18).from_buffer(out)))
+
+
+def adamw_step_grouped_dev(p16, master, m, v, g16, tile_group, hyper_dev, beta1, beta2, eps, grad_scale=1.0, sumsq=None, max_norm=0.0):
+    """adamw_step_grouped with lr / weight decay / bias corrections read from device memory (hyper_dev float32[18]): include/mpv.h"""
+    check(_lib.lib().mpv_adamw_step_grouped_dev(p16.data_ptr(), master.data_ptr(), m.data_ptr(), v.data_ptr(), g16.data_ptr(),
+                                                p16.numel(), tile_group.data_ptr(), hyper_dev.data_ptr(), beta1, beta2, eps, grad_scale,
+                                                _p(sumsq), max_norm, _stream()), "mpv_adamw_step_grouped_dev")
+
+
 def l2norm_fwd(x, rows, cols, eps=1e-12):
     y = torch.empty((rows, cols), dtype=torch.bfloat16, device=x.device)
     nrm = torch.empty(rows, dtype=torch.float32, device=x.device)

@@ -166,6 +166,16 @@ class DistributedGPT3_Pretrain(nn.Module):
         return loss, torch.zeros((), device=loss.device)                                   # :218-221
 
     @torch.no_grad()
+    def forward_backward(self, image, text):
+        """forward + backward of one micro-batch WITHOUT autograd: what `loss, _ = model(image, text); loss.backward()` does, as two
+        direct calls of the explicit pipeline.  Gradients land in the same .grad views.  This is the form a HIP graph can capture
+        (engine.graph_step): under autograd the anchor's AccumulateGrad node runs on the stream the anchor was created on, not
+        on the capturing stream."""
+        loss, tape = self._forward_pipeline(image, text.input_ids, text.attention_mask, prompt_lengths=getattr(text, "prompt_lengths", None))
+        self._backward_pipeline(tape, torch.ones((), dtype=torch.float32, device=loss.device))
+        return loss
+
+    @torch.no_grad()
     def forward_outputs(self, image, text):
         """Evaluation helper: full decoder outputs (logits, losses, last_hidden_state, loss)."""
         _, tape = self._forward_pipeline(image, text.input_ids, text.attention_mask, want_logits=True)

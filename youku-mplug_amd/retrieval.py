@@ -195,6 +195,13 @@ class DistributedGPT3_Retrieval(nn.Module):
         ops.copy_rows(dcls, demb, B, D, dmap=(1, S, 0))
         self.visual_encoder.backward_features(demb, tape["vit"])
 
+    @torch.no_grad()
+    def forward_backward(self, image, text, idx):
+        """forward + backward without autograd (see DistributedGPT3_Pretrain.forward_backward): the capturable form of the step"""
+        loss, tape = self._forward_pipeline(image, text.input_ids, text.attention_mask, idx)
+        self._backward_pipeline(tape, torch.ones((), dtype=torch.float32, device=loss.device))
+        return loss
+
     def forward(self, image, text, idx):
         ids, mask = text.input_ids, text.attention_mask
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
