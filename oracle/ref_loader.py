@@ -78,7 +78,7 @@ def _visual_config_dict(cfg: PathConfig):
         "num_frames": cfg.num_frames, "embed_dim": cfg.vit_dim, "num_heads": cfg.vit_heads,
         "mlp_ratio": cfg.vit_mlp_ratio, "drop_path": 0, "grad_ckpt": False,
         "stop_grad_conv1": False, "use_shared_rel_pos_bias": False, "use_abs_pos_emb": True,
-        "clip_model": True,
+        "clip_model": True, "connect_ln": bool(getattr(cfg, "connect_ln", False)),
     }
 
 

@@ -190,13 +190,22 @@ def gpt_forward(input_embeds, labels, loss_mask, sd, cfg: PathConfig,
                 last_hidden_state=h.transpose(0, 1).contiguous())
 
 
+def visual_connect(image_query, sd):
+    """models/distributed_gpt3.py:136: visual_norm(visual_fc(image_query)); visual_norm is LayerNormWithForceFP32(eps 1e-6) when the
+    visual config sets connect_ln (:112-115: its parameters are then in the state dict), the identity otherwise."""
+    qf = F.linear(image_query, sd["visual_fc.weight"], sd["visual_fc.bias"])
+    if "visual_norm.weight" in sd:
+        qf = ln_fp32(qf, sd["visual_norm.weight"], sd["visual_norm.bias"], 1e-6)
+    return qf
+
+
 def pretrain_forward(video, ids, attn_mask, sd, cfg: PathConfig):
     """models/distributed_gpt3.py:130-166 (use_contrastive False)."""
     B = video.shape[0]
     image_embeds = timesformer(video, sd, cfg)
     queries = sd["learnable_queries"].repeat(B, 1, 1)                                            # :134
     image_query = attention_pool(queries, image_embeds, sd, cfg)
-    query_features = F.linear(image_query, sd["visual_fc.weight"], sd["visual_fc.bias"])         # :136
+    query_features = visual_connect(image_query, sd)                                             # :136
     Q = query_features.shape[1]
     targets = torch.cat([ids[:, 1:], ids[:, 1:2]], dim=1)                                        # :142-143
     targets = torch.cat([torch.full((B, Q), 100, dtype=torch.long), targets], dim=1)             # :150-153
@@ -261,7 +270,7 @@ def pretrain_image_forward(image, ids, attn_mask, sd, cfg: PathConfig, prompt_le
     B = image.shape[0]
     image_embeds = eva_vit(image, sd, cfg)
     image_query = attention_pool(sd["learnable_queries"].repeat(B, 1, 1), image_embeds, sd, cfg)
-    query_features = F.linear(image_query, sd["visual_fc.weight"], sd["visual_fc.bias"])
+    query_features = visual_connect(image_query, sd)
     Q = query_features.shape[1]
     targets = torch.cat([ids[:, 1:], ids[:, 1:2]], dim=1)
     tla = attn_mask[:, 1:].clone()

@@ -38,6 +38,7 @@ class PathConfig:
     vocab: int = 51200
     max_pos: int = 2048
     gpt_ln_eps: float = 1e-5
+    connect_ln: bool = False          # visual_cfg['connect_ln']: LayerNorm behind visual_fc (models/distributed_gpt3.py:112-115,136)
 
     @property
     def n_patches(self):
@@ -107,6 +108,8 @@ def state_dict_spec(cfg: PathConfig):
     lin("attn_pool.mlp.fc1", hid, D)
     lin("attn_pool.mlp.fc2", D, hid)
     lin("visual_fc", H, D)
+    if cfg.connect_ln:
+        ln("visual_norm", H)
     lm = "text_decoder.dist_model.language_model."
     s.append((lm + "embedding.word_embeddings.weight", (cfg.vocab, H), "w_gpt"))
     s.append((lm + "embedding.position_embeddings.weight", (cfg.max_pos, H), "w_gpt"))

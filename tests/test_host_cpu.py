@@ -31,6 +31,23 @@ def test_cabi_exports_every_declared_symbol():
     assert _lib.lib().mpv_version() >= 100
 
 
+def test_adamw_hyper_pack_matches_the_by_value_formula():
+    """mpv_adamw_hyper_pack (host side of mpv_adamw_step_grouped_dev): lr[8], wd[8] and the two bias-correction factors computed as
+    mpv_adamw_step_grouped computes them (double pow, one rounding to float) -- the reason the device-hyper step is bit-identical."""
+    import youku_mplug_amd  # noqa: F401
+    from youku_mplug_amd import _lib
+    lrs, wds = [1e-4, 2.5e-5, 3e-3], [0.05, 0.0, 0.1]
+    out = (ctypes.c_float * 18)()
+    arr = ctypes.c_float * 3
+    for step in (1, 7, 2000):
+        _lib.check(_lib.lib().mpv_adamw_hyper_pack(arr(*lrs), arr(*wds), 3, 0.9, 0.999, step, out), "pack")
+        f32 = lambda x: ctypes.c_float(x).value
+        assert list(out[:3]) == [f32(x) for x in lrs] and list(out[8:11]) == [f32(x) for x in wds] and all(v == 0.0 for v in list(out[3:8]) + list(out[11:16]))
+        b1, b2 = float(f32(0.9)), float(f32(0.999))
+        assert out[16] == f32(1.0 / (1.0 - b1 ** step)) and out[17] == f32(1.0 / (1.0 - b2 ** step) ** 0.5)
+    assert _lib.lib().mpv_adamw_hyper_pack(arr(*lrs), arr(*wds), 3, 0.9, 0.999, 0, out) != 0      # steps count from 1
+
+
 def test_product_has_no_cpu_fallback():
     from youku_mplug_amd import _lib, ops
     with pytest.raises(_lib.MpvError):
@@ -81,6 +98,32 @@ def test_restatement_matches_reference_modules_live():
     assert list(sorted(mine)) == list(sorted(ref))
     for k in ref:
         assert tuple(mine[k].shape) == tuple(ref[k].shape), k
+
+
+def test_connect_ln_restatement_matches_reference_modules_live():
+    """visual_cfg['connect_ln'] (models/distributed_gpt3.py:112-115,136): LayerNormWithForceFP32 behind visual_fc.  The restatement
+    against the reference's own module built with the flag, and the product's state-dict layout against the reference's."""
+    import dataclasses
+    from oracle import restate
+    from oracle.ref_loader import build_reference_model, reference_forward
+    from oracle.weights import CONFIG_TINY, make_inputs
+    cfg = dataclasses.replace(CONFIG_TINY, connect_ln=True)
+    model, sd = build_reference_model(cfg, 6)
+    assert "visual_norm.weight" in sd and type(model.visual_norm).__name__ != "Identity"
+    video, ids, mask = make_inputs(cfg, 3, 10, seed=12, ragged=True)
+    loss, out, _ = reference_forward(model, video, ids, mask)
+    loss.backward()
+    sdd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    r = restate.pretrain_forward(video, ids, mask, sdd, cfg)
+    r["loss"].backward()
+    assert rel(r["logits"], out.logits) < 1e-5 and rel(r["last_hidden_state"], out.last_hidden_state) < 1e-5
+    for n in ("visual_norm.weight", "visual_norm.bias", "visual_fc.weight", "learnable_queries", "visual_encoder.blocks.0.attn.qkv.weight"):
+        assert rel(sdd[n].grad, dict(model.named_parameters())[n].grad) < 1e-4, n
+    from youku_mplug_amd.pretrain import synthetic_model
+    mine = synthetic_model(cfg, device="cpu").state_dict()
+    ref = model.state_dict()
+    assert list(sorted(mine)) == list(sorted(ref))
+    assert tuple(mine["visual_norm.weight"].shape) == tuple(ref["visual_norm.weight"].shape)
 
 
 def test_state_dict_layout_matches_spec():

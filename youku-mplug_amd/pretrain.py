@@ -70,8 +70,9 @@ class DistributedGPT3_Pretrain(nn.Module):
                                        eps=1e-6, std=0.02, device=device)                 # :106-109
         self.visual_fc = Linear(self.vision_width, self.text_width, std=0.015, device=device)   # :111,116
         self.visual_norm = nn.Identity()
-        if visual_cfg.get("connect_ln", False):
-            raise NotImplementedError("connect_ln is not set by any shipped visual config")
+        if visual_cfg.get("connect_ln", False):                                           # :112-115
+            from .vision import LayerNormWithForceFP32
+            self.visual_norm = LayerNormWithForceFP32(self.text_width, eps=1e-6, device=device)
         self.use_contrastive = config.get("use_contrastive", False)
         if self.use_contrastive:
             raise NotImplementedError("use_contrastive is false in the pre-train recipe (…yaml:26); ITC lives in the retrieval model")
@@ -120,6 +121,10 @@ class DistributedGPT3_Pretrain(nn.Module):
         image_query = self.attn_pool.forward_pool(self.learnable_queries, emb, B, S_img, tape["pool"])      # :134
         qf = ops.gemm(image_query, self.visual_fc.weight, B * Q, Hh, self.vision_width, bias=self.visual_fc.bias)   # :136
         tape["image_query"] = image_query
+        if not isinstance(self.visual_norm, nn.Identity):                                 # connect_ln: visual_norm(visual_fc(.))
+            vn = self.visual_norm
+            tape["qf_raw"] = qf
+            qf, tape["vn_mean"], tape["vn_rstd"] = ops.layernorm_fwd(qf, vn.weight, vn.bias, vn.eps, B * Q, Hh)
         if not want_logits and Q > 0 and ids.shape[1] > 0:
             # training / loss-only evaluation: labels and loss weights of the L text positions from one kernel (the Q query slots
             # in front never carry loss, :142-159): LM head + CE run on that window and no [B, S] target tensors are built
@@ -148,6 +153,10 @@ class DistributedGPT3_Pretrain(nn.Module):
         Q, Hh, D = self.num_learnable_token, self.text_width, self.vision_width
         dqf = self.text_decoder.backward_lm(tape["gpt"], grad_loss)
         iq = tape["image_query"]
+        if "qf_raw" in tape:
+            vn = self.visual_norm
+            dqf = ops.layernorm_bwd(dqf, tape["qf_raw"], vn.weight, tape["vn_mean"], tape["vn_rstd"], B * Q, Hh,
+                                    dgamma=grad_of(vn.weight), dbeta=grad_of(vn.bias))
         ops.colsum(dqf, B * Q, Hh, out=grad_of(self.visual_fc.bias))
         ops.gemm(dqf, iq, Hh, D, B * Q, trans_a=True, trans_b=True, out=grad_of(self.visual_fc.weight))
         diq = ops.gemm(dqf, self.visual_fc.weight, B * Q, D, Hh, trans_b=True)
@@ -225,7 +234,7 @@ def synthetic_model(shapes, device="cuda", num_frames=None) -> DistributedGPT3_P
     product never imports oracle/: tests pass the dataclass in)."""
     vis = dict(img_size=shapes.img_size, patch_size=shapes.patch_size, depth=shapes.vit_depth,
                num_frames=num_frames or shapes.num_frames, embed_dim=shapes.vit_dim, num_heads=shapes.vit_heads,
-               mlp_ratio=shapes.vit_mlp_ratio, clip_model=True)
+               mlp_ratio=shapes.vit_mlp_ratio, clip_model=True, connect_ln=bool(getattr(shapes, "connect_ln", False)))
     txt = GPT3Config(vocab_size=shapes.vocab, hidden_size=shapes.hidden, ffn_hidden_size=shapes.ffn,
                      num_hidden_layers=shapes.layers, num_attention_heads=shapes.heads, max_position_embeddings=shapes.max_pos,
                      layernorm_epsilon=shapes.gpt_ln_eps)
