@@ -78,7 +78,7 @@ def test_streaming_kernels_keep_their_waves(kernels):
 def test_attention_kernels_budgets(kernels):
     ks, _ = kernels
     for n, k in ks.items():
-        if "attn_" not in n or "temporal" in n or "pair64" in n:      # the paired-block kernels have their own test below
+        if "attn_" not in n or "temporal" in n or "pair64" in n or "duo96" in n:      # the paired-block / duo kernels have their own tests below
             continue
         lean = "ELi320ELi3EE" in n                               # <..., 320, 3>: GPT instances, two 5-wave workgroups per CU, 3 waves per SIMD
         assert k["vgpr"] + (0 if "attn_bwd_dkv_kernel" in n else k["agpr"]) <= (170 if lean else 512), (n, k)
@@ -95,6 +95,14 @@ def test_paired_causal_attention_kernels_fit_four_items_per_cu(kernels):
     for n, k in pair.items():
         limit = 256 if "ILi7ELi256ELi2EE" in n else 170      # the 7-block forward keeps 7 score tiles: two waves per SIMD
         assert k["scratch"] == 0 and k["vgpr"] + k["agpr"] <= limit and k["lds"] == 0, (n, k)
+
+
+def test_vit_duo_attention_kernels_fit_two_items_per_cu(kernels):
+    """csrc/attention_duo.inc: 4 waves per (batch, head) item, two items per CU -> 2 waves per SIMD (256 registers), no scratch"""
+    ks, _ = kernels
+    duo = _sel(ks, "duo96_kernel")
+    for n, k in duo.items():
+        assert k["scratch"] == 0 and k["vgpr"] + k["agpr"] <= 256 and k["lds"] == 0, (n, k)
 
 
 def test_persistent_attention_kernels_never_touch_scratch(kernels):

@@ -214,6 +214,11 @@ ATTN_CASES = [  # B, H, Sq, Sk, hd, causal, scale_q_bf16
     (9, 4, 224, 224, 64, True, False),
     (2, 2, 129, 129, 64, True, True),
     (33, 32, 160, 160, 64, True, False),    # config B exactly: 1056 items, four per CU
+    # ViT spatial dQ as two 4-wave items per CU (csrc/attention_duo.inc: head_dim 96, 7 key tiles): plain and pre-scaled q, the
+    # shortest and the longest 7-tile sequences (one key / all 32 keys in the last tile)
+    (5, 4, 197, 197, 96, False, False),
+    (2, 2, 193, 193, 96, False, True),
+    (2, 2, 224, 224, 96, False, False),
 ]
 
 

@@ -1621,6 +1621,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
 }
 
 #include "attention_pair.inc"
+#include "attention_duo.inc"
 
 // waves per workgroup: cover a whole sequence with one workgroup when it has <= 256 rows (no idle
 // waves: 160 rows -> 5 waves, 197 -> 7), otherwise 8 waves = 256 rows per workgroup
@@ -1752,6 +1753,15 @@ static int pair_mode() {
   }
   return mode;
 }
+// MPV_ATTN_DUO (measurement knob, read once): 0 = the one-shot 7-wave dQ kernel of the ViT shape; 1 (default) = two 4-wave items per CU
+static int duo_mode() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("MPV_ATTN_DUO");
+    mode = e ? atoi(e) : 1;
+  }
+  return mode;
+}
 constexpr int PAIR_MAX_ROWS = 224;
 static bool pair_ok(const mpv_attn_desc* d) {
   return pair_mode() > 0 && d->head_dim == 64 && d->causal && d->sq == d->sk && d->sk <= PAIR_MAX_ROWS;
@@ -1854,7 +1864,15 @@ extern "C" int mpv_attn_bwd(const mpv_attn_desc* d, const void* dO, void* dq, vo
           break;
         case 80: hipLaunchKernelGGL((attn_bwd_dq_res_kernel<80>), gq, dim3(64 * nw), lq, stream, a); break;
         default:
-          if (vit7) hipLaunchKernelGGL((attn_bwd_dq_res_kernel<96, 7>), gq, dim3(64 * nw), lq, stream, a);
+          if (vit7 && duo_mode() && d->sq == d->sk && d->head_dim == 96) {      // two 4-wave items per CU (attention_duo.inc)
+            static bool attr = false;
+            if (!attr) {
+              allow_lds(attn_bwd_dq_duo96_kernel<256>, 80 * 1024);
+              attr = true;
+            }
+            const size_t dl = (((size_t)d->sk * 208 + 1023) / 1024 + ((size_t)d->sk * 192 + 1023) / 1024) * 1024;
+            hipLaunchKernelGGL((attn_bwd_dq_duo96_kernel<256>), dim3(1, gy), dim3(256), dl, stream, a);
+          } else if (vit7) hipLaunchKernelGGL((attn_bwd_dq_res_kernel<96, 7>), gq, dim3(64 * nw), lq, stream, a);
           else hipLaunchKernelGGL((attn_bwd_dq_res_kernel<96>), gq, dim3(64 * nw), lq, stream, a);
           break;
       }

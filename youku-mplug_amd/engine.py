@@ -396,6 +396,9 @@ class MplugEngine(nn.Module):
 
         def copy_in(dst, src):
             if torch.is_tensor(dst):
+                if dst.shape != src.shape or dst.dtype != src.dtype:
+                    raise ValueError(f"graph_step: input {tuple(src.shape)} {src.dtype} differs from the captured {tuple(dst.shape)} {dst.dtype}; "
+                                     "a captured step replays fixed shapes (pad the batch, or use the eager step for this one)")
                 dst.copy_(src, non_blocking=True)
             elif hasattr(dst, "__dict__"):
                 for k, v in vars(dst).items():
@@ -409,6 +412,7 @@ class MplugEngine(nn.Module):
             after()
             return loss
         if self._graph is None:
+            assert self.module.training, "graph_step captures the training step (model.train())"
             static_in = tuple(clone_in(x) for x in inputs)
             counters = (self.optimizer.step_count,)
             torch.cuda.synchronize()
