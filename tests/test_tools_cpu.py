@@ -53,3 +53,4 @@ def test_zimage_layout_simulation():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.check(160, verbose=False) and mod.check(224, verbose=False) and mod.check(32, verbose=False)
+    assert mod.check_rot192(224, verbose=False)      # the head_dim-96 images of csrc/attention_duo.inc

@@ -108,6 +108,59 @@ def check(rows=160, verbose=True):
     return True
 
 
+def check_rot192(rows=224, verbose=True):
+    """The rotated 192-byte-pitch image of csrc/attention_duo.inc (head_dim 96): chunk c of row r at position (c + ((r >> 2) & 3)) mod 12.
+    Row fragments by the closed-form per-lane offsets of the kernels (only d-steps 4 and 5 can wrap), column fragments by the
+    per-d-tile lo / hi offsets (rotation h / h + 2): logical element + bank checks as in check()."""
+    P = 192
+    rot = lambda r: (r >> 2) & 3
+    rng = np.random.default_rng(1)
+    mat = rng.integers(0, 65535, size=(rows, 96), dtype=np.uint16)
+    lds = np.zeros(rows * P // 2, dtype=np.uint16)
+    for g in range(rows * 12):
+        row, pos = g // 12, g % 12
+        cc = pos - rot(row)
+        cc = cc + 12 if cc < 0 else cc
+        lds[g * 8:(g + 1) * 8] = mat[row, cc * 8:(cc + 1) * 8]
+    for t in range(rows // 32):
+        for st in range(6):
+            addrs = []
+            for lane in range(64):
+                r, h = lane & 31, lane >> 5
+                c0 = h + rot(r)
+                base = r * P + c0 * 16
+                a = base + st * 32 if st < 4 else (base + 128 - (192 if c0 == 4 else 0) if st == 4 else base + 160 - (192 if c0 >= 2 else 0))
+                a += t * 32 * P
+                c = (2 * st + h) * 8
+                assert (lds[a // 2:a // 2 + 8] == mat[t * 32 + r, c:c + 8]).all(), ("rot rows", t, st, lane)
+                addrs.append(a)
+            for grp in B128_GROUPS:
+                assert len(groups([addrs[l] for l in grp], 16)) == 16, ("rot rows conflict", t, st)
+        for ks in range(2):
+            for d in range(3):
+                for half in (0, 1):
+                    addrs = []
+                    for lane in range(64):
+                        ch, cm = lane >> 5, (lane & 15) >> 2
+                        cl, csub = ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1), ((lane & 3) & 1) * 8
+                        pos = (d * 4 + cl + ch + 2 * half) % 12
+                        a = t * 32 * P + ks * 16 * P + (4 * ch + cm + 8 * half) * P + pos * 16 + csub
+                        r = t * 32 + ks * 16 + 4 * ch + cm + 8 * half
+                        col = d * 32 + ((lane >> 4) & 1) * 16 + (lane & 3) * 4
+                        assert (lds[a // 2:a // 2 + 4] == mat[r, col:col + 4]).all(), ("rot cols", t, ks, d, half, lane)
+                        addrs.append(a)
+                    for p_ in range(2):
+                        banks = set()
+                        for a in addrs[32 * p_:32 * p_ + 32]:
+                            banks.add((a // 4) % 64)
+                            banks.add((a // 4 + 1) % 64)
+                        assert len(banks) == 64, ("rot cols conflict", t, ks, d, half, p_)
+    if verbose:
+        print(f"rotated 192-byte image, {rows} rows: row and column fragments return their logical elements, bank-conflict-free")
+    return True
+
+
 if __name__ == "__main__":
+    check_rot192(224)
     check(160)
     check(224)

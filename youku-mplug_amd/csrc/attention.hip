@@ -1753,12 +1753,13 @@ static int pair_mode() {
   }
   return mode;
 }
-// MPV_ATTN_DUO (measurement knob, read once): 0 = the one-shot 7-wave dQ kernel of the ViT shape; 1 (default) = two 4-wave items per CU
+// MPV_ATTN_DUO (measurement knob, read once): 0 = the one-shot 7-wave backward kernels of the ViT shape; 1 = dQ as two 4-wave items
+// per CU; 2 (default) = dQ and dK/dV
 static int duo_mode() {
   static int mode = -1;
   if (mode < 0) {
     const char* e = getenv("MPV_ATTN_DUO");
-    mode = e ? atoi(e) : 1;
+    mode = e ? atoi(e) : 2;
   }
   return mode;
 }
@@ -1884,7 +1885,18 @@ extern "C" int mpv_attn_bwd(const mpv_attn_desc* d, const void* dO, void* dq, vo
           else hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<64, 512>), gk, dim3(64 * nwk), lk, stream, a);
           break;
         case 80: hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<80, 512>), gk, dim3(64 * nwk), lk, stream, a); break;
-        default: hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<96, 512>), gk, dim3(64 * nwk), lk, stream, a); break;
+        default:
+          if (vit7 && duo_mode() >= 2 && d->sq == d->sk && d->head_dim == 96) {      // two 4-wave items per CU (attention_duo.inc)
+            static bool attr = false;
+            if (!attr) {
+              allow_lds(attn_bwd_dkv_duo96_kernel<256>, 80 * 1024);
+              attr = true;
+            }
+            const int qr = (d->sq + 31) / 32 * 32;
+            const size_t dl = ((size_t)(2 * qr * 4 + 1023) / 1024 + 2 * (((size_t)d->sq * 192 + 1023) / 1024)) * 1024;
+            hipLaunchKernelGGL((attn_bwd_dkv_duo96_kernel<256>), dim3(1, gy), dim3(256), dl, stream, a);
+          } else hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<96, 512>), gk, dim3(64 * nwk), lk, stream, a);
+          break;
       }
     }
     return mpv_check_launch("mpv_attn_bwd");
