@@ -935,11 +935,10 @@ __global__ __launch_bounds__(THREADS, WPE) void attn_bwd_dq_res_kernel(const Att
   }
 }
 
-// One workgroup of ceil(sk / 32) waves per (batch, head): Q and dO are loaded once, and the 512-thread bound keeps the
-// kernel within 256 VGPRs so that two workgroups (14 waves at S = 197) share a CU.  (As a 256-thread kernel it was
-// allocated 336 VGPRs: one 4-wave workgroup per CU, two workgroups per (batch, head) each re-loading Q and dO.)
-// (head_dim 64 fits both accumulator sets in 256 VGPRs and keeps one pass: measured 80 us against 106 us for the two-pass
-// form on the GPT shape)
+// One workgroup of ceil(sk / 32) waves per (batch, head): Q and dO are loaded once; the 512-thread bound keeps the kernel
+// within 256 VGPRs (2 waves per SIMD: one 5..8-wave workgroup per CU; the <64, 320, 3> instance fits 168 for two 5-wave
+// workgroups).  Both 32 x HD accumulator sets are live over ONE pass over the q-tiles (measured 80 us against 106 us for a
+// two-pass form on the GPT shape).  The ViT shape (head_dim 96, 7 tiles) runs on attn_bwd_dkv_duo96_kernel instead.
 template <int HD, int THREADS, int WPE = 1>
 __global__ __launch_bounds__(THREADS, WPE) void attn_bwd_dkv_res_kernel(const AttnArgs p) {
   const MpvSeedKeys seed_k = mpv_seed_keys(p.drop_thr ? mpv_resolve_seed(p.seed) : 0);      // (bit 63 set: the seed lives in device memory, mpv_common.h)
@@ -1018,9 +1017,9 @@ __global__ __launch_bounds__(THREADS, WPE) void attn_bwd_dkv_res_kernel(const At
   };
   // One pass over the q-tiles, S, P, dP and dS computed once, both 32 x HD accumulator sets live.  head_dim <= 64 keeps
   // the wave's K and V fragments in registers; above that the V fragments (24 more VGPRs at 96) are read from a third LDS
-  // region instead -- with them in registers the kernel needs ~290 VGPRs and the allocator parks fragments in scratch
-  // inside the loop (measured 5k clocks per q-tile); the earlier answer, two passes with one accumulator set each,
-  // recomputed S and the exponentials (+25% MFMAs, 2x exp, +33% LDS reads).
+  // region instead (a round-2 decision, when the register form spilled inside the loop; the current code compiles to 220 VGPRs
+  // without scratch in that form too -- attention_duo.inc's dK/dV kernel uses it -- but the one-shot instances were not
+  // re-measured with it).
   constexpr bool V_LDS = HD > 64;
   bf16x8 vf[V_LDS ? 1 : NS];
   if constexpr (!V_LDS) load_row_frags<HD>(vf, p.v + b * p.v_bs + h * p.v_hs, p.v_rs, krow, p.sk, lane, p.hd);
