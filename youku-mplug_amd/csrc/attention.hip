@@ -1743,7 +1743,8 @@ static void res_attr_once() {
 }
 
 // ---- paired-block causal kernels (attention_pair.inc): host side ----
-// MPV_ATTN_PAIR (measurement knob, read once): 0 = the one-shot resident kernels; 1 (default) = the paired forward and dQ kernels
+// MPV_ATTN_PAIR (measurement knob, read once): 0 = the one-shot resident kernels; 1 (default) = the paired forward and dQ kernels, the
+// paired dK/dV kernel above 5 blocks; 2 = the paired dK/dV kernel everywhere
 static int pair_mode() {
   static int mode = -1;
   if (mode < 0) {
@@ -1877,7 +1878,16 @@ extern "C" int mpv_attn_bwd(const mpv_attn_desc* d, const void* dO, void* dq, vo
           break;
       }
     }
-    {
+    // the dK/dV role paired too where it measured faster: above 5 blocks (S = 208: 4 waves and two items per CU instead of one
+    // 7-wave workgroup, backward 120.8 -> 99.4 us per layer); at S = 160 (three items per CU instead of two 5-wave ones) it is a
+    // tie, 76.4 vs 75.7 us, and the one-shot kernel stays (MPV_ATTN_PAIR=2 forces the paired one) -- profiles/r03_c19_dkv_pair_ab.log
+    if (pair_ok(d) && (pair_mode() >= 2 || (d->sk + 31) / 32 >= 6)) {
+      const int nb = (d->sk + 31) / 32;
+      const size_t pl = pair_lds(d->sk) + ((size_t)(2 * nb * 32 * 4) + 1023) / 1024 * 1024;
+      const dim3 pg(1, gy), pb(64 * ((nb + 1) / 2));
+      if (nb <= 5) hipLaunchKernelGGL((attn_bwd_dkv_pair64_kernel<192, 3>), pg, pb, pl, stream, a);
+      else hipLaunchKernelGGL((attn_bwd_dkv_pair64_kernel<256, 3>), pg, pb, pl, stream, a);
+    } else {
       switch (hdc) {
         case 64:
           if (small64) hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<64, 320, 3>), gk, dim3(64 * nwk), lk, stream, a);
