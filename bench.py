@@ -367,6 +367,9 @@ def main():
     dt = dt.item()
     final_loss = loss.item()
     log(f"timed region done: {dt / args.steps * 1e3:.1f} ms/step")
+    ms_ = torch.cuda.memory_stats(dev)
+    log(f"device memory: peak allocated {ms_.get('allocated_bytes.all.peak', 0) / 2**30:.1f} GiB, peak reserved {ms_.get('reserved_bytes.all.peak', 0) / 2**30:.1f} GiB, "
+        f"allocator retries {ms_.get('num_alloc_retries', 0)}, device mallocs {ms_.get('num_device_alloc', 0)} / frees {ms_.get('num_device_free', 0)}")
     assert math.isfinite(final_loss), "non-finite loss in the timed region"
 
     roof = None

@@ -12,3 +12,6 @@ grep -E "passed|failed" $OUT/f_gpu_tests.log
 tail -1 $OUT/f_profile.log | cut -c1-300
 (MPV_BENCH_BY_SHAPE=$OUT/${TAG}_gemm_in_step_by_shape.md timeout 400 python bench.py --no-cpu-baseline < /dev/null > $OUT/f_bench_B.json 2> $OUT/f_bench_B.err); tail -4 $OUT/f_bench_B.err | cut -c1-300; cut -c1-400 $OUT/f_bench_B.json
 (MPV_GRAPH=1 timeout 300 python bench.py --no-cpu-baseline --no-roofline --steps 30 < /dev/null 2>&1 | grep -E "timed region|host |rror" | cut -c1-300) > $OUT/f_bench_graph.log; cat $OUT/f_bench_graph.log
+for c in D E; do
+  (timeout 400 python bench.py --config $c --no-cpu-baseline --steps 20 < /dev/null > $OUT/f_bench_$c.json 2> $OUT/f_bench_$c.err); tail -2 $OUT/f_bench_$c.err | cut -c1-200; cut -c1-300 $OUT/f_bench_$c.json
+done

@@ -183,6 +183,19 @@ class _WgradLane:
         if self.on:
             torch.cuda.current_stream().wait_stream(self.side)
 
+    def check_memory(self, device):
+        """Called once, at the start of the first backward (the forward's activations are allocated by then).  A second stream is a
+        second pool of the caching allocator: blocks the main stream frees while the side stream still uses them cannot be
+        reused at once, and the reserved memory drifts towards twice the activations.  When the activations already take more than
+        a third of the device (the ITC retrieval step at its YAML batch of 96 x 16 frames: 130 GiB allocated, 259 GiB reserved of
+        288, then multi-second allocator retries) the lane buys nothing anyway (its launches are large) and is switched off."""
+        if not self.on or getattr(self, "_mem_checked", False):
+            return
+        self._mem_checked = True
+        total = torch.cuda.get_device_properties(device).total_memory
+        if torch.cuda.memory_allocated(device) > total // 3:
+            self.on = False
+
 
 # MPV_VIT_COMPOSE=0: measurement knob -- temporal_attn.proj / temporal_fc as the reference's two products (forward) and two dgrads +
 # two wgrads (backward) instead of the composed projection (TimeSformer.forward_features / backward_features)
@@ -393,6 +406,7 @@ class TimeSformer(nn.Module):
                           xmap=(1, T * N1, 0), ymap=(1, S, 0))
         wl = _WgradLane(demb.device) if not hasattr(self, "_wgrad_lane") else self._wgrad_lane
         self._wgrad_lane = wl
+        wl.check_memory(demb.device)
         lnb = self.__dict__.setdefault("_ln_batch", ops.LnDparamBatch())   # a block's three dgamma/dbeta reductions: one launch
         for bi in range(len(self.blocks) - 1, -1, -1):
             blk, s = self.blocks[bi], tape["blocks"][bi]
