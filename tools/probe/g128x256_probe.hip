@@ -82,6 +82,12 @@ __global__ __launch_bounds__(256, WPE) void g128x256(const bf16* __restrict__ A,
     if (isA) off[j] = (m0 + row) < M ? (uint32_t)(((size_t)(m0 + row) * K + kc * 8) * 2) : 0x80000000u;
     else off[j] = (n0 + row) < N ? (uint32_t)(((size_t)(n0 + row) * K + kc * 8) * 2) : 0x80000000u;
   }
+  auto dma_piece = [&](int kt, int j) {      // piece j (0..5) of this wave's share of stage kt
+    const uint32_t kb = kt < nk ? (uint32_t)(kt * BK * 2) : 0x80000000u;
+    char* st = smem + (kt % NSTAGE) * STAGE;
+    char* dst = j < 2 ? st + (wave * 2 + j) * 1024 : st + A_BYTES + (wave * 4 + (j - 2)) * 1024;
+    dma16(j < 2 ? ra : rb, (uint32_t)(uintptr_t)(lds_void*)dst, off[j] + kb);
+  };
   auto dma_stage = [&](int kt) {
     const uint32_t kb = kt < nk ? (uint32_t)(kt * BK * 2) : 0x80000000u;
     char* st = smem + (kt % NSTAGE) * STAGE;
@@ -116,7 +122,9 @@ __global__ __launch_bounds__(256, WPE) void g128x256(const bf16* __restrict__ A,
   auto step = [&](int kt, const char* st) {
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#if VARIANT < 2
     dma_stage(kt + 2);      // (past the end: every lane out of range -> no traffic, the wait counts stay uniform)
+#endif
     bf16x8 fa[2][4], fb[2][2];
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
@@ -129,12 +137,25 @@ __global__ __launch_bounds__(256, WPE) void g128x256(const bf16* __restrict__ A,
     SB();
     __builtin_amdgcn_s_setprio(1);
 #endif
+#if VARIANT >= 2      // VARIANT 2: the six DMA pieces of stage kt + 2 woven between the MFMAs (one after every second MFMA) instead of in a burst
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int s2 = q >> 3, i = (q >> 1) & 3, j = q & 1;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[s2][j], fa[s2][i], acc[i][j], 0, 0, 0);
+      SB();
+      if ((q & 1) && q < 12) {
+        dma_piece(kt + 2, q >> 1);
+        SB();
+      }
+    }
+#else
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[s2][j], fa[s2][i], acc[i][j], 0, 0, 0);
+#endif
 #if VARIANT >= 1
     __builtin_amdgcn_s_setprio(0);
     SB();
