@@ -319,6 +319,24 @@ int mpv_kv_reorder(void* const* src, void* const* dst, int layers, const int64_t
 int mpv_video_resized_crop_normalize(const uint8_t* clip, int T, int H, int W, int crop_i, int crop_j, int crop_h, int crop_w,
                                      int out_h, int out_w, int mode, int flip, const float* mean3, const float* std3, void* out,
                                      int64_t c_stride, int64_t t_stride, mpv_stream_t stream);
+
+/* The clip-consistent RandAugment of the loaders (dataset/video_utils/randaugment_video.py; dataset/__init__.py:65-66,75-76) on the
+ * device, on uint8 clips [T][H][W][3].  mpv_video_resized_crop_u8 is mpv_video_resized_crop_normalize stopped at the point where
+ * the augmentation takes over: the .long() value as uint8 with numpy's wrapping cast (randaugment_video.py:343), [T][oh][ow][3].
+ * mpv_video_aug_pointwise: op 0 = contrast_func (:120-130; the per-frame luminance mean needs sums_ws, 3 * T uint64), op 1 =
+ * brightness_func (:133-139), in place.  mpv_video_aug_sharpness: sharpness_func (:142-160; cv2.filter2D restated), out of place.
+ * mpv_video_aug_warp_affine: cv2.warpAffine(INTER_LINEAR, BORDER_CONSTANT) with the INVERTED 2 x 3 matrix (the host inverts as
+ * opencv does) -- shear_x/y :163-167,:198-202, translate_x/y :170-187, rotate :67-75 -- out of place.  mpv_video_u8_normalize:
+ * ClipToTensor + Normalize (dataset/__init__.py:68-69) into the [3][T][H][W] slot of the batch.  Bit-exact against
+ * oracle/augment.py; what that restatement pins is stated in its header (opencv itself is not available to compare with). */
+int mpv_video_resized_crop_u8(const uint8_t* clip, int T, int H, int W, int crop_i, int crop_j, int crop_h, int crop_w, int out_h,
+                              int out_w, int mode, int flip, uint8_t* out, mpv_stream_t stream);
+int mpv_video_aug_pointwise(uint8_t* frames, int T, int H, int W, int op, double factor, uint64_t* sums_ws, mpv_stream_t stream);
+int mpv_video_aug_sharpness(const uint8_t* in, uint8_t* out, int T, int H, int W, double factor, mpv_stream_t stream);
+int mpv_video_aug_warp_affine(const uint8_t* in, uint8_t* out, int T, int H, int W, const double* inverse_matrix6, const uint8_t* fill3,
+                              mpv_stream_t stream);
+int mpv_video_u8_normalize(const uint8_t* frames, int T, int H, int W, const float* mean3, const float* std3, void* out,
+                           int64_t c_stride, int64_t t_stride, mpv_stream_t stream);
 /* Soft-target contrastive cross-entropy over fp32 similarities sim[rows][cols] (:966-978):
  * targets[i][j] = [row_ids[i]==col_ids[j]] / count_i; losses[i] = -sum_j log_softmax(sim_i)[j] targets[i][j];
  * dsim (bf16, optional) = (softmax - targets) * scale; dts[i] (optional) = sum_j dsim[i][j] * sim[i][j]. */

@@ -126,6 +126,48 @@ def test_connect_ln_restatement_matches_reference_modules_live():
     assert tuple(mine["visual_norm.weight"].shape) == tuple(ref["visual_norm.weight"].shape)
 
 
+def test_randaugment_restatement_vs_reference_module_through_cv2_shim():
+    """oracle/augment.py against the reference's dataset/video_utils/randaugment_video.py, imported with oracle/cv2_shim.py standing
+    in for opencv (not installed): the class-level draw logic (ops per clip, apply mask, level -> arguments), the numpy ops and the
+    code around the cv2 calls are the reference's own; the cv2 calls themselves land in the oracle's restatement of opencv
+    ("parity unpinned" at that boundary, see oracle/augment.py)."""
+    import importlib.util
+    import numpy as np
+    ref_file = "/root/reference/dataset/video_utils/randaugment_video.py"
+    if not os.path.isfile(ref_file):
+        pytest.skip("reference not present")
+    from oracle import augment as A, cv2_shim
+    cv2_shim.install()
+    spec = importlib.util.spec_from_file_location("ref_randaugment_video", ref_file)
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    rng = np.random.default_rng(0)
+    frames = rng.integers(0, 256, size=(4, 48, 56, 3), dtype=np.uint8)
+    for M in (5, 3, 10):
+        for seed in range(8):
+            np.random.seed(seed)
+            r = ref.TemporalConsistentRandomAugment(N=2, M=M, augs=A.DEFAULT_AUGS)(torch.from_numpy(frames)).numpy()
+            np.random.seed(seed)
+            o = A.TemporalConsistentRandomAugment(N=2, M=M, augs=A.DEFAULT_AUGS)(frames)
+            assert r.dtype == o.dtype and np.array_equal(r, o), (M, seed)
+    for name in A.DEFAULT_AUGS:
+        for level in (0, 3, 5, 10):
+            assert ref.arg_dict[name](level) == A.level_to_args(name, level), (name, level)
+            got, want = A.FUNC[name](frames[1], *A.level_to_args(name, level)), ref.func_dict[name](frames[1], *ref.arg_dict[name](level))
+            assert np.array_equal(got, want), (name, level)
+    # restated opencv pieces: properties that do not need opencv to check
+    img = frames[0]
+    assert np.array_equal(A.warp_affine_linear(img, np.float32([[1, 0, 0], [0, 1, 0]]), (128, 128, 128)), img)
+    t = A.translate_x_func(img, 5, (128, 128, 128))
+    assert np.array_equal(t[:, :-5], img[:, 5:]) and (t[:, -5:] == 128).all()
+    t = A.translate_y_func(img, 3, (128, 128, 128))
+    assert np.array_equal(t[:-3], img[3:]) and (t[-3:] == 128).all()
+    r360 = A.warp_affine_linear(img, A.get_rotation_matrix_2d((28, 24), 360, 1), (0, 0, 0))
+    assert np.abs(r360.astype(int) - img.astype(int)).max() <= 1
+    flat = np.full((9, 9, 3), 77, dtype=np.uint8)
+    assert np.array_equal(A.sharpness_func(flat, 0.64), flat) and np.array_equal(A.sharpness_func(flat, 0.0), flat)
+
+
 def test_state_dict_layout_matches_spec():
     from oracle.weights import CONFIG_TINY, state_dict_spec
     from youku_mplug_amd.pretrain import synthetic_model

@@ -751,3 +751,47 @@ def test_ln_stream_fwd_bwd(dev, rows, cols):
     ops.ln_stream_bwd(dy, h2, gam, m, r, n, cols, dres=dres, dx=dx, xmap=(grp, stride, off))
     close(dx[win], x.grad + dres[win].float(), 1e-2, "dx through the fp32 stream")
     assert dx[outside].float().abs().max().item() == 0
+
+
+def test_video_randaugment_kernels_vs_oracle(dev):
+    """csrc/augment.hip against oracle/augment.py, bit for bit: every one of the nine ops of the training recipes at several levels on
+    random uint8 clips (odd sizes), the whole TemporalConsistentRandomAugment with the reference's draws (numpy's global RNG), and
+    the two ends of the pipeline (the uint8 view of the resized clip, ClipToTensor + Normalize)."""
+    import numpy as np
+    from oracle import augment as A
+    from youku_mplug_amd import video_input as V
+    rng = np.random.default_rng(3)
+    for (T, H, W) in ((3, 41, 57), (2, 224, 224)):
+        frames = rng.integers(0, 256, size=(T, H, W, 3), dtype=np.uint8)
+        frames[0, : H // 2] //= 4                                      # a dark region: contrast tables with a different mean per frame
+        d = torch.from_numpy(frames).to(dev)
+        aug = V.TemporalConsistentRandomAugment(N=2, M=5)
+        for name in V.PRETRAIN_AUGS:
+            for level in (0, 3, 5, 10):
+                got = aug.apply(d, name, level).cpu().numpy()
+                want = np.stack([A.FUNC[name](f, *A.level_to_args(name, level)) for f in frames])
+                assert got.dtype == np.uint8 and np.array_equal(got, want), (name, level, (T, H, W), int(np.abs(got.astype(int) - want.astype(int)).max()))
+        for M in (5, 8):
+            for seed in range(6):
+                np.random.seed(seed)
+                got = V.TemporalConsistentRandomAugment(N=2, M=M)(d).cpu().numpy()
+                np.random.seed(seed)
+                want = A.TemporalConsistentRandomAugment(N=2, M=M, augs=V.PRETRAIN_AUGS)(frames)
+                assert np.array_equal(got.astype(np.float32), want), (M, seed)
+    # pipeline ends: without overshoot (nearest / bilinear) the two-kernel path equals the fused one bit for bit
+    clip = torch.from_numpy(rng.integers(0, 256, size=(4, 120, 160, 3), dtype=np.uint8)).to(dev)
+    for mode, flip in (("nearest", False), ("bilinear", True)):
+        box = (7, 11, 96, 120)
+        fused = V.resized_crop_normalize(clip, box, (64, 64), mode, flip)
+        u8 = V.resized_crop_u8(clip, box, (64, 64), mode, flip)
+        assert u8.dtype == torch.uint8 and tuple(u8.shape) == (4, 64, 64, 3)
+        assert torch.equal(V.u8_normalize(u8), fused)
+    # the whole training transform with rand_augment: runs, shape / dtype of the batch slot, deterministic under the same seeds
+    import random
+    tf = V.VideoInputTransform(64, train=True, rand_augment=True)
+    outs = []
+    for _ in range(2):
+        random.seed(5)
+        np.random.seed(5)
+        outs.append(tf(clip))
+    assert tuple(outs[0].shape) == (3, 4, 64, 64) and outs[0].dtype == torch.bfloat16 and torch.equal(outs[0], outs[1])

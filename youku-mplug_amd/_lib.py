@@ -90,6 +90,11 @@ _SIGS = {
     "mpv_l2norm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "mpv_gather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "mpv_video_resized_crop_normalize": (c_int, [c_void_p] + [c_int] * 11 + [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "mpv_video_resized_crop_u8": (c_int, [c_void_p] + [c_int] * 11 + [c_void_p, c_void_p]),
+    "mpv_video_aug_pointwise": (c_int, [c_void_p, c_int, c_int, c_int, c_int, C.c_double, c_void_p, c_void_p]),
+    "mpv_video_aug_sharpness": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, C.c_double, c_void_p]),
+    "mpv_video_aug_warp_affine": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint8), c_void_p]),
+    "mpv_video_u8_normalize": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "mpv_scatter_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "mpv_gather_rows_ld": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     "mpv_logprob_topk_workspace_size": (c_size_t, [c_int64, c_int]),

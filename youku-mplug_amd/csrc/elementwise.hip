@@ -569,6 +569,7 @@ struct VideoTfArgs {
   int T, H, W, ci, cj, ch, cw, oh, ow, mode, flip;
   long long c_stride, t_stride;
   float mean[3], stdv[3];
+  uint8_t* out_u8;        // when set: the .long() value as uint8 (numpy's wrapping astype) at [t][y][x][c] instead of the normalised bf16
 };
 __device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
 __device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
@@ -624,6 +625,10 @@ __global__ void video_transform_kernel(const VideoTfArgs p) {
       }
     }
     const int dx = p.flip ? p.ow - 1 - ox : ox;
+    if (p.out_u8) {      // the view TemporalConsistentRandomAugment takes of the clip: frames.numpy().astype(np.uint8) (randaugment_video.py:343)
+      for (int c = 0; c < 3; ++c) p.out_u8[(((long long)t * p.oh + oy) * p.ow + dx) * 3 + c] = (uint8_t)(long long)truncf(v[c]);
+      continue;
+    }
     for (int c = 0; c < 3; ++c) {
       const float q = truncf(v[c]);                              // .long()
       const float y = (q / 255.f - p.mean[c]) / p.stdv[c];
@@ -905,6 +910,21 @@ extern "C" int mpv_video_resized_crop_normalize(const uint8_t* clip, int T, int 
   for (int c = 0; c < 3; ++c) { a.mean[c] = mean3[c]; a.stdv[c] = std3[c]; }
   hipLaunchKernelGGL(video_transform_kernel, dim3(ew_grid((long long)T * out_h * out_w)), dim3(256), 0, stream, a);
   return mpv_check_launch("mpv_video_resized_crop_normalize");
+}
+
+extern "C" int mpv_video_resized_crop_u8(const uint8_t* clip, int T, int H, int W, int crop_i, int crop_j, int crop_h, int crop_w, int out_h,
+                                        int out_w, int mode, int flip, uint8_t* out, hipStream_t stream) {
+  MPV_REQUIRE(clip && out, MPV_E_ARG, "mpv_video_resized_crop_u8: null pointer");
+  MPV_REQUIRE(T > 0 && H > 0 && W > 0 && out_h > 0 && out_w > 0 && crop_h > 0 && crop_w > 0 && crop_i >= 0 && crop_j >= 0 &&
+                  crop_i + crop_h <= H && crop_j + crop_w <= W,
+              MPV_E_SHAPE, "mpv_video_resized_crop_u8: crop (%d,%d,%d,%d) outside a %dx%d frame", crop_i, crop_j, crop_h, crop_w, H, W);
+  MPV_REQUIRE(mode >= 0 && mode <= 2, MPV_E_ARG, "mpv_video_resized_crop_u8: mode must be 0 (nearest), 1 (bilinear) or 2 (bicubic)");
+  VideoTfArgs a = {};
+  a.clip = clip; a.out_u8 = out;
+  a.T = T; a.H = H; a.W = W; a.ci = crop_i; a.cj = crop_j; a.ch = crop_h; a.cw = crop_w; a.oh = out_h; a.ow = out_w;
+  a.mode = mode; a.flip = flip;
+  hipLaunchKernelGGL(video_transform_kernel, dim3(ew_grid((long long)T * out_h * out_w)), dim3(256), 0, stream, a);
+  return mpv_check_launch("mpv_video_resized_crop_u8");
 }
 
 extern "C" int mpv_soft_target_ce(const float* sim, const int64_t* row_ids, const int64_t* col_ids, float scale, float* losses,
