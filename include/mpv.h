@@ -250,6 +250,11 @@ int mpv_gpt_embed_fwd(const void* query, const int64_t* ids, const void* wte, co
 /* dquery[b,q,:] = dh[b,q,:] * keepmask/(1-p) */
 int mpv_gpt_embed_bwd(const void* dh, void* dquery, int B, int Q, int L, int H, float dropout_p, uint64_t seed,
                       uint64_t offset, mpv_stream_t stream);
+/* The same dropout mask applied to the gradient of EVERY row of the embedding output: dfull[rows, H] = dropout_mask * dh (rows = B * S).
+ * A trainable decoder (freeze_text_decoder: false, models/distributed_gpt3.py:91-93) needs it for the word- and position-embedding
+ * gradients (GPT3Embedding, models/modeling_distributed_gpt3.py:640-666). */
+int mpv_gpt_embed_bwd_full(const void* dh, void* dfull, int64_t rows, int H, float dropout_p, uint64_t seed, uint64_t offset,
+                           mpv_stream_t stream);
 
 /* Masked cross-entropy over bf16 logits in fp32 (models/modeling_distributed_gpt3.py:1352-1359,
  * 1615-1617): losses[r] = lse(logits[r]) - logits[r][labels[r]];  if dlogits != NULL it is

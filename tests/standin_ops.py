@@ -345,6 +345,11 @@ def gpt_embed_bwd(dh, B, Q, L, H, dropout_p=0.0, seed=0, offset=0):
     return dh.view(B, Q + L, H)[:, :Q].reshape(B * Q, H).clone()
 
 
+def gpt_embed_bwd_full(dh, rows, H, dropout_p=0.0, seed=0, offset=0):
+    assert dropout_p == 0.0
+    return dh.view(rows, H).clone()
+
+
 def cross_entropy(logits, labels, weight, rows, vocab, *, ld=None, dlogits=None, want_losses=True):
     ld = ld or vocab
     lg = _rd(logits, torch.arange(rows), ld, vocab)
@@ -489,7 +494,7 @@ def decode_step(self, tokens, query_embeds=None):
 
 NAMES = ["ln_stream_fwd", "ln_stream_bwd", "LnDparamBatch", "accum_f32", "f32_to_bf16", "copy_segments", "vit_compose_bwd_finish", "caption_targets", "gather_rows_ld", "logprob_topk", "add", "gather_rows", "scatter_rows", "l2norm_fwd", "l2norm_bwd", "soft_target_ce", "gemm", "layernorm_fwd", "layernorm_bwd", "AttnLayout", "attn_fwd", "attn_bwd", "temporal_attn_fwd", "temporal_attn_bwd",
          "im2col_patches", "vit_embed_assemble_fwd", "vit_embed_assemble_bwd", "vit_cls_fix_fwd", "vit_cls_merge_bwd_inplace",
-         "copy_rows", "colsum", "gpt_embed_fwd", "gpt_embed_bwd", "cross_entropy"]
+         "copy_rows", "colsum", "gpt_embed_fwd", "gpt_embed_bwd", "gpt_embed_bwd_full", "cross_entropy"]
 
 
 def install(monkeypatch):

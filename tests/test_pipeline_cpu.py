@@ -70,6 +70,54 @@ def test_pipelines_on_standins_vs_reference_golden(monkeypatch):
     assert not bad, bad[:8]
 
 
+def test_trainable_decoder_gradients_on_standins(monkeypatch):
+    """freeze_text_decoder: false (models/distributed_gpt3.py:91-93): the decoder's weight, bias, LayerNorm and (tied) embedding
+    gradients of the explicit backward against autograd through the fp32 restatement, on the stand-ins (host logic: which saved
+    activation meets which gradient, the LM-head + lookup halves of the word-embedding gradient, the position-embedding sum)."""
+    from oracle import restate
+    from oracle.weights import CONFIG_TINY, make_inputs, make_state_dict
+    from youku_mplug_amd.pretrain import DistributedGPT3_Pretrain
+    from youku_mplug_amd.gpt3 import GPT3Config
+    standin_ops.install(monkeypatch)
+    cfg = CONFIG_TINY
+    vis = dict(img_size=cfg.img_size, patch_size=cfg.patch_size, depth=cfg.vit_depth, num_frames=cfg.num_frames, embed_dim=cfg.vit_dim,
+               num_heads=cfg.vit_heads, mlp_ratio=cfg.vit_mlp_ratio, clip_model=True)
+    txt = GPT3Config(vocab_size=cfg.vocab, hidden_size=cfg.hidden, ffn_hidden_size=cfg.ffn, num_hidden_layers=cfg.layers,
+                     num_attention_heads=cfg.heads, max_position_embeddings=cfg.max_pos, layernorm_epsilon=cfg.gpt_ln_eps)
+    model = DistributedGPT3_Pretrain({"num_learnable_token": cfg.num_queries, "_synthetic": True, "freeze_text_decoder": False},
+                                     visual_cfg=vis, text_cfg=txt, device="cpu")
+    sd = make_state_dict(cfg, 17)
+    model.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+    model.eval()                                                     # dropout off: the masks are not reproducible across implementations
+    assert model.text_decoder.trainable
+    video, ids, mask = make_inputs(cfg, 3, 10, seed=23, ragged=True)
+    text = types.SimpleNamespace(input_ids=ids, attention_mask=mask)
+    loss, _ = model(video.to(torch.bfloat16), text)
+    loss.backward()
+    sdr = {k: v.bfloat16().float().requires_grad_(True) for k, v in sd.items()}
+    ref = restate.pretrain_forward(video.bfloat16().float(), ids, mask, sdr, cfg)
+    ref["loss"].backward()
+    assert abs(loss.item() - ref["loss"].item()) <= 5e-3 * abs(ref["loss"].item())
+    lm = "text_decoder.dist_model.language_model."
+    keys = [lm + "embedding.word_embeddings.weight", lm + "embedding.position_embeddings.weight", lm + "encoder.final_layernorm.weight",
+            lm + "encoder.final_layernorm.bias"]
+    for i in range(cfg.layers):
+        b = f"{lm}encoder.layers.{i}."
+        keys += [b + n for n in ("input_layernorm.weight", "input_layernorm.bias", "post_attention_layernorm.weight", "self_attention.query_key_value.weight",
+                                 "self_attention.query_key_value.bias", "self_attention.dense.weight", "self_attention.dense.bias", "mlp.dense_h_to_4h.weight",
+                                 "mlp.dense_h_to_4h.bias", "mlp.dense_4h_to_h.weight", "mlp.dense_4h_to_h.bias")]
+    keys += ["visual_fc.weight", "visual_encoder.blocks.0.attn.qkv.weight"]      # and the frozen-decoder gradients are still right
+    params = dict(model.named_parameters())
+    bad = []
+    for k in keys:
+        g, r = params[k].grad, sdr[k].grad
+        assert g is not None and r is not None, k
+        e = rel(g, r)
+        if not (math.isfinite(e) and e <= 4e-2):
+            bad.append((k, e))
+    assert not bad, bad
+
+
 def test_composed_temporal_backward_matches_two_launch_backward(monkeypatch):
     """TimeSformer.forward_features / backward_features: proj + temporal_fc as one composed projection vs the reference's two
     products, two dgrads and two wgrads -- the same loss and gradients up to bf16 rounding of the intermediate products, for

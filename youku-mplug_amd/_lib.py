@@ -85,6 +85,7 @@ _SIGS = {
                                             C.POINTER(c_int), c_int, c_int64, c_void_p]),
     "mpv_gpt_embed_fwd": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_float, c_uint64, c_uint64, c_void_p]),
     "mpv_gpt_embed_bwd": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_float, c_uint64, c_uint64, c_void_p]),
+    "mpv_gpt_embed_bwd_full": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_uint64, c_uint64, c_void_p]),
     "mpv_cross_entropy": (c_int, [c_void_p] * 6 + [c_int64] * 3 + [c_void_p]),
     "mpv_l2norm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p]),
     "mpv_l2norm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),

@@ -315,6 +315,24 @@ __global__ void gpt_embed_bwd_kernel(const bf16* __restrict__ dh, bf16* __restri
   }
 }
 
+// dropout mask of the embedding front applied to the gradient of EVERY row (trainable decoder: word / position embedding gradients)
+__global__ void gpt_embed_bwd_full_kernel(const bf16* __restrict__ dh, bf16* __restrict__ dfull, long long rows, int H, float drop_scale, uint32_t thr,
+                                          uint64_t seed, uint64_t offset) {
+  const int H8 = H / 8;
+  const long long total = rows * H8;
+  const uint64_t seed_r = thr ? mpv_resolve_seed(seed) : 0;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(idx % H8);
+    const long long row = idx / H8;
+    f32x8 v = cvt8(*(const bf16x8*)(dh + row * H + c8 * 8));
+    if (thr) {
+      const uint64_t base = offset + (uint64_t)row * (uint64_t)H + (uint64_t)(c8 * 8);
+      v = mpv_dropout_vec<f32x8, 8>(v, seed_r, base, thr, drop_scale);
+    }
+    *(bf16x8*)(dfull + row * H + c8 * 8) = cvt8(v);
+  }
+}
+
 // ---------------------------------------------------------------- masked cross-entropy
 // one workgroup per row; two sweeps over the row (second one hits L2): stats, then gradient.
 __global__ __launch_bounds__(256) void cross_entropy_kernel(const bf16* __restrict__ logits, const int64_t* __restrict__ labels,
@@ -910,6 +928,16 @@ extern "C" int mpv_video_resized_crop_normalize(const uint8_t* clip, int T, int 
   for (int c = 0; c < 3; ++c) { a.mean[c] = mean3[c]; a.stdv[c] = std3[c]; }
   hipLaunchKernelGGL(video_transform_kernel, dim3(ew_grid((long long)T * out_h * out_w)), dim3(256), 0, stream, a);
   return mpv_check_launch("mpv_video_resized_crop_normalize");
+}
+
+extern "C" int mpv_gpt_embed_bwd_full(const void* dh, void* dfull, int64_t rows, int H, float dropout_p, uint64_t seed, uint64_t offset,
+                                     hipStream_t stream) {
+  MPV_REQUIRE(dh && dfull, MPV_E_ARG, "mpv_gpt_embed_bwd_full: null pointer");
+  MPV_REQUIRE(rows > 0 && H > 0 && H % 8 == 0, MPV_E_SHAPE, "mpv_gpt_embed_bwd_full: H must be a multiple of 8");
+  MPV_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, MPV_E_ARG, "mpv_gpt_embed_bwd_full: bad dropout_p");
+  hipLaunchKernelGGL(gpt_embed_bwd_full_kernel, dim3(ew_grid(rows * (H / 8))), dim3(256), 0, stream, (const bf16*)dh, (bf16*)dfull, (long long)rows, H,
+                     1.0f / (1.0f - dropout_p), dropout_p > 0.f ? mpv_drop_threshold(dropout_p) : 0u, seed, offset);
+  return mpv_check_launch("mpv_gpt_embed_bwd_full");
 }
 
 extern "C" int mpv_video_resized_crop_u8(const uint8_t* clip, int T, int H, int W, int crop_i, int crop_j, int crop_h, int crop_w, int out_h,

@@ -24,6 +24,7 @@ import torch
 from torch import nn
 
 from . import ops
+from .vision import grad_of
 from .ops import ACT_GELU_TANH
 from .vision import Linear, _param
 
@@ -179,6 +180,11 @@ class DistributedGPT3(nn.Module):
         self.step_seed = 0        # bumped by the engine every step -> fresh dropout masks
         self.seed_dev = None      # engine.enable_device_step_state(): int64[4] device tensor, seed of decoder pass k of this step
 
+    @property
+    def trainable(self) -> bool:
+        """freeze_text_decoder: false (models/distributed_gpt3.py:91-93): the decoder's own parameters receive gradients"""
+        return any(p.requires_grad for p in self.parameters())
+
     # -------------------------------------------------------------- explicit forward / backward
     def forward_lm(self, query_features: Optional[torch.Tensor], ids: torch.Tensor, labels: Optional[torch.Tensor],
                    loss_mask: Optional[torch.Tensor], tape: dict, want_logits: bool = False, hidden_only: bool = False,
@@ -220,7 +226,12 @@ class DistributedGPT3(nn.Module):
                 window = (w0, wl)
         nl = len(lm.encoder.layers)
         layers = []
-        if FP32_STREAM:
+        train_dec = self.trainable and not want_logits      # (autograd.Function.forward runs with grad mode off: not a usable signal)
+        if train_dec:
+            # a trainable decoder runs the reference's own bf16 residual stream (the LayerNorm backward with parameter gradients reads
+            # bf16 rows) on all rows of every layer, and keeps what the weight gradients need: the inputs of the four products
+            h, xf, mf, rf = self._layers_bf16_stream(h, lay, scale, window, layers, seed, p_h, p_a, B, S, R, H, np_, hn, keep_inputs=True)
+        elif FP32_STREAM:
             # stream = the residual stream (bf16 straight out of the embedding, fp32 from the first add on); `pending` = the last
             # sublayer output (bias + dropout applied by its GEMM) that the next LayerNorm adds into the stream in fp32
             stream, pending, pmap = h, None, ops.IDENT
@@ -272,7 +283,7 @@ class DistributedGPT3(nn.Module):
             logits = ops.gemm(xf, lm.embedding.word_embeddings.weight, Rw, V, H)       # xf is already the window's rows
             _, loss = ops.cross_entropy(logits, window_targets[0], window_targets[1], Rw, V, dlogits=logits)
             tape.update(B=B, Q=Q, L=L, S=S, layers=layers, h_last=h, sf=(mf, rf), dlogits=logits, lm_window=window, lay=lay, scale=scale,
-                        seed=seed, p_h=p_h, p_a=p_a)
+                        seed=seed, p_h=p_h, p_a=p_a, xf=xf if train_dec else None, ids=ids_dev if train_dec else None)
             return dict(loss=loss, losses=None, last_hidden_state=None)
         lmf = loss_mask.to(torch.float32)
         denom = lmf.sum()
@@ -292,17 +303,20 @@ class DistributedGPT3(nn.Module):
             keep_logits = logits.clone() if want_logits else None
             losses, loss = ops.cross_entropy(logits, labels.contiguous().view(-1), w.view(-1), R, V, dlogits=logits)
         tape.update(B=B, Q=Q, L=L, S=S, layers=layers, h_last=h, sf=(mf, rf), dlogits=logits, lm_window=window, lay=lay, scale=scale,
-                    seed=seed, p_h=p_h, p_a=p_a)
+                    seed=seed, p_h=p_h, p_a=p_a, xf=xf if train_dec else None, ids=ids_dev if train_dec else None)
         # under a loss window the top layer and the final LayerNorm exist on the window rows only: no full last_hidden_state
         out = dict(loss=loss, losses=losses.view(B, S)[:, :S - 1], last_hidden_state=xf.view(B, S, H) if window is None else None)
         if want_logits:
             out["logits"] = keep_logits.view(B, S, V)
         return out
 
-    def _layers_bf16_stream(self, h, lay, scale, window, layers, seed, p_h, p_a, B, S, R, H, np_, hn):
-        """The layer stack with the reference's bf16 residual stream (residual adds in the GEMM epilogues): MPV_DECODER_STREAM=bf16."""
+    def _layers_bf16_stream(self, h, lay, scale, window, layers, seed, p_h, p_a, B, S, R, H, np_, hn, keep_inputs=False):
+        """The layer stack with the reference's bf16 residual stream (residual adds in the GEMM epilogues): MPV_DECODER_STREAM=bf16,
+        and always for a trainable decoder (keep_inputs: x1 / x2 / gelu(z) stay on the tape for the weight gradients, and the top layer
+        is not trimmed to the loss window)."""
         lm = self.dist_model.language_model
         nl = len(lm.encoder.layers)
+        trim_top = window is not None and not keep_inputs
         for li, layer in enumerate(lm.encoder.layers):
             ln = li + 1
             att, mlp = layer.self_attention, layer.mlp
@@ -311,7 +325,7 @@ class DistributedGPT3(nn.Module):
             ctx = torch.empty((R, H), dtype=torch.bfloat16, device=h.device)
             lse = ops.attn_fwd(qkv, qkv[:, hn:], qkv[:, 2 * hn:], ctx, lay, B, np_, S, S, hn, causal=True, scale=scale,
                                dropout_p=p_a, seed=seed, offset=_offset(ln, _SITE_ATTN))
-            if window is not None and li == nl - 1:
+            if trim_top and li == nl - 1:
                 # Top layer under a loss window: nothing downstream reads its hidden states outside the window (they feed only
                 # the LM head, which runs on the window), and everything after the attention is row-wise -- the projection,
                 # LN2, the MLP and their residual adds run on the B * wl window rows (a row map on the [B*S, H] stream; the
@@ -343,7 +357,10 @@ class DistributedGPT3(nn.Module):
             g = ops.gemm(x2, mlp.dense_h_to_4h.weight, R, F4, H, bias=mlp.dense_h_to_4h.bias, act=ACT_GELU_TANH, preact_out=z)
             h2 = ops.gemm(g, mlp.dense_4h_to_h.weight, R, H, F4, bias=mlp.dense_4h_to_h.bias, residual=h1, dropout_p=p_h,
                           seed=seed, offset=_offset(ln, _SITE_DROP2))
-            layers.append(dict(h=h, s1=(m1, r1), qkv=qkv, ctx=ctx, lse=lse, h1=h1, s2=(m2, r2), z=z))
+            ent = dict(h=h, s1=(m1, r1), qkv=qkv, ctx=ctx, lse=lse, h1=h1, s2=(m2, r2), z=z)
+            if keep_inputs:
+                ent.update(x1=x1, x2=x2, g=g)
+            layers.append(ent)
             h = h2
         fl = lm.encoder.final_layernorm
         if window is not None:       # final LayerNorm on the window rows of the stream -> compact [B * wl, H]
@@ -395,6 +412,13 @@ class DistributedGPT3(nn.Module):
         nl = len(lm.encoder.layers)
         fl = lm.encoder.final_layernorm
         tm = None
+        td = tape.get("xf") is not None       # trainable decoder (forward_lm kept the GEMM inputs): weight gradients below
+        wte = lm.embedding.word_embeddings.weight
+        if td and tape["dlogits"] is not None:
+            # tied LM head (:1348-1350): dWte = grad_loss * dlogits^T xf over the rows the head ran on (the loss window, or all rows);
+            # the lookup half of the word-embedding gradient is added at the end (embedding front)
+            rows_lm = B * tape["lm_window"][1] if tape.get("lm_window") is not None else R
+            ops.gemm(tape["dlogits"], tape["xf"], V, H, rows_lm, trans_a=True, trans_b=True, alpha_dev=grad_loss, out=grad_of(wte))
         if tape["dlogits"] is not None and tape.get("lm_window") is not None:
             # LM head dgrad on the loss window only (few output tiles, K = V: split along K inside mpv_gemm_bf16): dxf is the
             # compact [B * wl, H] gradient of the final LayerNorm's window rows; the final LayerNorm and the top layer's
@@ -412,10 +436,21 @@ class DistributedGPT3(nn.Module):
             dxf = d_last_hidden
         drop = p_h > 0.0
         dh_m = torch.empty((R, H), dtype=torch.bfloat16, device=dxf.device) if drop else None
-        if tm is not None:      # window rows of the [B*S, H] stream (the other rows of dh / dh_m are never read)
+        lnp = lambda ln_mod: dict(dgamma=grad_of(ln_mod.weight), dbeta=grad_of(ln_mod.bias)) if td else {}
+        if tm is not None and td:
+            # trainable decoder: every layer runs on all rows; the rows outside the window carry an exactly-zero gradient
+            dh = torch.zeros((R, H), dtype=torch.bfloat16, device=dxf.device)
+            if dh_m is not None:
+                dh_m.zero_()
+            self._ln_bwd(dxf, tape["h_last"], fl.weight, *tape["sf"], B * tm[0], H, dx=dh, dx_drop=dh_m, dropout_p=p_h, seed=seed,
+                              offset=_offset(nl, _SITE_DROP2), xmap=tm, **lnp(fl))
+        elif tm is not None:      # window rows of the [B*S, H] stream (the other rows of dh / dh_m are never read)
             dh = torch.empty((R, H), dtype=torch.bfloat16, device=dxf.device)
             self._ln_bwd(dxf, tape["h_last"], fl.weight, *tape["sf"], B * tm[0], H, dx=dh, dx_drop=dh_m, dropout_p=p_h, seed=seed,
                               offset=_offset(nl, _SITE_DROP2), xmap=tm)
+        elif td:
+            dh = self._ln_bwd(dxf, tape["h_last"], fl.weight, *tape["sf"], R, H, dx_drop=dh_m, dropout_p=p_h, seed=seed,
+                                   offset=_offset(nl, _SITE_DROP2), **lnp(fl))
         else:
             dh = self._ln_bwd(dxf, tape["h_last"], fl.weight, *tape["sf"], R, H, dx_drop=dh_m, dropout_p=p_h, seed=seed,
                                    offset=_offset(nl, _SITE_DROP2))
@@ -442,23 +477,48 @@ class DistributedGPT3(nn.Module):
                 self._dgrad(da, att.dense.weight, Rw, H, H, amap=rm, cmap=rm, out=dctx)
             else:
                 dz = self._dgrad(do, mlp.dense_4h_to_h.weight, R, F4, H, act_bwd_z=s["z"], act_bwd=ACT_GELU_TANH)
+                if td:      # dense_4h_to_h: dW = do^T gelu(z), db = colsum(do); dense_h_to_4h: dW = dz^T x2, db = colsum(dz)
+                    ops.gemm(do, s["g"], H, F4, R, trans_a=True, trans_b=True, out=grad_of(mlp.dense_4h_to_h.weight))
+                    ops.colsum(do, R, H, out=grad_of(mlp.dense_4h_to_h.bias))
+                    ops.gemm(dz, s["x2"], F4, H, R, trans_a=True, trans_b=True, out=grad_of(mlp.dense_h_to_4h.weight))
+                    ops.colsum(dz, R, F4, out=grad_of(mlp.dense_h_to_4h.bias))
                 dx2 = self._dgrad(dz, mlp.dense_h_to_4h.weight, R, H, F4)
                 dh1_m = torch.empty((R, H), dtype=torch.bfloat16, device=dh.device) if drop else None
                 dh1 = self._ln_bwd(dx2, s["h1"], layer.post_attention_layernorm.weight, *s["s2"], R, H, dres=dh, dx_drop=dh1_m,
-                                        dropout_p=p_h, seed=seed, offset=_offset(ln, _SITE_DROP1))
+                                        dropout_p=p_h, seed=seed, offset=_offset(ln, _SITE_DROP1), **lnp(layer.post_attention_layernorm))
                 da = dh1_m if drop else dh1
+                if td:      # attention output projection: dW = da^T ctx
+                    ops.gemm(da, s["ctx"], H, H, R, trans_a=True, trans_b=True, out=grad_of(att.dense.weight))
+                    ops.colsum(da, R, H, out=grad_of(att.dense.bias))
                 dctx = self._dgrad(da, att.dense.weight, R, H, H)
             qkv = s["qkv"]
             dqkv = torch.empty_like(qkv)
             ops.attn_bwd(qkv, qkv[:, hn:], qkv[:, 2 * hn:], s["ctx"], s["lse"], dctx, dqkv, dqkv[:, hn:], dqkv[:, 2 * hn:], lay,
                          B, np_, S, S, hn, causal=True, scale=scale, dropout_p=p_a, seed=seed, offset=_offset(ln, _SITE_ATTN))
+            if td:      # fused q/k/v projection: dW = dqkv^T x1
+                ops.gemm(dqkv, s["x1"], 3 * H, H, R, trans_a=True, trans_b=True, out=grad_of(att.query_key_value.weight))
+                ops.colsum(dqkv, R, 3 * H, out=grad_of(att.query_key_value.bias))
             dx1 = self._dgrad(dqkv, att.query_key_value.weight, R, H, 3 * H)
             prev_off = _offset(li, _SITE_DROP2) if li > 0 else 0
             want_mask = drop and li > 0
             dh_m = torch.empty((R, H), dtype=torch.bfloat16, device=dh.device) if want_mask else None
             dh = self._ln_bwd(dx1, s["h"], layer.input_layernorm.weight, *s["s1"], R, H, dres=dh1, dx_drop=dh_m,
-                                   dropout_p=p_h if want_mask else 0.0, seed=seed, offset=prev_off)
+                                   dropout_p=p_h if want_mask else 0.0, seed=seed, offset=prev_off, **lnp(layer.input_layernorm))
             tape["layers"][li] = None
+        if td:
+            # embedding front (GPT3Embedding, :640-666): h0 = dropout(x + wpe[s]) with x = the query features (s < Q) or wte[ids].
+            # de = mask * dh on every row; dWpe[s] = sum over the batch of de[b, s]; the word-embedding rows get de through the
+            # lookup -- a one-hot product so that repeated tokens add up: dWte += onehot(ids)^T de[text rows] (on top of the LM head's half)
+            de = ops.gpt_embed_bwd_full(dh, R, H, dropout_p=p_h, seed=seed, offset=_offset(0, _SITE_EMBED))
+            wpe = lm.embedding.position_embeddings.weight
+            gpe = grad_of(wpe)
+            gpe.zero_()
+            ops.colsum(de, B, S * H, out=gpe.view(-1)[:S * H])
+            if L > 0:
+                onehot = torch.zeros((B * L, V), dtype=torch.bfloat16, device=dh.device)
+                onehot.scatter_(1, tape["ids"].reshape(-1, 1), 1.0)
+                de_text = ops.copy_rows(de, torch.empty((B * L, H), dtype=torch.bfloat16, device=dh.device), B * L, H, smap=(L, S, Q))
+                ops.gemm(onehot, de_text, V, H, B * L, trans_a=True, trans_b=True, accumulate=True, out=grad_of(wte))
         if Q == 0:
             return None
         return ops.gpt_embed_bwd(dh, B, Q, L, H, dropout_p=p_h, seed=seed, offset=_offset(0, _SITE_EMBED))

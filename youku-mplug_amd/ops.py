@@ -384,6 +384,13 @@ def gpt_embed_fwd(query, ids, wte, wpe, B, Q, L, H, dropout_p=0.0, seed=0, offse
     return h
 
 
+def gpt_embed_bwd_full(dh, rows, H, dropout_p=0.0, seed=0, offset=0):
+    """dropout-masked gradient of every row of the embedding output (trainable decoder): include/mpv.h"""
+    out = torch.empty((rows, H), dtype=torch.bfloat16, device=dh.device)
+    check(_lib.lib().mpv_gpt_embed_bwd_full(dh.data_ptr(), out.data_ptr(), rows, H, dropout_p, seed, offset, _stream()), "mpv_gpt_embed_bwd_full")
+    return out
+
+
 def gpt_embed_bwd(dh, B, Q, L, H, dropout_p=0.0, seed=0, offset=0):
     dq = torch.empty((B * Q, H), dtype=torch.bfloat16, device=dh.device)
     check(_lib.lib().mpv_gpt_embed_bwd(dh.data_ptr(), dq.data_ptr(), B, Q, L, H, dropout_p, seed, offset, _stream()),

@@ -57,11 +57,9 @@ class DistributedGPT3_Pretrain(nn.Module):
             for name, p in self.visual_encoder.named_parameters():
                 if not any(x in name for x in ("time", "temporal")):
                     p.requires_grad = False
-        if not config.get("freeze_text_decoder", True):
-            raise NotImplementedError("the gfx950 path implements the frozen-decoder recipe (freeze_text_decoder: true, "
-                                      "configs/pretrain/gpt3_1.3B/pretrain_gpt3_freezeGPT_youku_v0.yaml:23)")
-        for p in self.text_decoder.parameters():                                          # :91-93
-            p.requires_grad = False
+        if config.get("freeze_text_decoder", True):                                       # :91-93 (every shipped recipe freezes it)
+            for p in self.text_decoder.parameters():
+                p.requires_grad = False
         self.vision_width = visual_cfg["embed_dim"]
         self.text_width = self.text_decoder.config.hidden_size
         self.num_learnable_token = config.get("num_learnable_token", 256)                 # :102
