@@ -134,7 +134,7 @@ def _data(n=8, dim=24):
     return torch.randn(n, dim, generator=g), torch.randn(n, 5, generator=g)
 
 
-def _engine_worker(rank, world, port, q):
+def _engine_worker(rank, world, port, q, zero=0, ckpt_dir=None):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -143,7 +143,10 @@ def _engine_worker(rank, world, port, q):
     model = _StubModel(seed=1234 + rank)                  # the reference seeds every rank differently (run_pretrain...py:210)
     launched = []
     groups = eng.get_parameter_groups(model, 0.05)
-    engine, opt, _, _ = eng.initialize(model=model, model_parameters=groups, config=dict(lr=1e-2, clip_grad=0.5, opt_eps=1e-6))
+    cfg = dict(lr=1e-2, clip_grad=0.5, opt_eps=1e-6)
+    if zero:
+        cfg["zero_optimization"] = {"stage": zero}        # as utils.py:528-529 writes it into the DeepSpeed config
+    engine, opt, _, _ = eng.initialize(model=model, model_parameters=groups, config=cfg)
     orig = engine.reducer.stage_ready
     engine.reducer.stage_ready = lambda name: (launched.append(name), orig(name))[1]
     model.visual_encoder.on_block_grads_ready = lambda bi: engine.reducer.stage_ready("stem" if bi < 0 else f"block{bi}")
@@ -155,7 +158,18 @@ def _engine_worker(rank, world, port, q):
         loss, _ = engine(xs, ys)
         engine.backward(loss)
         engine.step()
-    q.put((rank, p0, engine.flat.params.clone(), list(engine.flat.stage_slices.items()), launched[:6], opt._global_grad_norm))
+    extra = None
+    if zero:
+        assert engine.zero_shards is not None and opt.master.numel() == opt.hi - opt.lo < engine.flat.numel
+        engine.save_checkpoint(ckpt_dir, tag="z")
+        files = sorted(os.listdir(os.path.join(ckpt_dir, "z")))
+        before = (engine.flat.params.clone(), opt.exp_avg.clone(), opt.step_count)
+        engine.flat.params.zero_()
+        opt.exp_avg.zero_()
+        engine.load_checkpoint(ckpt_dir, tag="z")
+        extra = (files, torch.equal(before[0], engine.flat.params) and torch.equal(before[1], opt.exp_avg) and opt.step_count == before[2],
+                 (opt.lo, opt.hi))
+    q.put((rank, p0, engine.flat.params.clone(), list(engine.flat.stage_slices.items()), launched[:6], opt._global_grad_norm, extra))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -196,6 +210,37 @@ def test_real_engine_world2_gloo(monkeypatch):
         engine.step()
     assert torch.allclose(engine.flat.params, res[0][1], atol=2e-6), (engine.flat.params - res[0][1]).abs().max()
     assert abs(opt._global_grad_norm - res[0][4]) < 1e-5
+
+
+def test_zero_stage1_world2_gloo_matches_replicated_optimizer(tmp_path):
+    """ZeRO stage 1 (utils.py:528-529): optimizer states partitioned over the ranks, every rank updates its own run of the flat buffer and
+    the runs are handed round -- the parameters after two steps are BIT-identical to the replicated optimizer's, each rank holds only
+    its shard of master / exp_avg / exp_avg_sq, and the checkpoint is DeepSpeed's ZeRO layout (one optimizer-state file per rank)
+    that loads back."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    results = {}
+    for zero in (0, 1):
+        q = ctx.Queue()
+        port = 26000 + (os.getpid() + 17 * zero) % 3000
+        d = str(tmp_path / f"ck{zero}")
+        os.makedirs(d, exist_ok=True)
+        procs = [ctx.Process(target=_engine_worker, args=(r, 2, port, q, zero, d)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = {r[0]: r[1:] for r in (q.get(timeout=180) for _ in range(2))}
+        for p in procs:
+            p.join(timeout=60)
+        results[zero] = res
+    for r in range(2):
+        assert torch.equal(results[0][r][1], results[1][r][1]), f"rank {r}: ZeRO-1 parameters differ from the replicated optimizer's"
+    assert torch.equal(results[1][0][1], results[1][1][1])
+    files, reloaded, shard0 = results[1][0][5]
+    _, _, shard1 = results[1][1][5]
+    assert reloaded and results[1][1][5][1]
+    assert "mp_rank_00_model_states.pt" in files and "zero_pp_rank_0_mp_rank_00_optim_states.pt" in files and \
+        "zero_pp_rank_1_mp_rank_00_optim_states.pt" in files and "mp_rank_00_optim_states.pt" not in files
+    assert shard0[0] == 0 and shard0[1] == shard1[0] and shard1[1] >= shard1[0]
 
 
 def test_gradient_accumulation_matches_big_batch(monkeypatch):

@@ -161,16 +161,21 @@ class FlatAdamW:
     """torch.optim-shaped facade (param_groups with lr / lr_scale / weight_decay / betas mutated by the
     training loop every step) over the grouped HIP AdamW kernel."""
 
-    def __init__(self, flat: FlatParams, param_groups: List[dict], lr=1e-4, betas=(0.9, 0.999), eps=1e-6, clip_grad=0.0):
+    def __init__(self, flat: FlatParams, param_groups: List[dict], lr=1e-4, betas=(0.9, 0.999), eps=1e-6, clip_grad=0.0,
+                 shard: Optional[Tuple[int, int]] = None):
+        """shard = (lo, hi), multiples of the 256-element tile: ZeRO stage 1 -- this rank keeps fp32 master / exp_avg / exp_avg_sq of
+        flat elements [lo, hi) only and updates only those (the engine then shares the updated bf16 slices between the ranks)."""
         assert len(param_groups) <= 8
         self.flat = flat
+        self.lo, self.hi = shard if shard is not None else (0, flat.numel)
+        assert self.lo % TILE == 0 and (self.hi % TILE == 0 or self.hi == flat.numel) and 0 <= self.lo <= self.hi <= flat.numel
         self.param_groups = param_groups
         for g in param_groups:
             g.setdefault("lr", lr * g.get("lr_scale", 1.0))
             g.setdefault("betas", list(betas))
             g.setdefault("eps", eps)
         self.clip_grad = clip_grad
-        self.master = flat.params.float()
+        self.master = flat.params[self.lo:self.hi].float()
         self.exp_avg = torch.zeros_like(self.master)
         self.exp_avg_sq = torch.zeros_like(self.master)
         self.sumsq = torch.zeros((), dtype=torch.float32, device=flat.device)
@@ -188,16 +193,20 @@ class FlatAdamW:
         self.step_count += 1
         self._grad_scale = grad_scale
         self.sumsq.zero_()
-        ops.grad_sumsq(self.flat.grads, self.sumsq)
+        ops.grad_sumsq(self.flat.grads, self.sumsq)          # the norm of the WHOLE (reduced) gradient, also under ZeRO-1
         g0 = self.param_groups[0]
+        if self.hi == self.lo:
+            return
+        p16, g16 = self.flat.params[self.lo:self.hi], self.flat.grads[self.lo:self.hi]
+        tg = self.flat.tile_group[self.lo // TILE:(self.hi + TILE - 1) // TILE]
         if self.hyper_dev is not None:
             if upload:                                     # (not while a graph is being captured: the values would be frozen with it)
                 self.upload_hyper()
-            ops.adamw_step_grouped_dev(self.flat.params, self.master, self.exp_avg, self.exp_avg_sq, self.flat.grads, self.flat.tile_group,
+            ops.adamw_step_grouped_dev(p16, self.master, self.exp_avg, self.exp_avg_sq, g16, tg,
                                        self.hyper_dev, float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]), grad_scale,
                                        self.sumsq, float(self.clip_grad or 0.0))
             return
-        ops.adamw_step_grouped(self.flat.params, self.master, self.exp_avg, self.exp_avg_sq, self.flat.grads, self.flat.tile_group,
+        ops.adamw_step_grouped(p16, self.master, self.exp_avg, self.exp_avg_sq, g16, tg,
                                [float(g["lr"]) for g in self.param_groups], [float(g["weight_decay"]) for g in self.param_groups],
                                float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]), self.step_count, grad_scale,
                                self.sumsq, float(self.clip_grad or 0.0))
@@ -211,14 +220,16 @@ class FlatAdamW:
 
     def state_dict(self):
         return {"master": self.master, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count,
+                "shard": (self.lo, self.hi),
                 "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
 
     def load_state_dict(self, sd):
+        assert tuple(sd.get("shard", (0, self.flat.numel))) == (self.lo, self.hi), "optimizer state of another ZeRO partition"
         self.master.copy_(sd["master"])
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_count = sd["step"]
-        self.flat.params.copy_(self.master)
+        self.flat.params[self.lo:self.hi].copy_(self.master)
 
 
 def init_process_group_for_dp(backend: Optional[str] = None, **kw):
@@ -258,7 +269,7 @@ def broadcast_module_state(model: nn.Module, flat: Optional["FlatParams"], proce
 
 class MplugEngine(nn.Module):
     def __init__(self, model: nn.Module, param_groups: List[dict], lr=1e-4, betas=(0.9, 0.999), eps=1e-6, clip_grad=0.0,
-                 process_group=None, gradient_accumulation_steps: int = 1):
+                 process_group=None, gradient_accumulation_steps: int = 1, zero_stage: int = 0):
         super().__init__()
         self.module = model
         self.gas = max(1, int(gradient_accumulation_steps))
@@ -275,7 +286,20 @@ class MplugEngine(nn.Module):
         # the window sum of micro-batch gradients is kept in fp32 (DeepSpeed's bf16 optimizer does the same): in bf16 every add
         # rounds to 8 mantissa bits and small contributions vanish against a large running sum
         self.grad_acc = torch.zeros(self.flat.numel, dtype=torch.float32, device=self.flat.device) if self.gas > 1 else None
-        self.optimizer = FlatAdamW(self.flat, param_groups, lr=lr, betas=betas, eps=eps, clip_grad=clip_grad)
+        # ZeRO stage 1 (utils.py:528-529, `--zero_stage 1`): optimizer states partitioned over the data-parallel ranks.  The flat
+        # buffer is cut into `world` runs of whole 256-element tiles; every rank still receives the whole reduced gradient (the
+        # bucketed all-reduce is unchanged: the clip needs its global norm), updates its own run, and the updated bf16 runs are
+        # broadcast from their owners.  (Stages 2 / 3 -- gradient / parameter partitioning -- are not built.)
+        assert zero_stage in (0, 1), "ZeRO stages 2 and 3 are not built"
+        self.zero_shards = None
+        shard = None
+        if zero_stage == 1 and self.reducer.world > 1:
+            ntiles = (self.flat.numel + TILE - 1) // TILE
+            per = (ntiles + self.reducer.world - 1) // self.reducer.world
+            self.zero_shards = [(min(r * per * TILE, self.flat.numel), min((r + 1) * per * TILE, self.flat.numel)) for r in range(self.reducer.world)]
+            shard = self.zero_shards[dist.get_rank(process_group)]
+        self.process_group = process_group
+        self.optimizer = FlatAdamW(self.flat, param_groups, lr=lr, betas=betas, eps=eps, clip_grad=clip_grad, shard=shard)
         self.micro_steps = 0                  # the training loop resets this every epoch (run_pretrain_distributed_gpt3.py:72-73)
         self._window_fill = 0                 # micro-batches summed into the current accumulation window
         self.micro_batches_seen = 0           # never reset, saved with the optimizer state: drives the dropout seed
@@ -341,7 +365,17 @@ class MplugEngine(nn.Module):
         self.reducer.hold = False
         self.reducer.finish()
         self.optimizer.step(grad_scale=1.0 / (self.reducer.world * self.gas))
+        self._share_zero_shards()
         self.global_steps += 1
+
+    def _share_zero_shards(self):
+        """ZeRO-1: every rank has updated its own run of the flat bf16 parameters; hand the runs round"""
+        if self.zero_shards is None:
+            return
+        for r, (lo, hi) in enumerate(self.zero_shards):
+            if hi > lo:
+                src = dist.get_global_rank(self.process_group, r) if self.process_group is not None else r
+                dist.broadcast(self.flat.params[lo:hi], src=src, group=self.process_group)
 
     def zero_grad(self):
         pass      # every gradient is overwritten (never accumulated) by the next backward
@@ -379,6 +413,7 @@ class MplugEngine(nn.Module):
             loss = self.module.forward_backward(*args)       # (not module(...) + loss.backward(): see forward_backward)
             self.reducer.finish()
             self.optimizer.step(grad_scale=1.0 / self.reducer.world, upload=False)
+            self._share_zero_shards()
             return loss
 
         def after():
@@ -443,13 +478,21 @@ class MplugEngine(nn.Module):
             state = {"module": {k: v.detach().cpu() for k, v in self.module.state_dict().items()}}
             state.update(client_state or {})
             torch.save(state, os.path.join(d, "mp_rank_00_model_states.pt"))
-            osd = dict(self.optimizer.state_dict(), micro_batches_seen=self.micro_batches_seen)
-            torch.save({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in osd.items()}, os.path.join(d, "mp_rank_00_optim_states.pt"))
+            if self.zero_shards is None:
+                osd = dict(self.optimizer.state_dict(), micro_batches_seen=self.micro_batches_seen)
+                torch.save({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in osd.items()}, os.path.join(d, "mp_rank_00_optim_states.pt"))
             with open(os.path.join(save_dir, "latest"), "w") as f:
                 f.write(str(tag))
         if dist.is_initialized():
             dist.barrier()
+        if self.zero_shards is not None:       # DeepSpeed's ZeRO layout: one optimizer-state file per data-parallel rank
+            osd = dict(self.optimizer.state_dict(), micro_batches_seen=self.micro_batches_seen)
+            torch.save({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in osd.items()}, os.path.join(d, self._zero_file()))
+            dist.barrier()
         return True
+
+    def _zero_file(self):
+        return f"zero_pp_rank_{dist.get_rank(self.process_group)}_mp_rank_00_optim_states.pt"
 
     def load_checkpoint(self, load_dir, tag=None):
         if tag is None:
@@ -463,12 +506,13 @@ class MplugEngine(nn.Module):
         if unexpected:
             raise KeyError(f"checkpoint {d} holds keys this model does not have: {sorted(unexpected)[:8]}")
         self.last_load_missing_keys = list(missing)
-        op = os.path.join(d, "mp_rank_00_optim_states.pt")
+        op = os.path.join(d, self._zero_file() if self.zero_shards is not None else "mp_rank_00_optim_states.pt")
         osd = torch.load(op, map_location=self.flat.device) if os.path.isfile(op) else None
-        if osd is not None and osd["master"].numel() == self.optimizer.master.numel():
+        if osd is not None and osd["master"].numel() == self.optimizer.master.numel() and \
+                tuple(osd.get("shard", (0, self.flat.numel))) == (self.optimizer.lo, self.optimizer.hi):
             self.optimizer.load_state_dict(osd)
         else:       # weights only, or a checkpoint of another shape (resized embeddings): fresh optimizer state, as the
-            self.optimizer.master.copy_(self.flat.params.float())     # downstream scripts build a new optimizer after --resume
+            self.optimizer.master.copy_(self.flat.params[self.optimizer.lo:self.optimizer.hi].float())     # downstream scripts build a new optimizer after --resume
             self.optimizer.exp_avg.zero_()
             self.optimizer.exp_avg_sq.zero_()
             self.optimizer.step_count = 0
@@ -496,9 +540,12 @@ def initialize(args=None, model=None, model_parameters=None, dist_init_required=
     groups = list(model_parameters) if model_parameters is not None else get_parameter_groups(model, pick("weight_decay", 0.05))
     groups = [g if isinstance(g, dict) else {"params": [g], "weight_decay": 0.0, "lr_scale": 1.0} for g in groups]
     gas = pick("gradient_accumulation_steps", None) or pick("update_freq", 1) or 1
+    zero = pick("zero_stage", 0) or 0                                                     # utils.py:528-529 (`--zero_stage`)
+    if isinstance(cfg.get("zero_optimization"), dict):                                    # ... or the DeepSpeed config it is copied into
+        zero = cfg["zero_optimization"].get("stage", zero)
     engine = MplugEngine(model, groups, lr=pick("lr", 1e-4), betas=tuple(pick("opt_betas", (0.9, 0.999))), eps=pick("opt_eps", 1e-6),
                          clip_grad=pick("clip_grad", 0.0) or 0.0, process_group=kw.get("process_group"),
-                         gradient_accumulation_steps=gas)
+                         gradient_accumulation_steps=gas, zero_stage=int(zero))
     return engine, engine.optimizer, None, None
 
 
