@@ -247,6 +247,167 @@ def test_retrieval_entrypoint_train_eval_resume(tmp_path, dev):
     assert set(res) == {"val", "test"} and all(0.0 <= v <= 100.0 for v in res["val"].values())
 
 
+def _write_finetune_config(d, name, extra, batch_size=4, tokens_to_generate=None):
+    _write_configs(d)
+    if tokens_to_generate is not None:                       # short beam searches for the caption test
+        cfg = json.load(open(os.path.join(d, "txt.json")))
+        cfg["tokens_to_generate"] = tokens_to_generate
+        json.dump(cfg, open(os.path.join(d, "txt.json"), "w"))
+    yml = f"""
+text_decoder: 'nlp_gpt3_text-generation_1.3B/'
+text_cfg: {d}/txt.json
+visual_cfg: '{d}/vis.json'
+_synthetic: true
+batch_size: {batch_size}
+num_workers: 0
+max_length: 24
+freeze_vit: false
+freeze_text_decoder: true
+num_learnable_token: 32
+{extra}
+optimizer: {{lr: 1e-4, opt: "AdamW", weight_decay: 0.05, clip_grad: 3.0, opt_betas: [0.9, 0.999], opt_eps: 1e-8}}
+schedular: {{epochs: 1, min_lr: 1e-7, warmup_epochs: -1, warmup_steps: 1, lr_sched_type: "cosine"}}
+"""
+    path = os.path.join(d, f"{name}.yaml")
+    open(path, "w").write(yml)
+    return path
+
+
+def _finetune_entry(module_name):
+    sys.path.insert(0, os.path.join(ROOT, "downstream"))
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(24000 + os.getpid() % 2000))
+    import importlib
+    return importlib.import_module(module_name)
+
+
+def test_itm_entrypoint_train_eval(tmp_path, dev):
+    """downstream/run_retrieval_distributed_gpt3_itm.py restated on this engine (reference :66-224, 228-286, 343-541): two ITM
+    training steps (two derangements of negatives per step, generation + matching-head losses), the re-ranking evaluation (every clip
+    against every title, generation and cls score matrices, recall both ways), checkpoint and log line; then `--evaluate_only
+    --resume <checkpoint>`."""
+    entry = _finetune_entry("run_retrieval_distributed_gpt3_itm")
+    cfg = _write_finetune_config(str(tmp_path), "itm", "use_cls: true")
+    out = str(tmp_path / "out")
+    args, config = entry.get_args(["--config", cfg, "--output_dir", out, "--bf16", "--enable_deepspeed", "--synthetic_steps", "2", "--seed", "5",
+                                   "--eval_freq", "1"])
+    assert config["num_classes"] == 2 and args.max_length == 24
+    stats = entry.main(args, config)
+    assert math.isfinite(stats["train_loss"]) and stats["train_grad_norm"] > 0
+    assert stats["train_loss_generation"] > 0 and stats["train_loss_cls"] > 0
+    assert abs(stats["train_loss"] - stats["train_loss_generation"] - stats["train_loss_cls"]) < 1e-3 * stats["train_loss"]
+    for split in ("val", "test"):
+        for head in ("gen", "cls"):
+            assert 0.0 <= stats[f"{split}_{head}_r_mean"] <= 100.0
+    ck = os.path.join(out, "checkpoint-0", "mp_rank_00_model_states.pt")
+    assert os.path.isfile(ck) and json.loads(open(os.path.join(out, "log.txt")).read().strip().splitlines()[-1])["epoch"] == 0
+    args2, config2 = entry.get_args(["--config", cfg, "--output_dir", str(tmp_path / "out2"), "--bf16", "--enable_deepspeed", "--synthetic_steps", "1",
+                                     "--evaluate_only", "--resume", ck])
+    res = entry.main(args2, config2)
+    # the checkpointed model scores the validation split as it did at the end of training
+    assert res["val"]["gen_r_mean"] == pytest.approx(stats["val_gen_r_mean"], abs=1e-6)
+    assert res["val"]["cls_r_mean"] == pytest.approx(stats["val_cls_r_mean"], abs=1e-6)
+
+
+def test_itm_random_derangement_and_labels():
+    """random_derangement (reference :42-53): permutations without fixed points, reproducible from `random`'s seed; a negative whose
+    video id equals the anchor's is labelled a match (:112-116)."""
+    import random
+    entry = _finetune_entry("run_retrieval_distributed_gpt3_itm")
+    random.seed(3)
+    for n in (2, 3, 7, 24):
+        v = entry.random_derangement(n)
+        assert sorted(v) == list(range(n)) and all(v[i] != i for i in range(n))
+    random.seed(11)
+    a = entry.random_derangement(9)
+    random.seed(11)
+    assert entry.random_derangement(9) == a
+    with pytest.raises(ValueError):
+        entry.random_derangement(1)
+    from finetune_common import SyntheticTextTokenizer
+    random.seed(0)
+    video = torch.zeros(3, 1)
+    _, text, ptext, neg, labels = entry.make_training_batch(video, ["\u4e00\u4e01", "\u4e02", "\u4e03\u4e04\u4e05"], torch.tensor([7, 7, 9]),
+                                                            SyntheticTextTokenizer(100), torch.device("cpu"), 24)
+    ids = [7, 7, 9]
+    assert labels.tolist() == [1, 1, 1] + [int(ids[i % 3] == ids[n]) for i, n in enumerate(neg)]
+    assert text.input_ids.shape == (9, 24) and ptext.input_ids.shape == (9, 24) and text.prompt_lengths.shape == (9,)
+
+
+def test_synthetic_tokenizer_pair_contract():
+    """SyntheticTextTokenizer keeps DistributedGPT3Tokenizer's call contract (models/modeling_distributed_gpt3.py:209-317): bos +
+    prompt + text + eos, prompt_lengths, padding to max_length, the prompt is cut before the target."""
+    _finetune_entry("finetune_common")
+    from finetune_common import SyntheticTextTokenizer
+    tok = SyntheticTextTokenizer(1000)
+    a, b = "\u4e00\u4e01\u4e02", "\u4e10\u4e11"
+    e = tok([[a, b]], padding="max_length", max_length=10)
+    assert e.input_ids.tolist() == [[1, 5, 6, 7, 21, 22, 0, 0, 0, 0]] and e.attention_mask.sum().item() == 7 and e.prompt_lengths.tolist() == [3]
+    e = tok([[a * 4, b]], padding="max_length", max_length=10)             # 12 prompt tokens: cut to 10 - 2 - 2 = 6
+    assert e.prompt_lengths.tolist() == [6] and e.attention_mask.sum().item() == 10 and e.input_ids[0, -3:].tolist() == [21, 22, 0]
+    e = tok([a, b * 6], padding="longest", max_length=8)
+    assert e.input_ids.shape == (2, 8) and e.attention_mask.sum(-1).tolist() == [5, 8]
+    assert tok.decode(tok([a], max_length=8).input_ids[0]) == a
+
+
+def test_cls_entrypoint_train_eval(tmp_path, dev):
+    """downstream/run_cls_distributed_gpt3.py restated on this engine (reference :50-200, 203-263, 266-470): two training steps
+    (generation loss on the class name + cls_head loss), top-1 / top-5 accuracy of both heads on val and test, checkpoint, log
+    line; then `--evaluate_only --resume`."""
+    entry = _finetune_entry("run_cls_distributed_gpt3")
+    cfg = _write_finetune_config(str(tmp_path), "cls", "use_cls: true\nnum_classes: 6", batch_size=20)
+    out = str(tmp_path / "out")
+    args, config = entry.get_args(["--config", cfg, "--output_dir", out, "--bf16", "--enable_deepspeed", "--synthetic_steps", "2", "--seed", "6"])
+    stats = entry.main(args, config)
+    assert math.isfinite(stats["train_loss"]) and stats["train_loss_cls"] > 0 and stats["train_grad_norm"] > 0
+    for split in ("val", "test"):
+        for head in ("gen", "cls"):
+            assert 0.0 <= stats[f"{split}_{head}_top1_accuracy"] <= stats[f"{split}_{head}_top5_accuracy"] <= 100.0
+    ck = os.path.join(out, "checkpoint-0", "mp_rank_00_model_states.pt")
+    args2, config2 = entry.get_args(["--config", cfg, "--output_dir", str(tmp_path / "out2"), "--bf16", "--enable_deepspeed", "--synthetic_steps", "1",
+                                     "--evaluate_only", "--resume", ck])
+    res = entry.main(args2, config2)
+    assert res["epoch"] == -1 and res["val_cls_top5_accuracy"] == pytest.approx(stats["val_cls_top5_accuracy"], abs=1e-6)
+    assert json.loads(open(os.path.join(str(tmp_path / "out2"), "log.txt")).read().strip().splitlines()[-1])["epoch"] == -1
+
+
+def test_caption_entrypoint_train_generate(tmp_path, dev):
+    """downstream/run_caption_distributed_gpt3.py restated on this engine (reference :66-205, 208-238, 301-500): two caption
+    training steps, a checkpoint; then `--evaluate_only --resume`: beam-search captions of the validation clips, the per-rank and
+    merged result files, and the metric line."""
+    entry = _finetune_entry("run_caption_distributed_gpt3")
+    cfg = _write_finetune_config(str(tmp_path), "caption", 'prompt: ""', tokens_to_generate=6)
+    out = str(tmp_path / "out")
+    args, config = entry.get_args(["--config", cfg, "--output_dir", out, "--bf16", "--enable_deepspeed", "--synthetic_steps", "2", "--seed", "7"])
+    stats = entry.main(args, config)
+    assert math.isfinite(stats["train_loss_generation"]) and stats["train_grad_norm"] > 0
+    ck = os.path.join(out, "checkpoint-0", "mp_rank_00_model_states.pt")
+    out2 = str(tmp_path / "out2")
+    args2, config2 = entry.get_args(["--config", cfg, "--output_dir", out2, "--bf16", "--enable_deepspeed", "--synthetic_steps", "1", "--evaluate_only",
+                                     "--resume", ck])
+    res = entry.main(args2, config2)
+    merged = json.load(open(os.path.join(out2, "result", "val_caption_result.json")))
+    assert len(merged) == 5 and all(set(r) == {"video_id", "pred_caption", "gold_caption"} and len(r["gold_caption"]) == 2 for r in merged)
+    assert os.path.isfile(os.path.join(out2, "result", "val_caption_result_rank0.json"))
+    assert all(0.0 <= res[f"val_{k}"] <= 1.0 for k in ("Bleu_1", "Bleu_4", "ROUGE_L")) and all(r["pred_caption"] for r in merged)
+
+
+def test_caption_metrics_known_answers():
+    """The built-in scorers against hand-computed values (pycocoevalcap's definitions): one clip, hypothesis 'a b c d' against
+    references 'a b c e' and 'a b': BLEU-1 = 3/4, BLEU-2 = sqrt(3/4 * 2/3), ROUGE-L from LCS 3 (P = 3/4, R = max(3/4, 2/2))."""
+    entry = _finetune_entry("run_caption_distributed_gpt3")
+    pairs = [("a b c d".split(), ["a b c e".split(), "a b".split()])]
+    b = entry.bleu_scores(pairs)
+    assert b[0] == pytest.approx(0.75, rel=1e-6) and b[1] == pytest.approx(math.sqrt(0.75 * 2 / 3), rel=1e-6)
+    assert b[2] == pytest.approx((0.75 * (2 / 3) * 0.5) ** (1 / 3), rel=1e-6)
+    p, r, beta = 0.75, 1.0, 1.2
+    assert entry.rouge_l(pairs) == pytest.approx((1 + beta ** 2) * p * r / (r + beta ** 2 * p), rel=1e-9)
+    short = [("a b".split(), ["a b c d".split()])]                      # brevity penalty exp(1 - 4/2)
+    assert entry.bleu_scores(short)[0] == pytest.approx(math.exp(-1.0), rel=1e-6)
+    assert entry.normalize("ab\u4e00, \u4e01!") == "\u4e00 \u4e01"
+
+
 def test_itm_eval_recall_metrics():
     """itm_eval (reference :296-339) against an independent count (rank of the true match = number of strictly larger scores in
     its row) on a random tie-free 40 x 40 similarity matrix with a boosted diagonal."""

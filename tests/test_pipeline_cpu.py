@@ -331,6 +331,50 @@ def test_retrieval_entrypoint_on_standins(tmp_path, monkeypatch):
         dist.destroy_process_group()
 
 
+def _finetune_entry_on_standins(tmp_path, monkeypatch, test_name, port):
+    import json
+    import test_entrypoint_gpu as t
+    from test_engine_cpu import _stub_optimizer_kernels
+    orig = t._write_configs
+
+    def write(d, update_freq=1):
+        path = orig(d, update_freq)
+        cfg = json.load(open(os.path.join(d, "txt.json")))
+        cfg.update(hidden_dropout=0.0, attention_dropout=0.0)          # the stand-ins do not model the hash dropout
+        json.dump(cfg, open(os.path.join(d, "txt.json"), "w"))
+        return path
+    monkeypatch.setattr(t, "_write_configs", write)
+    _stub_optimizer_kernels(monkeypatch)
+    monkeypatch.setenv("MASTER_PORT", str(port + os.getpid() % 2000))
+    getattr(t, test_name)(tmp_path, _on_cpu(monkeypatch))
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def test_itm_entrypoint_on_standins(tmp_path, monkeypatch):
+    """downstream/run_retrieval_distributed_gpt3_itm.py (derangement negatives, generation + matching losses, re-ranking evaluation,
+    checkpoint, --evaluate_only --resume) on CPU / gloo through the stand-ins -- the assertions of the GPU test."""
+    _finetune_entry_on_standins(tmp_path, monkeypatch, "test_itm_entrypoint_train_eval", 30000)
+
+
+def test_cls_entrypoint_on_standins(tmp_path, monkeypatch):
+    """downstream/run_cls_distributed_gpt3.py (class-name generation + cls_head losses, top-k accuracies) on the stand-ins."""
+    _finetune_entry_on_standins(tmp_path, monkeypatch, "test_cls_entrypoint_train_eval", 32000)
+
+
+def test_caption_entrypoint_on_standins(tmp_path, monkeypatch):
+    """downstream/run_caption_distributed_gpt3.py (caption loss; beam-search evaluation, result files, metric line) on the stand-ins."""
+    _finetune_entry_on_standins(tmp_path, monkeypatch, "test_caption_entrypoint_train_generate", 34000)
+
+
+def test_finetune_host_pieces_on_cpu():
+    import test_entrypoint_gpu as t
+    t.test_itm_random_derangement_and_labels()
+    t.test_synthetic_tokenizer_pair_contract()
+    t.test_caption_metrics_known_answers()
+
+
 def test_itm_eval_on_cpu():
     import test_entrypoint_gpu as t
     t.test_itm_eval_recall_metrics()
