@@ -373,7 +373,9 @@ def main():
     assert math.isfinite(final_loss), "non-finite loss in the timed region"
 
     roof = None
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:
+        # EVERY rank runs these extra steps (each holds the step's gradient all-reduces: a rank that stepped alone would leave its
+        # peers' next collective unmatched); only rank 0's launch timings go into the line
         nroof = min(args.steps, 3)
         # per-launch durations are taken with the weight-gradient lane off (vision._WgradLane: in the timed region the
         # ViT wgrad GEMMs run on a second stream and share the chip with the dgrad launches, which stretches both
@@ -386,10 +388,11 @@ def main():
             for i in range(nroof):
                 step(total + i, eager=True)
         tot = gt.summary()
-        if os.environ.get("MPV_BENCH_BY_SHAPE"):
+        if rank == 0 and os.environ.get("MPV_BENCH_BY_SHAPE"):
             gt.by_shape(os.environ["MPV_BENCH_BY_SHAPE"], nroof)
         if lane is not None:
             lane.on = lane_on
+    if rank == 0 and not args.no_roofline:
         fl = sum(v[0] for v in tot.values())
         tt = sum(v[1] for v in tot.values())
         n = sum(v[2] for v in tot.values())
