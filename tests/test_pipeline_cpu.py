@@ -375,6 +375,97 @@ def test_finetune_host_pieces_on_cpu():
     t.test_caption_metrics_known_answers()
 
 
+def _entry_world2_worker(rank, world, port, d, which, q):
+    """one rank of a two-process run of an entry point on the stand-ins (gloo); reports the final flat parameters and statistics"""
+    import json
+    import sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from test_engine_cpu import _stub_optimizer_kernels
+    import test_entrypoint_gpu as t
+    mp_ = _MP()
+    standin_ops.install(mp_)
+    _stub_optimizer_kernels(mp_)
+    sys.path.insert(0, t.ROOT)
+    sys.path.insert(0, os.path.join(t.ROOT, "downstream"))
+    from youku_mplug_amd import engine as eng
+    seen = {}
+    orig_init = eng.initialize
+
+    def spy(**kw):
+        r = orig_init(**kw)
+        seen["engine"] = r[0]
+        return r
+    eng.initialize = spy
+    out = os.path.join(d, "out")
+    if which == "pretrain":
+        import run_pretrain_distributed_gpt3 as entry
+        entry.mpv_engine.initialize = spy
+        cfg = os.path.join(d, "pretrain.yaml")
+        args, config = entry.get_args(["--config", cfg, "--output_dir", out, "--bf16", "--enable_deepspeed", "--synthetic_steps", "2", "--seed", "7"])
+    else:
+        import run_retrieval_distributed_gpt3_itm as entry
+        import finetune_common as ft
+        ft.mpv_engine.initialize = spy
+        cfg = os.path.join(d, "itm.yaml")
+        args, config = entry.get_args(["--config", cfg, "--output_dir", out, "--bf16", "--enable_deepspeed", "--synthetic_steps", "2", "--seed", "5",
+                                       "--eval_freq", "1"])
+    stats = entry.main(args, config)
+    e = seen["engine"]
+    q.put((rank, e.flat.params.clone(), e.zero_shards, {k: v for k, v in stats.items() if isinstance(v, (int, float))}))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("which", ["pretrain", "itm"])
+def test_entrypoints_world2_gloo_zero1(tmp_path, which):
+    """run_pretrain_distributed_gpt3.py and downstream/run_retrieval_distributed_gpt3_itm.py as TWO gloo ranks on the stand-ins, with
+    the command line's default `--zero_stage 1` (the reference's default launch, utils.py:528-529): both ranks finish, end with
+    identical parameters (every rank updated only its optimizer-state partition and received the rest), the checkpoint holds one
+    zero_pp_rank_<r> optimizer file per rank next to the model states, and the ITM evaluation (clips split over the ranks, score
+    matrices summed) reports the same metrics on both ranks."""
+    import json
+    import torch.multiprocessing as mp
+    import test_entrypoint_gpu as t
+    d = str(tmp_path)
+    t._write_configs(d)
+    if which == "itm":
+        t._write_finetune_config(d, "itm", "use_cls: true")
+    cfg = json.load(open(os.path.join(d, "txt.json")))
+    cfg.update(hidden_dropout=0.0, attention_dropout=0.0)              # the stand-ins do not model the hash dropout
+    json.dump(cfg, open(os.path.join(d, "txt.json"), "w"))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 36000 + os.getpid() % 3000 + (7 if which == "itm" else 0)
+    procs = [ctx.Process(target=_entry_world2_worker, args=(r, 2, port, d, which, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2 * 150):                                            # (a worker that died early must not cost the whole timeout)
+        try:
+            r = q.get(timeout=2)
+            res[r[0]] = r[1:]
+        except Exception:
+            if any(p.exitcode not in (None, 0) for p in procs):
+                break
+        if len(res) == 2:
+            break
+    for p in procs:
+        p.join(timeout=120 if len(res) == 2 else 5)
+        if p.is_alive():                                                # its peer died: it would wait in a collective for ever
+            p.kill()
+    assert [p.exitcode for p in procs] == [0, 0]
+    assert torch.equal(res[0][0], res[1][0]), "ranks must end with identical parameters"
+    shards = res[0][1]
+    assert shards is not None and len(shards) == 2 and shards[0][1] == shards[1][0] and shards[1][1] == res[0][0].numel()
+    last = "checkpoint-1" if which == "pretrain" else "checkpoint-0"
+    files = sorted(os.listdir(os.path.join(d, "out", last)))
+    assert files == ["mp_rank_00_model_states.pt", "zero_pp_rank_0_mp_rank_00_optim_states.pt", "zero_pp_rank_1_mp_rank_00_optim_states.pt"], files
+    if which == "itm":
+        for k in ("val_gen_r_mean", "val_cls_r_mean", "test_gen_r_mean"):
+            assert res[0][2][k] == res[1][2][k], k
+
+
 def test_itm_eval_on_cpu():
     import test_entrypoint_gpu as t
     t.test_itm_eval_recall_metrics()
