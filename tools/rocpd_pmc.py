@@ -1,6 +1,7 @@
 """Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate passes because
 the TCC block has 4 counter slots).  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 128-B
 requests of wide coalesced streams at 64 B -> doubled.  Usage: rocpd_pmc.py FETCH.db WRITE.db [out.md]"""
+import os
 import re
 import sqlite3
 import sys
@@ -48,8 +49,8 @@ def main():
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         from bench import gemm_source_digest
         json.dump({"hbm_mb_per_launch": round(sum(t for t, _ in gem) / nl / 1024, 1), "launches": nl, "per": "mpv_gemm_bf16 call" if len(sys.argv) > 5 and int(sys.argv[5]) > 0 else "kernel launch", "gemm_src_sha": gemm_source_digest(),
-                   "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 1 --warmup 1`, 2*FETCH+WRITE, " + sys.argv[3]},
-                  open(sys.argv[4], "w"))  # note: copy into profiles/ with a repo-relative source
+                   "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 1 --warmup 1`, 2*FETCH+WRITE, profiles/" + os.path.basename(sys.argv[3])},
+                  open(sys.argv[4], "w"))
 
 
 if __name__ == "__main__":
