@@ -69,7 +69,10 @@ def test_gemm_kernels_fit_their_occupancy(kernels):
 def test_streaming_kernels_keep_their_waves(kernels):
     ks, _ = kernels
     budget = {"14ln_fwd8_kernelILi2EE": 72, "14ln_fwd8_kernelILi4EE": 128, "14ln_bwd8_kernelILi2ELb1EE": 128,      # <2>, <4>, <2, true>
-              "20ln_bwd8_plain_kernelILi4ELb0EE": 168, "20ln_bwd8_plain_kernelILi4ELb1EE": 168, "20ln_stream_fwd_kernelILi4E": 168, "20temporal_attn_kernelILb0ELi8ELi96EE": 128, "20temporal_attn_kernelILb1ELi8ELi96EE": 128}
+              "20ln_bwd8_plain_kernelILi4ELb0EE": 168, "20ln_bwd8_plain_kernelILi4ELb1EE": 168, "20ln_stream_fwd_kernelILi4E": 168, "20temporal_attn_kernelILb0ELi8ELi96EE": 128, "20temporal_attn_kernelILb1ELi8ELi96EE": 128,
+              # 4 frames (the shipped pre-train YAML) and 16 (the retrieval recipe; LDS allows 7 / 5 waves per CU there, registers are not the limit)
+              "20temporal_attn_kernelILb0ELi4ELi96EE": 128, "20temporal_attn_kernelILb1ELi4ELi96EE": 128,
+              "20temporal_attn_kernelILb0ELi16ELi96EE": 192, "20temporal_attn_kernelILb1ELi16ELi96EE": 192}
     for prefix, lim in budget.items():
         for n, k in _sel(ks, prefix).items():
             assert k["scratch"] == 0 and k["vgpr"] <= lim, (n, k, lim)

@@ -1377,7 +1377,8 @@ struct TempArgs {
 // one wave per (sequence, head); T <= 16, hd <= 96 (multiple of 4).  Rows live in LDS as fp32 with a pitch of
 // hd+4 floats so every inner product runs on 16-byte ds_read_b128 operands (conflict-free across rows).
 // LDS floats per wave: (3|4)*T*(hd+4) + (1|2)*T*(T+1).
-// TC / HDC > 0: T and head_dim known at compile time (the ViT-B/16 instance: 8 frames, head_dim 96).  With run-time trip
+// TC / HDC > 0: T and head_dim known at compile time (the ViT-B/16 instances: 4 frames -- the shipped pre-train YAML --, 8 -- the
+// benchmark configuration -- and 16 -- the retrieval recipe --, head_dim 96).  With run-time trip
 // counts none of the inner loops unrolls, every iteration waits on its own LDS reads (~130 clocks each: measured 15k
 // clocks per problem for ~450 instructions); unrolled, the reads of 8 iterations are in flight together.
 template <bool BWD, int TC = 0, int HDC = 0>
@@ -1393,7 +1394,8 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TempArgs p) {
   float* ps = (BWD ? dos + T * ld : dos);           // [T][T+1] probabilities
   float* dss = ps + T * (T + 1);                    // BWD only: dS [T][T+1]
   const long long nprob = (long long)p.n_outer * p.n_inner * p.heads;
-  const long long pstride = (long long)gridDim.x * 4;
+  const int nwv = (int)(blockDim.x >> 6);           // waves (= problems in flight) per workgroup: 4, fewer where LDS packs better (T = 16)
+  const long long pstride = (long long)gridDim.x * nwv;
   // The operands of a wave's NEXT problem are requested (into registers) before the current one is computed: a problem is a
   // load -> LDS -> three dependent LDS phases -> store chain, and with 12-16 waves per CU the memory system saw the loads of
   // one phase at a time (4.1-4.5 TB/s); compile-time instances only (the register arrays need constant trip counts).
@@ -1422,7 +1424,7 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TempArgs p) {
       }
     }
   };
-  long long pr0 = (long long)blockIdx.x * 4 + wave;
+  long long pr0 = (long long)blockIdx.x * nwv + wave;
   if (PF && pr0 < nprob) request(pr0);
   for (long long pr = pr0; pr < nprob; pr += pstride) {
     int h;
@@ -1947,6 +1949,33 @@ static int temporal_common(TempArgs& t, int n_outer, int64_t outer_stride, int n
   return MPV_OK;
 }
 
+// Waves (one problem each) per workgroup: 4 unless fewer waves per workgroup put more waves on a CU (LDS is what limits the
+// occupancy of this kernel: 160 KiB per CU, a wave's rows are 10 KiB at 8 frames -- 4 x 4 waves either way -- but 20 / 28 KiB at
+// 16 frames, where 4-wave workgroups would leave one workgroup = 4 waves per CU and 1- / 2-wave ones fit 7 / 5).
+static int temporal_waves_per_workgroup(size_t wave_lds) {
+  const size_t cu = 160 * 1024;
+  int best = 4, best_waves = (int)(cu / (4 * wave_lds)) * 4;
+  for (int n = 3; n >= 1; --n) {
+    const int waves = (int)(cu / (n * wave_lds)) * n;
+    if (waves > best_waves) best = n, best_waves = waves;
+  }
+  return best;
+}
+static void temporal_set_attributes() {
+  static bool done = false;
+  if (done) return;
+  const int lim = 150 * 1024;
+  (void)hipFuncSetAttribute((const void*)temporal_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute((const void*)temporal_attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute((const void*)temporal_attn_kernel<false, 8, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute((const void*)temporal_attn_kernel<true, 8, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute((const void*)temporal_attn_kernel<false, 16, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute((const void*)temporal_attn_kernel<true, 16, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute((const void*)temporal_attn_kernel<false, 4, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute((const void*)temporal_attn_kernel<true, 4, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  done = true;
+}
+
 extern "C" int mpv_temporal_attn_fwd(const void* qkv, void* out, int n_outer, int64_t outer_stride, int n_inner,
                                      int64_t inner_offset, int64_t t_stride, int T, int heads, int head_dim,
                                      float scale, hipStream_t stream) {
@@ -1957,19 +1986,15 @@ extern "C" int mpv_temporal_attn_fwd(const void* qkv, void* out, int n_outer, in
   if (rc) return rc;
   t.qkv = (const bf16*)qkv;
   t.out = (bf16*)out;
-  const int nwv = 4;
-  const size_t lds = nwv * sizeof(float) * (size_t)(((3 * T * (head_dim + 4) + T * (T + 1)) + 3) & ~3);
+  const size_t wave_lds = sizeof(float) * (size_t)(((3 * T * (head_dim + 4) + T * (T + 1)) + 3) & ~3);
+  const int nwv = temporal_waves_per_workgroup(wave_lds);
+  const size_t lds = nwv * wave_lds;
   const long long nprob = (long long)n_outer * n_inner * heads;
   const int grid = (int)((nprob + nwv - 1) / nwv < 16384 ? (nprob + nwv - 1) / nwv : 16384);
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)temporal_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipFuncSetAttribute((const void*)temporal_attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipFuncSetAttribute((const void*)temporal_attn_kernel<false, 8, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipFuncSetAttribute((const void*)temporal_attn_kernel<true, 8, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    attr = true;
-  }
+  temporal_set_attributes();
   if (T == 8 && head_dim == 96) hipLaunchKernelGGL((temporal_attn_kernel<false, 8, 96>), dim3(grid), dim3(64 * nwv), lds, stream, t);
+  else if (T == 16 && head_dim == 96) hipLaunchKernelGGL((temporal_attn_kernel<false, 16, 96>), dim3(grid), dim3(64 * nwv), lds, stream, t);
+  else if (T == 4 && head_dim == 96) hipLaunchKernelGGL((temporal_attn_kernel<false, 4, 96>), dim3(grid), dim3(64 * nwv), lds, stream, t);
   else hipLaunchKernelGGL((temporal_attn_kernel<false>), dim3(grid), dim3(64 * nwv), lds, stream, t);
   return mpv_check_launch("mpv_temporal_attn_fwd");
 }
@@ -1985,19 +2010,15 @@ extern "C" int mpv_temporal_attn_bwd(const void* qkv, const void* dout, void* dq
   t.qkv = (const bf16*)qkv;
   t.dout = (const bf16*)dout;
   t.dqkv = (bf16*)dqkv;
-  const int nwv = 4;
-  const size_t lds = nwv * sizeof(float) * (size_t)(((4 * T * (head_dim + 4) + 2 * T * (T + 1)) + 3) & ~3);
+  const size_t wave_lds = sizeof(float) * (size_t)(((4 * T * (head_dim + 4) + 2 * T * (T + 1)) + 3) & ~3);
+  const int nwv = temporal_waves_per_workgroup(wave_lds);
+  const size_t lds = nwv * wave_lds;
   const long long nprob = (long long)n_outer * n_inner * heads;
   const int grid = (int)((nprob + nwv - 1) / nwv < 16384 ? (nprob + nwv - 1) / nwv : 16384);
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)temporal_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipFuncSetAttribute((const void*)temporal_attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipFuncSetAttribute((const void*)temporal_attn_kernel<false, 8, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipFuncSetAttribute((const void*)temporal_attn_kernel<true, 8, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    attr = true;
-  }
+  temporal_set_attributes();
   if (T == 8 && head_dim == 96) hipLaunchKernelGGL((temporal_attn_kernel<true, 8, 96>), dim3(grid), dim3(64 * nwv), lds, stream, t);
+  else if (T == 16 && head_dim == 96) hipLaunchKernelGGL((temporal_attn_kernel<true, 16, 96>), dim3(grid), dim3(64 * nwv), lds, stream, t);
+  else if (T == 4 && head_dim == 96) hipLaunchKernelGGL((temporal_attn_kernel<true, 4, 96>), dim3(grid), dim3(64 * nwv), lds, stream, t);
   else hipLaunchKernelGGL((temporal_attn_kernel<true>), dim3(grid), dim3(64 * nwv), lds, stream, t);
   return mpv_check_launch("mpv_temporal_attn_bwd");
 }
