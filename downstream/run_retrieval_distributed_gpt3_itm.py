@@ -105,7 +105,6 @@ def synthetic_loaders(args, config, seed):
         titles = ft.synthetic_titles(n, max(4, config["max_length"] // 4), torch.Generator().manual_seed(s))
         if train:
             sp = ft.SyntheticSplit(n, bs, frames, res, s, lambda i: (titles[i], i), drop_last=True)
-            sp.collate = None
         else:
             sp = ft.SyntheticSplit(n, bs, frames, res, s, lambda i: (i,))
         sp.text, sp.video = titles, list(range(n))

@@ -146,6 +146,13 @@ def _engine_worker(rank, world, port, q, zero=0, ckpt_dir=None):
     cfg = dict(lr=1e-2, clip_grad=0.5, opt_eps=1e-6)
     if zero:
         cfg["zero_optimization"] = {"stage": zero}        # as utils.py:528-529 writes it into the DeepSpeed config
+    gathers = [0]
+    orig_gather = dist.all_gather_into_tensor
+
+    def counted_gather(*a, **k):
+        gathers[0] += 1
+        return orig_gather(*a, **k)
+    dist.all_gather_into_tensor = counted_gather
     engine, opt, _, _ = eng.initialize(model=model, model_parameters=groups, config=cfg)
     orig = engine.reducer.stage_ready
     engine.reducer.stage_ready = lambda name: (launched.append(name), orig(name))[1]
@@ -168,7 +175,7 @@ def _engine_worker(rank, world, port, q, zero=0, ckpt_dir=None):
         opt.exp_avg.zero_()
         engine.load_checkpoint(ckpt_dir, tag="z")
         extra = (files, torch.equal(before[0], engine.flat.params) and torch.equal(before[1], opt.exp_avg) and opt.step_count == before[2],
-                 (opt.lo, opt.hi))
+                 (opt.lo, opt.hi), gathers[0], engine.flat.numel)
     q.put((rank, p0, engine.flat.params.clone(), list(engine.flat.stage_slices.items()), launched[:6], opt._global_grad_norm, extra))
     dist.barrier()
     dist.destroy_process_group()
@@ -235,12 +242,29 @@ def test_zero_stage1_world2_gloo_matches_replicated_optimizer(tmp_path):
     for r in range(2):
         assert torch.equal(results[0][r][1], results[1][r][1]), f"rank {r}: ZeRO-1 parameters differ from the replicated optimizer's"
     assert torch.equal(results[1][0][1], results[1][1][1])
-    files, reloaded, shard0 = results[1][0][5]
-    _, _, shard1 = results[1][1][5]
+    files, reloaded, shard0, gathers, numel = results[1][0][5]
+    _, _, shard1, _, _ = results[1][1][5]
     assert reloaded and results[1][1][5][1]
+    # equal runs of whole tiles over the (padded) flat buffer, shared by ONE all-gather per optimizer step
+    assert gathers == 2 and shard1[1] == numel and shard0[1] - shard0[0] == shard1[1] - shard1[0] and numel % 512 == 0
     assert "mp_rank_00_model_states.pt" in files and "zero_pp_rank_0_mp_rank_00_optim_states.pt" in files and \
         "zero_pp_rank_1_mp_rank_00_optim_states.pt" in files and "mp_rank_00_optim_states.pt" not in files
     assert shard0[0] == 0 and shard0[1] == shard1[0] and shard1[1] >= shard1[0]
+
+
+def test_flat_params_padding_for_equal_zero_runs():
+    """FlatParams(pad_tiles_to=w): the tile count becomes a multiple of w; the padding tiles carry group 255 (the optimizer kernel
+    skips groups >= 8) and no parameter lives in them."""
+    from youku_mplug_amd.engine import TILE, FlatParams
+    ps = [nn.Parameter(torch.randn(300).to(torch.bfloat16)), nn.Parameter(torch.randn(5, 7).to(torch.bfloat16)), nn.Parameter(torch.randn(700).to(torch.bfloat16))]
+    group_of = {id(p): i % 2 for i, p in enumerate(ps)}
+    plain = FlatParams([("head", ps[:2]), ("stem", ps[2:])], group_of)
+    assert plain.numel == (2 + 1 + 3) * TILE
+    ps2 = [nn.Parameter(p.detach().clone()) for p in ps]
+    padded = FlatParams([("head", ps2[:2]), ("stem", ps2[2:])], {id(p): i % 2 for i, p in enumerate(ps2)}, pad_tiles_to=4)
+    assert padded.numel == 8 * TILE and padded.stage_slices == plain.stage_slices
+    assert padded.tile_group.tolist() == plain.tile_group.tolist() + [255, 255]
+    assert torch.equal(padded.params[:plain.numel], plain.params) and padded.params[plain.numel:].abs().sum().item() == 0
 
 
 def test_gradient_accumulation_matches_big_batch(monkeypatch):

@@ -77,7 +77,9 @@ class FlatParams:
     """Flat bf16 parameter/gradient buffers (+ stage slices) with the parameters re-pointed at views."""
 
     def __init__(self, stages: Sequence[Tuple[str, Sequence[nn.Parameter]]], group_of: Optional[Dict[int, int]] = None,
-                 dtype=None):
+                 dtype=None, pad_tiles_to: int = 1):
+        """pad_tiles_to: the buffers end with as many padding tiles (group 255: skipped by the optimizer, gradients stay zero) as it
+        takes to make the tile count a multiple of it -- ZeRO-1 cuts the buffer into `world` EQUAL runs, one all-gather shares them."""
         params = [p for _, ps in stages for p in ps]
         assert params, "no trainable parameters"
         self.device = params[0].device
@@ -92,6 +94,8 @@ class FlatParams:
                 self.slots.append((p, off, n))
                 off += (n + TILE - 1) // TILE * TILE
             self.stage_slices[name] = (start, off)
+        quantum = TILE * max(1, int(pad_tiles_to))
+        off = (off + quantum - 1) // quantum * quantum
         self.numel = off
         self.params = torch.zeros(off, dtype=self.dtype, device=self.device)
         self.grads = torch.zeros(off, dtype=self.dtype, device=self.device)
@@ -280,16 +284,18 @@ class MplugEngine(nn.Module):
         stages = default_stages(model)
         stages = [(n, [p for p in ps if id(p) in group_of]) for n, ps in stages]
         stages = [s for s in stages if s[1]]
-        self.flat = FlatParams(stages, group_of)
+        world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.flat = FlatParams(stages, group_of, pad_tiles_to=world if zero_stage == 1 else 1)
         broadcast_module_state(model, self.flat, process_group)     # replicas start identical (before the fp32 master copy)
         self.reducer = DPReducer(self.flat, process_group)
         # the window sum of micro-batch gradients is kept in fp32 (DeepSpeed's bf16 optimizer does the same): in bf16 every add
         # rounds to 8 mantissa bits and small contributions vanish against a large running sum
         self.grad_acc = torch.zeros(self.flat.numel, dtype=torch.float32, device=self.flat.device) if self.gas > 1 else None
         # ZeRO stage 1 (utils.py:528-529, `--zero_stage 1`): optimizer states partitioned over the data-parallel ranks.  The flat
-        # buffer is cut into `world` runs of whole 256-element tiles; every rank still receives the whole reduced gradient (the
-        # bucketed all-reduce is unchanged: the clip needs its global norm), updates its own run, and the updated bf16 runs are
-        # broadcast from their owners.  (Stages 2 / 3 -- gradient / parameter partitioning -- are not built.)
+        # buffer (padded to a multiple of `world` tiles) is cut into `world` equal runs of whole 256-element tiles; every rank still
+        # receives the whole reduced gradient (the bucketed all-reduce is unchanged: the clip needs its global norm), updates its own
+        # run, and ONE in-place all-gather hands the updated bf16 runs round.  (Stages 2 / 3 -- gradient / parameter partitioning --
+        # are not built.)
         assert zero_stage in (0, 1), "ZeRO stages 2 and 3 are not built"
         self.zero_shards = None
         shard = None
@@ -372,10 +378,15 @@ class MplugEngine(nn.Module):
         """ZeRO-1: every rank has updated its own run of the flat bf16 parameters; hand the runs round"""
         if self.zero_shards is None:
             return
-        for r, (lo, hi) in enumerate(self.zero_shards):
-            if hi > lo:
+        lo, hi = self.zero_shards[dist.get_rank(self.process_group)]
+        if all(b - a == hi - lo for a, b in self.zero_shards) and self.zero_shards[-1][1] == self.flat.numel:
+            # equal runs (FlatParams(pad_tiles_to=world)): in place, rank r's input IS slice r of the output
+            dist.all_gather_into_tensor(self.flat.params, self.flat.params[lo:hi], group=self.process_group)
+            return
+        for r, (a, b) in enumerate(self.zero_shards):       # (a flat buffer built without the padding)
+            if b > a:
                 src = dist.get_global_rank(self.process_group, r) if self.process_group is not None else r
-                dist.broadcast(self.flat.params[lo:hi], src=src, group=self.process_group)
+                dist.broadcast(self.flat.params[a:b], src=src, group=self.process_group)
 
     def zero_grad(self):
         pass      # every gradient is overwritten (never accumulated) by the next backward
