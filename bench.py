@@ -170,6 +170,11 @@ class _StdoutToStderr:
 
     def __exit__(self, *exc):
         sys.stdout.flush()
+        try:        # the banner sits in the C library's stdout buffer (fully buffered on a pipe): without this it would surface at
+            import ctypes      # process exit, on the restored fd 1, AFTER the JSON line
+            ctypes.CDLL(None).fflush(None)
+        except (OSError, AttributeError):
+            pass
         os.dup2(self.saved, 1)
         os.close(self.saved)
 

@@ -426,3 +426,31 @@ def test_itm_eval_recall_metrics():
     t, v = recalls(s), recalls(s.T)
     assert [r["txt_r1"], r["txt_r5"], r["txt_r10"]] == pytest.approx(t) and [r["vid_r1"], r["vid_r5"], r["vid_r10"]] == pytest.approx(v)
     assert r["r_mean"] == pytest.approx((sum(t) / 3 + sum(v) / 3) / 2) and 0 < r["txt_r1"] < 100
+
+
+def test_bench_contract_line_forced_distributed_path():
+    """bench.py as the driver runs it (a subprocess, one JSON line on stdout), with MPV_BENCH_FORCE_DIST=1 so that the N > 1 code path
+    -- RCCL communicator on the high-priority stream, parameter broadcast, bucketed all-reduce in the backward, fences with barriers,
+    max-over-ranks timing, the post-run roofline steps on every rank -- executes on this one GPU: exactly one line, the contract's keys,
+    value = global batch x steps / time, roofline with a live HIP-event measurement."""
+    import subprocess
+    env = dict(os.environ, MPV_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(25000 + os.getpid() % 2000))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env, stdin=subprocess.DEVNULL)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in rec, k
+    assert rec["n_gpus"] == 1 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["unit"] == "samples/s" and rec["higher_is_better"] is True
+    assert rec["scaling"] == "weak" and rec["vs_baseline"] is None and rec["dtype"] == "bf16" and rec["data"] == "synthetic" and rec["cpu_baseline"] is None
+    assert "workload" in rec["config"] and rec["config"]["global_batch"] == 32 and rec["config"]["parallelism"] == "dp1"
+    assert rec["value"] == pytest.approx(32 * 3 / (rec["ms_per_step"] * 3e-3), rel=1e-3)
+    roof = rec["roofline"]
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 2500.0
+    assert 0.2 < roof["frac"] < 1.0 and roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], abs=1e-3)
+    assert 30.0 < rec["ms_per_step"] < 400.0
