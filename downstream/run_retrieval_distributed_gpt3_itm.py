@@ -12,8 +12,9 @@ What this entry point adds to downstream/finetune_common.py:
     matrices, each ranked both ways by itm_eval (recall@1/5/10).
 Two deliberate differences, both only visible where the reference misbehaves: the evaluation statistics of the classification
 scores are logged under `cls_*` (the reference overwrites the `gen_*` entries with them, :459-462), and with more than one rank
-the videos are split over the ranks batch by batch and summed (the reference offsets rows by rank although its evaluation
-loaders are not sharded, :246-250)."""
+the evaluation loaders are left unsharded and their batches are split over the ranks and summed (the reference places a rank's
+rows at rank * (videos // world + 1) although its DistributedSampler hands every rank a STRIDED shard, :246-250, :372; its own
+launch script says to evaluate on one process)."""
 import os
 import random
 import sys
@@ -117,7 +118,8 @@ def real_loaders(args, config):
     from dataset import create_dataset, create_loader, create_sampler
     from models.modeling_distributed_gpt3 import DistributedGPT3Tokenizer
     datasets = create_dataset("video_retrieval", config)
-    samplers = create_sampler(datasets, [True, False, False], dist.get_world_size(), dist.get_rank())
+    # evaluation loaders stay unsharded (every rank walks the whole split; `evaluation` scores the batches b % world == rank)
+    samplers = create_sampler(datasets[:1], [True], dist.get_world_size(), dist.get_rank()) + [None, None]
     loaders = create_loader(datasets, samplers, batch_size=[args.batch_size] * 3, num_workers=[args.num_workers] * 3,
                             is_trains=[True, False, False], collate_fns=[None, None, None])
     return loaders, DistributedGPT3Tokenizer(config["text_decoder"])
