@@ -292,6 +292,33 @@ def test_gradient_accumulation_matches_big_batch(monkeypatch):
     assert torch.allclose(ea.flat.params, eb.flat.params, atol=2e-6)
 
 
+def test_epoch_reset_of_micro_steps_drops_a_partial_accumulation_window(monkeypatch):
+    """the training loops write `model.micro_steps = 0` at every epoch start (run_pretrain_distributed_gpt3.py:72-73).
+    With len(loader) % update_freq != 0 the last window of an epoch is partial; DeepSpeed's boundary is micro_steps % gas, so
+    the reset realigns it and the partial sum is discarded.  Here: one stray micro-batch, epoch reset, then a full window must
+    equal the same full window on a fresh engine."""
+    _stub_optimizer_kernels(monkeypatch)
+    from youku_mplug_amd import engine as eng
+    x, y = _data()
+    ma, mb = _StubModel(seed=5), _StubModel(seed=5)
+    ea, _, _, _ = eng.initialize(model=ma, model_parameters=eng.get_parameter_groups(ma, 0.05), config=dict(lr=1e-2, update_freq=2))
+    eb, _, _, _ = eng.initialize(model=mb, model_parameters=eng.get_parameter_groups(mb, 0.05), config=dict(lr=1e-2, update_freq=2))
+    loss, _ = ea(3.0 * x[:4], y[:4])          # the ragged tail of "epoch 0": half a window
+    ea.backward(loss)
+    ea.step()
+    assert not ea.is_gradient_accumulation_boundary() and ea.global_steps == 0
+    ea.micro_steps = 0                         # epoch 1 starts
+    ea.zero_grad()
+    assert ea.is_gradient_accumulation_boundary() and ea.micro_steps == 0
+    for e in (ea, eb):
+        for sl in (slice(0, 4), slice(4, 8)):
+            loss, _ = e(x[sl], y[sl])
+            e.backward(loss)
+            e.step()
+    assert ea.global_steps == 1 and eb.global_steps == 1
+    assert torch.equal(ea.flat.params, eb.flat.params)
+
+
 def test_checkpoint_round_trip_deepspeed_layout(monkeypatch):
     """save_checkpoint -> load_checkpoint into a fresh engine: module weights, fp32 master / moments and the step counter
     survive; files follow utils.py:440-480 (<dir>/<tag>/mp_rank_00_model_states.pt with key 'module', <dir>/latest)."""

@@ -490,3 +490,25 @@ def test_caption_generate_on_standins(monkeypatch):
         return m
     monkeypatch.setattr(downstream, "synthetic_gencls_model", build)
     t.test_caption_generate_vs_reference_golden(_on_cpu(monkeypatch))
+
+
+@pytest.mark.parametrize("kind", ["itm", "cls", "caption"])
+def test_gencls_models_refuse_options_only_the_pretrain_class_implements(monkeypatch, kind):
+    """`connect_ln` and `freeze_text_decoder: false` are implemented in DistributedGPT3_Pretrain; the
+    generation / classification pipelines of downstream.py inherit its constructor but apply neither (no visual_norm stage in
+    _query_features, no decoder weight-gradient inputs in the hidden-only prompt pass): they must refuse, not train silently wrong."""
+    from oracle.weights import CONFIG_TINY as c
+    from youku_mplug_amd.downstream import DistributedGPT3_Caption, DistributedGPT3_Cls, DistributedGPT3_Retrieval_Cls
+    from youku_mplug_amd.gpt3 import GPT3Config
+    standin_ops.install(monkeypatch)
+    klass = {"itm": DistributedGPT3_Retrieval_Cls, "cls": DistributedGPT3_Cls, "caption": DistributedGPT3_Caption}[kind]
+    vis = dict(img_size=c.img_size, patch_size=c.patch_size, depth=c.vit_depth, num_frames=c.num_frames, embed_dim=c.vit_dim,
+               num_heads=c.vit_heads, mlp_ratio=c.vit_mlp_ratio, clip_model=True)
+    txt = GPT3Config(vocab_size=c.vocab, hidden_size=c.hidden, ffn_hidden_size=c.ffn, num_hidden_layers=c.layers,
+                     num_attention_heads=c.heads, max_position_embeddings=c.max_pos, layernorm_epsilon=c.gpt_ln_eps)
+    base = {"num_learnable_token": c.num_queries, "_synthetic": True, "use_cls": kind != "caption", "num_classes": 2}
+    klass(base, visual_cfg=vis, text_cfg=txt, device="cpu")                                   # the shipped form builds
+    with pytest.raises(NotImplementedError, match="connect_ln"):
+        klass(base, visual_cfg=dict(vis, connect_ln=True), text_cfg=txt, device="cpu")
+    with pytest.raises(NotImplementedError, match="freeze_text_decoder"):
+        klass(dict(base, freeze_text_decoder=False), visual_cfg=vis, text_cfg=txt, device="cpu")

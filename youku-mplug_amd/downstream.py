@@ -49,8 +49,17 @@ class _GenCls(DistributedGPT3_Pretrain):
         config = dict(config or {})
         if visual_cfg is not None and "num_frames" in config:          # TimeSformer(num_frames=config['num_frames']) (:441, :998)
             visual_cfg = dict(visual_cfg, num_frames=config["num_frames"])
+        # The pre-train class implements both options below; the generation / classification pipelines of this file do not
+        # (their hidden-only prompt pass records no decoder weight-gradient inputs, and _query_features has no visual_norm
+        # stage), and no shipped recipe sets either: refuse loudly instead of training silently wrong.
+        if not config.get("freeze_text_decoder", True):
+            raise NotImplementedError("freeze_text_decoder: false (models/distributed_gpt3.py:492, 722, 1049) is implemented for "
+                                      "DistributedGPT3_Pretrain only; the ITM / classification / caption models refuse it")
         super().__init__(config, tokenizer, visual_cfg=visual_cfg, text_cfg=text_cfg, device=device)
-        self.use_cls = config.get("use_cls", False)                                           # :523 / :1079
+        if not isinstance(self.visual_norm, nn.Identity):
+            raise NotImplementedError("connect_ln (models/distributed_gpt3.py:513-516, 1070-1073) is implemented for "
+                                      "DistributedGPT3_Pretrain only; the ITM / classification / caption models refuse it")
+        self.use_cls = config.get("use_cls", False)                                         # :523 / :1079
         if self.use_cls:
             H = self.text_width
             self.num_classes = config["num_classes"]

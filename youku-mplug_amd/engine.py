@@ -250,7 +250,10 @@ def init_process_group_for_dp(backend: Optional[str] = None, **kw):
         try:
             opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
             return dist.init_process_group(backend, pg_options=opts, **kw)
-        except (AttributeError, TypeError, RuntimeError):
+        except (AttributeError, TypeError):
+            # this torch build has no such option / keyword: nothing has been initialised yet, fall through.  A RuntimeError
+            # (store, rendezvous, communicator) is a real failure of the first attempt and must surface as itself, not as the
+            # "initialised twice" / "address in use" a blind retry would raise on top of it.
             pass
     return dist.init_process_group(backend, **kw)
 
@@ -306,7 +309,7 @@ class MplugEngine(nn.Module):
             shard = self.zero_shards[dist.get_rank(process_group)]
         self.process_group = process_group
         self.optimizer = FlatAdamW(self.flat, param_groups, lr=lr, betas=betas, eps=eps, clip_grad=clip_grad, shard=shard)
-        self.micro_steps = 0                  # the training loop resets this every epoch (run_pretrain_distributed_gpt3.py:72-73)
+        self._micro_steps = 0                 # `micro_steps`: the training loop resets it every epoch (run_pretrain_distributed_gpt3.py:72-73)
         self._window_fill = 0                 # micro-batches summed into the current accumulation window
         self.micro_batches_seen = 0           # never reset, saved with the optimizer state: drives the dropout seed
         self.global_steps = 0
@@ -325,6 +328,20 @@ class MplugEngine(nn.Module):
     def forward(self, *a, **k):
         return self.module(*a, **k)
 
+    @property
+    def micro_steps(self) -> int:
+        return self._micro_steps
+
+    @micro_steps.setter
+    def micro_steps(self, value: int):
+        """The reference's loops write `model.micro_steps = 0` at the top of every epoch (run_pretrain_distributed_gpt3.py:72-73):
+        DeepSpeed's accumulation boundary is `micro_steps % gas`, so that write realigns the window and the partial window a
+        ragged epoch left behind (len(loader) % update_freq != 0) is discarded with the following zero_grad().  Same here: a
+        write that lands on a window boundary drops the partial fp32 sum (the next accumulate starts with first=True)."""
+        self._micro_steps = int(value)
+        if self._micro_steps % max(1, self.gas) == 0:
+            self._window_fill = 0
+
     def is_gradient_accumulation_boundary(self) -> bool:
         return self._window_fill == 0
 
@@ -335,7 +352,7 @@ class MplugEngine(nn.Module):
         overlapped bucket all-reduce only exists without accumulation (with it, the window's sum is reduced in step())."""
         self.reducer.hold = self.gas > 1
         loss.backward()
-        self.micro_steps += 1
+        self._micro_steps += 1
         self.micro_batches_seen += 1
         if self.gas > 1:
             from . import ops
@@ -428,7 +445,7 @@ class MplugEngine(nn.Module):
             return loss
 
         def after():
-            self.micro_steps += 1
+            self._micro_steps += 1
             self.micro_batches_seen += 1
             self.global_steps += 1
             self._set_dropout_seed()           # next step's seeds -> device (stream-ordered behind this step)
@@ -465,7 +482,8 @@ class MplugEngine(nn.Module):
             g = torch.cuda.CUDAGraph()
             self._upload_seeds = False
             try:
-                with torch.cuda.graph(g):
+                # thread_local: a DataLoader's pin-memory thread (hipHostMalloc / event calls) must not invalidate the capture
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     static_loss = run(static_in)
             finally:
                 self._upload_seeds = True
@@ -484,7 +502,8 @@ class MplugEngine(nn.Module):
     def save_checkpoint(self, save_dir, tag=None, client_state=None):
         tag = tag or f"global_step{self.global_steps}"
         d = os.path.join(save_dir, str(tag))
-        if not dist.is_initialized() or dist.get_rank() == 0:
+        rank0 = not dist.is_initialized() or dist.get_rank() == 0
+        if rank0:
             os.makedirs(d, exist_ok=True)
             state = {"module": {k: v.detach().cpu() for k, v in self.module.state_dict().items()}}
             state.update(client_state or {})
@@ -492,13 +511,16 @@ class MplugEngine(nn.Module):
             if self.zero_shards is None:
                 osd = dict(self.optimizer.state_dict(), micro_batches_seen=self.micro_batches_seen)
                 torch.save({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in osd.items()}, os.path.join(d, "mp_rank_00_optim_states.pt"))
-            with open(os.path.join(save_dir, "latest"), "w") as f:
-                f.write(str(tag))
         if dist.is_initialized():
-            dist.barrier()
+            dist.barrier()                     # the directory exists for every rank
         if self.zero_shards is not None:       # DeepSpeed's ZeRO layout: one optimizer-state file per data-parallel rank
             osd = dict(self.optimizer.state_dict(), micro_batches_seen=self.micro_batches_seen)
             torch.save({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in osd.items()}, os.path.join(d, self._zero_file()))
+            dist.barrier()                     # every rank's shard is on disk ...
+        if rank0:                              # ... before `latest` names the checkpoint: a crash in between leaves the previous one current
+            with open(os.path.join(save_dir, "latest"), "w") as f:
+                f.write(str(tag))
+        if dist.is_initialized():
             dist.barrier()
         return True
 
@@ -519,14 +541,27 @@ class MplugEngine(nn.Module):
         self.last_load_missing_keys = list(missing)
         op = os.path.join(d, self._zero_file() if self.zero_shards is not None else "mp_rank_00_optim_states.pt")
         osd = torch.load(op, map_location=self.flat.device) if os.path.isfile(op) else None
-        if osd is not None and osd["master"].numel() == self.optimizer.master.numel() and \
-                tuple(osd.get("shard", (0, self.flat.numel))) == (self.optimizer.lo, self.optimizer.hi):
+        usable = osd is not None and osd["master"].numel() == self.optimizer.master.numel() and \
+            tuple(osd.get("shard", (0, self.flat.numel))) == (self.optimizer.lo, self.optimizer.hi)
+        if self.zero_shards is not None:
+            # every rank must take the SAME branch (one rank resuming its Adam moments while another restarts from zero would run
+            # different bias corrections on shards of one model): the decision is the AND over ranks, and it is said out loud
+            flags = [None] * dist.get_world_size(self.process_group)
+            dist.all_gather_object(flags, bool(usable), group=self.process_group)
+            if not all(flags) and any(flags) and dist.get_rank(self.process_group) == 0:
+                print(f"load_checkpoint: optimizer shards of {d} are missing or of another partition on ranks "
+                      f"{[r for r, f in enumerate(flags) if not f]} (saved at another world size?): ALL ranks restart the optimizer state")
+            usable = all(flags)
+        elif osd is not None and not usable:
+            print(f"load_checkpoint: optimizer state of {d} does not fit this model's flat buffer (resized embeddings?): fresh optimizer state")
+        if usable:
             self.optimizer.load_state_dict(osd)
         else:       # weights only, or a checkpoint of another shape (resized embeddings): fresh optimizer state, as the
             self.optimizer.master.copy_(self.flat.params[self.optimizer.lo:self.optimizer.hi].float())     # downstream scripts build a new optimizer after --resume
             self.optimizer.exp_avg.zero_()
             self.optimizer.exp_avg_sq.zero_()
             self.optimizer.step_count = 0
+            osd = None if self.zero_shards is not None else osd
         # a resume starts a fresh accumulation window (a NaN auto-resume may arrive mid-window with a stale partial sum) and
         # continues the dropout stream where the checkpoint left it
         self._window_fill = 0
