@@ -87,6 +87,32 @@ def algorithmic_train_flops_E(B, T, L, s=Shapes, E=256):
     return 3.0 * vit + gpt + heads
 
 
+# MPV_BENCH_DEVICE=cpu is a TEST HOOK for the N > 1 control flow (tests/test_pipeline_cpu.py::test_bench_control_flow_world8_gloo):
+# eight gloo ranks run this file's barriers / MAX-reduce / rank-0-only JSON line on the torch stand-ins of tests/standin_ops.py.
+# The product has no CPU path: without the stand-ins installed every op raises on a CPU tensor.  Events / sync shims for that mode:
+_ON_CPU = os.environ.get("MPV_BENCH_DEVICE", "cuda") == "cpu"
+
+
+class _HostEvent:
+    def __init__(self, enable_timing=True):
+        self.t = None
+
+    def record(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
+def _event():
+    return _HostEvent() if _ON_CPU else torch.cuda.Event(enable_timing=True)
+
+
+def _sync():
+    if not _ON_CPU:
+        torch.cuda.synchronize()
+
+
 class GemmTimer:
     """Times every mpv_gemm_bf16 launch with HIP events on the launch stream (torch's current stream)."""
 
@@ -100,14 +126,18 @@ class GemmTimer:
         self.ops, self.orig = ops, ops.gemm
 
         def timed(a, b, M, N, K, **kw):
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s, e = _event(), _event()
             s.record()
             r = self.orig(a, b, M, N, K, **kw)
             e.record()
             # kernel variant: <0,0> k-contiguous operands (forward, and dgrad against the frozen decoder's transposed weight
             # copies), <0,1> dgrad against trainable weights, <1,1> wgrad
             kind = "gemm<1,1> wgrad" if kw.get("trans_a") else ("gemm<0,1> dgrad" if kw.get("trans_b") else "gemm<0,0> fwd + frozen-weight dgrad")
-            self.records.append((kind, 2.0 * M * N * K, s, e, 2.0 * (M * K + N * K + M * N)))
+            # algorithmic bytes of the launch: both operands + the output, plus every [M, N] tensor its epilogue reads or writes besides
+            # C (the pre-activation copy of fc1, the residual, the GELU' pre-activation of a dgrad) -- all bf16.  Split-K partials
+            # of the wgrad form are NOT algorithmic (they are the implementation's own traffic and show up in `traffic` only).
+            extra = sum(1 for k in ("preact_out", "residual", "act_bwd_z") if torch.is_tensor(kw.get(k)))
+            self.records.append((kind, 2.0 * M * N * K, s, e, 2.0 * (M * K + N * K + (1 + extra) * M * N)))
             epi = "+".join(k for k in ("bias", "act", "preact_out", "residual", "act_bwd_z", "dropout_p", "colsum_out", "row_tap_out", "kmap", "amap")
                            if (torch.is_tensor(kw.get(k)) or kw.get(k) not in (None, 0, 0.0, False, (0, 0, 0))))
             self.shapes.append((kind.split()[0], M, N, K, epi))
@@ -121,7 +151,7 @@ class GemmTimer:
 
     def by_shape(self, path, steps):
         """MPV_BENCH_BY_SHAPE=<file>: per (form, M, N, K, epilogue) launches per step, mean us and TFLOP/s inside the step."""
-        torch.cuda.synchronize()
+        _sync()
         agg = {}
         for (kind, fl, s, e, _), key in zip(self.records, self.shapes):
             a = agg.setdefault(key, [0, 0.0, fl])
@@ -133,7 +163,7 @@ class GemmTimer:
                 f.write(f"| {key[0]} | {key[1]} | {key[2]} | {key[3]} | {key[4] or 'plain'} | {n / steps:g} | {us / n:.1f} | {fl / (us / n) / 1e6:.0f} | {us / steps / 1e3:.2f} |\n")
 
     def summary(self):
-        torch.cuda.synchronize()
+        _sync()
         tot = {}
         for kind, fl, s, e, by in self.records:
             t = tot.setdefault(kind, [0.0, 0.0, 0, 0.0])
@@ -261,8 +291,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if _ON_CPU:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     # MPV_BENCH_FORCE_DIST=1 runs the distributed code path (RCCL init, broadcast, barriers, bucketed all-reduce, max-over-ranks
     # timing) even at world size 1 -- the only way to exercise it on a 1-GPU box
     dist_on = world > 1 or os.environ.get("MPV_BENCH_FORCE_DIST", "0") == "1"
@@ -271,14 +304,18 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29577")
         with _StdoutToStderr():
             from youku_mplug_amd.engine import init_process_group_for_dp      # RCCL on a high-priority stream (engine.py)
-            init_process_group_for_dp("nccl", rank=rank, world_size=world, device_id=dev)
+            if _ON_CPU:
+                init_process_group_for_dp("gloo", rank=rank, world_size=world)
+            else:
+                init_process_group_for_dp("nccl", rank=rank, world_size=world, device_id=dev)
             dist.barrier()                                               # brings the communicator (and its banner) up now
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
 
     import youku_mplug_amd  # noqa: F401  raises if libmpv_hip.so is missing
     from youku_mplug_amd import _lib, engine as eng
     from youku_mplug_amd.pretrain import synthetic_model
-    _lib.check(_lib.lib().mpv_check_device(), "mpv_check_device")
+    if not _ON_CPU:
+        _lib.check(_lib.lib().mpv_check_device(), "mpv_check_device")
 
     global Shapes
     if args.config == "D":
@@ -305,7 +342,7 @@ def main():
     if dist_on and world == 1:
         engine.reducer.always = True
     B, T, L = args.batch, args.frames, args.text_len
-    video = torch.randn(B, 3, T, 224, 224, device=dev).to(torch.bfloat16)
+    video = torch.randn(B, 3, T, Shapes.img_size, Shapes.img_size, device=dev).to(torch.bfloat16)
     ids = torch.randint(0, Shapes.vocab, (B, L), device=dev)
     text = types.SimpleNamespace(input_ids=ids, attention_mask=torch.ones(B, L, dtype=torch.long, device=dev))
     total = args.warmup + args.steps
@@ -335,15 +372,15 @@ def main():
     log("model + engine built")
     for i in range(args.warmup):
         loss = step(i)
-    torch.cuda.synchronize()
+    _sync()
     log("warmup done")
     def fence():
         if dist_on:
             dist.barrier()
-        torch.cuda.synchronize()
+        _sync()
     # per-step HIP events on the launch stream (torch's current stream is the stream every kernel of the step is launched
     # on) give the distribution; the reported value is the whole timed region between two fences (the contract)
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    marks = [_event() for _ in range(args.steps + 1)]
     fence()
     t0 = time.perf_counter()
     c0 = time.thread_time()
@@ -360,11 +397,11 @@ def main():
     # the same on an IDLE queue (nothing to wait for): what the host really spends to launch one step
     t_idle = []
     for i in range(3):
-        torch.cuda.synchronize()
+        _sync()
         t1, c1 = time.perf_counter(), time.thread_time()
         step(total - 1)
         t_idle.append((time.perf_counter() - t1, time.thread_time() - c1))
-    torch.cuda.synchronize()
+    _sync()
     log(f"host time to launch one step on an idle queue: {min(t[0] for t in t_idle) * 1e3:.1f} ms wall, {min(t[1] for t in t_idle) * 1e3:.1f} ms CPU")
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     if dist_on:
@@ -372,7 +409,7 @@ def main():
     dt = dt.item()
     final_loss = loss.item()
     log(f"timed region done: {dt / args.steps * 1e3:.1f} ms/step")
-    ms_ = torch.cuda.memory_stats(dev)
+    ms_ = {} if _ON_CPU else torch.cuda.memory_stats(dev)
     log(f"device memory: peak allocated {ms_.get('allocated_bytes.all.peak', 0) / 2**30:.1f} GiB, peak reserved {ms_.get('reserved_bytes.all.peak', 0) / 2**30:.1f} GiB, "
         f"allocator retries {ms_.get('num_alloc_retries', 0)}, device mallocs {ms_.get('num_device_alloc', 0)} / frees {ms_.get('num_device_free', 0)}")
     assert math.isfinite(final_loss), "non-finite loss in the timed region"

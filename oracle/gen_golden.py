@@ -97,12 +97,13 @@ def run_retrieval(name: str = "retrieval_tiny"):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
-def gencls_inputs(cfg, kind: str):
-    """Seeded inputs shared by the golden generator and the tests (tiny shapes)."""
+def gencls_inputs(cfg, kind: str, Bv: int = 3, L: int = 10, Lp: int = 8):
+    """Seeded inputs shared by the golden generator and the tests (defaults: the tiny goldens' shapes)."""
     g = torch.Generator().manual_seed(77 if kind == "itm" else 78)
-    Bv, L, Lp, C = 3, 10, 8, (2 if kind == "itm" else 3)
+    C = 2 if kind == "itm" else 3
     video = torch.randn(Bv, 3, cfg.num_frames, cfg.img_size, cfg.img_size, generator=g)
-    neg = [1, 2, 0, 2, 0, 1] if kind == "itm" else None                     # two derangements (run_retrieval_..._itm.py:110-111)
+    # two derangements (run_retrieval_..._itm.py:110-111): rotations by 1 and by Bv - 1
+    neg = ([(i + 1) % Bv for i in range(Bv)] + [(i + Bv - 1) % Bv for i in range(Bv)]) if kind == "itm" else None
     n = Bv + (len(neg) if neg else 0)
 
     def text(rows, length):
@@ -124,16 +125,29 @@ def gencls_inputs(cfg, kind: str):
                 e_ids=e_ids, e_mask=e_mask, e_pids=e_pids, e_pmask=e_pmask, e_plen=e_plen)
 
 
-def run_gencls(kind: str):
-    """DistributedGPT3_Retrieval_Cls ("itm") / DistributedGPT3_Cls ("cls"), use_cls on: SURVEY.md section 8(f) rank 1."""
+FULL_GENCLS = dict(Bv=3, L=12, Lp=8)      # the true-dims ITM / classification goldens: 16 frames, 1.3B, full depth; 3 clips is what 62 GB of host memory hold of the fp32 reference (4 clips + two derangements: OOM-killed)
+
+
+def full_gencls_cfg():
+    import dataclasses
+    from .weights import CONFIG_B
+    return dataclasses.replace(CONFIG_B, num_frames=16)          # BASELINE.json configs[4]: 16-frame fine-tune at 1.3B dims
+
+
+def run_gencls(kind: str, full: bool = False):
+    """DistributedGPT3_Retrieval_Cls ("itm") / DistributedGPT3_Cls ("cls"), use_cls on: SURVEY.md section 8(f) rank 1.
+    full=True: the reference modules at the TRUE dims (ViT-B/16 x 12 blocks x 16 frames, 24-layer 1.3B decoder), Bv = 4."""
     import types
     from .ref_loader import build_reference_gencls
-    cfg = CONFIG_TINY
-    name = f"{kind}_tiny"
-    rec = {"meta": dict(case=name, weight_seed=3, torch=str(torch.__version__))}
+    cfg = full_gencls_cfg() if full else CONFIG_TINY
+    shape = FULL_GENCLS if full else {}
+    name = f"{kind}_1p3b" if full else f"{kind}_tiny"
+    wseed = 23 if full else 3
+    rec = {"meta": dict(case=name, weight_seed=wseed, torch=str(torch.__version__), **shape)}
     for tag, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
-        inp = gencls_inputs(cfg, kind)
-        model, sd = build_reference_gencls(cfg, kind, 3, dtype=dtype, num_classes=inp["num_classes"])
+        t0 = time.time()
+        inp = gencls_inputs(cfg, kind, **shape)
+        model, sd = build_reference_gencls(cfg, kind, wseed, dtype=dtype, num_classes=inp["num_classes"])
         model.eval()                                                       # dropout off; forward(train=True) still takes the loss branch
         text = types.SimpleNamespace(input_ids=inp["ids"], attention_mask=inp["mask"], prompt_lengths=inp["plen"])
         ptext = types.SimpleNamespace(input_ids=inp["p_ids"], attention_mask=inp["p_mask"])
@@ -156,23 +170,37 @@ def run_gencls(kind: str):
                 gen, cl = model(inp["video"].to(dtype), etext, eptext, train=False)
         r["generation_logits"], r["cls_logits"] = gen.float().clone(), cl.float().clone()
         rec[tag] = r
-        print(f"[{name}/{tag}] loss_caption={float(lc):.6f} loss_cls={float(lk):.6f}", flush=True)
+        print(f"[{name}/{tag}] loss_caption={float(lc):.6f} loss_cls={float(lk):.6f}  {time.time() - t0:.0f}s", flush=True)
+        del model, sd
     path = os.path.join(GOLDEN_DIR, f"{name}.pt")
     torch.save(rec, path)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def full_eva_cfg():
+    """EVA-ViT-g as models/eva_vit.py:413-427 builds it (patch 14, width 1408, 40 blocks, 16 heads of 88, MLP 6144) in front
+    of the 1.3B decoder."""
+    import dataclasses
+    from .weights import CONFIG_B
+    return dataclasses.replace(CONFIG_B, img_size=224, patch_size=14, vit_dim=1408, vit_depth=40, vit_heads=16, vit_mlp_ratio=4.3637,
+                               num_frames=1)
+
+
 def run_eva(name: str = "eva_tiny"):
-    """DistributedGPT3_Pretrain_Image with the EVA encoder, shape-reduced
-    (heads of 88, MLP ratio 4.3637, patch 14); B=3, L=9 ragged, prompt_lengths masked."""
+    """DistributedGPT3_Pretrain_Image with the EVA encoder.  "eva_tiny": shape-reduced
+    (heads of 88, MLP ratio 4.3637, patch 14); B=3, L=9 ragged, prompt_lengths masked.  "eva_g_full": the true ViT-g
+    (1408 x 40 blocks) + the 24-layer 1.3B decoder, B=2."""
     import types
     from .ref_loader import build_reference_image
     from .weights import CONFIG_EVA_TINY
-    cfg = CONFIG_EVA_TINY
-    rec = {"meta": dict(case=name, batch=3, text_len=9, weight_seed=4, input_seed=6, prompt_lengths=[1, 2, 1], torch=str(torch.__version__))}
+    full = name != "eva_tiny"
+    cfg = full_eva_cfg() if full else CONFIG_EVA_TINY
+    B, wseed = (2, 24) if full else (3, 4)
+    rec = {"meta": dict(case=name, batch=B, text_len=9, weight_seed=wseed, input_seed=6, prompt_lengths=[1, 2, 1][:B], torch=str(torch.__version__))}
     for tag, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
-        model, sd = build_reference_image(cfg, 4, dtype=dtype)
-        video, ids, mask = make_inputs(cfg, 3, 9, seed=6, ragged=True)
+        t0 = time.time()
+        model, sd = build_reference_image(cfg, wseed, dtype=dtype)
+        video, ids, mask = make_inputs(cfg, B, 9, seed=6, ragged=True)
         image = video[:, :, 0]
         model.eval()
         captured = {}
@@ -190,13 +218,14 @@ def run_eva(name: str = "eva_tiny"):
         loss.backward()
         out = captured["out"]
         r = {"loss": loss.detach().float().clone(), "losses": out.losses.detach().float().clone(),
-             "logits": out.logits.detach()[:, :, ::8].float().clone(), "grad_norm": {}, "grad_sample": {}}
+             "logits": out.logits.detach()[:, :, ::(50 if full else 8)].float().clone(), "grad_norm": {}, "grad_sample": {}}
         for n, p in model.named_parameters():
             if p.grad is not None:
                 r["grad_norm"][n] = float(p.grad.float().norm())
                 r["grad_sample"][n] = grad_sample(p.grad)
         rec[tag] = r
-        print(f"[{name}/{tag}] loss={float(loss):.6f}", flush=True)
+        print(f"[{name}/{tag}] loss={float(loss):.6f}  {time.time() - t0:.0f}s", flush=True)
+        del model, sd, out, captured
     path = os.path.join(GOLDEN_DIR, f"{name}.pt")
     torch.save(rec, path)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
@@ -207,13 +236,16 @@ def run_caption(name: str = "caption_tiny"):
     best sequence + score per sample, plus the per-step logits of a teacher-forced decode for the cache-path check."""
     import types
     from .ref_loader import build_reference_caption, cpu_generation_patches
-    cfg = CONFIG_TINY
-    rec = {"meta": dict(case=name, batch=2, text_len=6, weight_seed=6, input_seed=8, tokens_to_generate=12, eod_id=7, torch=str(torch.__version__))}
+    from .weights import CONFIG_B
+    full = name != "caption_tiny"          # "caption_1p3b": BASELINE configs[1] dims (8 frames, 24-layer 1.3B decoder), three clips
+    cfg = CONFIG_B if full else CONFIG_TINY
+    B, wseed = (3, 26) if full else (2, 6)
+    rec = {"meta": dict(case=name, batch=B, text_len=6, weight_seed=wseed, input_seed=8, tokens_to_generate=12, eod_id=7, torch=str(torch.__version__))}
     for tag, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
-        model, sd = build_reference_caption(cfg, 6, dtype=dtype, tokens_to_generate=12, eod_id=7)
-        video, ids, mask = make_inputs(cfg, 2, 6, seed=8, ragged=False)
+        model, sd = build_reference_caption(cfg, wseed, dtype=dtype, tokens_to_generate=12, eod_id=7)
+        video, ids, mask = make_inputs(cfg, B, 6, seed=8, ragged=False)
         mask[1, 4:] = 0
-        text = types.SimpleNamespace(input_ids=ids, attention_mask=mask, prompt_lengths=torch.tensor([1, 1]))
+        text = types.SimpleNamespace(input_ids=ids, attention_mask=mask, prompt_lengths=torch.tensor([1] * B))
         model.eval()
         captured = []
         td = model.text_decoder
@@ -277,6 +309,8 @@ if __name__ == "__main__":
             run_retrieval(c)
         elif c in ("itm", "cls"):
             run_gencls(c)
+        elif c in ("itm_1p3b", "cls_1p3b"):
+            run_gencls(c.split("_")[0], full=True)
         elif c.startswith("eva"):
             run_eva(c)
         elif c.startswith("caption"):

@@ -512,3 +512,72 @@ def test_gencls_models_refuse_options_only_the_pretrain_class_implements(monkeyp
         klass(base, visual_cfg=dict(vis, connect_ln=True), text_cfg=txt, device="cpu")
     with pytest.raises(NotImplementedError, match="freeze_text_decoder"):
         klass(dict(base, freeze_text_decoder=False), visual_cfg=vis, text_cfg=txt, device="cpu")
+
+
+_BENCH_WORKER = r'''
+import os, sys
+ROOT = sys.argv[1]
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+torch.set_num_threads(1)
+import standin_ops, test_engine_cpu
+class MP:
+    def setattr(self, o, n, v): setattr(o, n, v)
+standin_ops.install(MP()); test_engine_cpu._stub_optimizer_kernels(MP())
+import bench
+from youku_mplug_amd import gpt3
+S = bench.Shapes                                    # the control flow is what is under test: tiny dims
+S.img_size, S.patch_size, S.vit_dim, S.vit_depth, S.vit_heads, S.num_queries = 64, 16, 192, 2, 2, 32
+S.hidden, S.layers, S.heads, S.ffn, S.vocab, S.max_pos = 256, 2, 4, 1024, 1024, 256
+_init = gpt3.GPT3Config.__init__
+def _no_dropout(self, *a, **k):                     # the stand-ins do not model the hash dropout
+    _init(self, *a, **k); self.hidden_dropout = self.attention_dropout = 0.0
+gpt3.GPT3Config.__init__ = _no_dropout
+sys.argv = ["bench.py", "--gpus", os.environ["WORLD_SIZE"], "--steps", "2", "--warmup", "1", "--batch", "2", "--frames", "4", "--text-len", "8"]
+bench.main()
+'''
+
+
+def test_bench_control_flow_world8_gloo(tmp_path):
+    """VERDICT r03 next-round 7(c): bench.py's N > 1 branch has never run with N > 1 (gpurun boxes have one GPU).  Its control flow --
+    process-group bring-up, parameter broadcast, the bucketed all-reduce in every backward, barrier + sync fences on both sides of
+    the timed region, MAX over ranks of the region's time, the post-run roofline steps on EVERY rank (each holds collectives), ONE
+    JSON line from rank 0 and nothing on any other rank's stdout -- runs here as EIGHT gloo ranks launched the way the driver
+    launches them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), on the stand-ins (MPV_BENCH_DEVICE=cpu: a test
+    hook, tiny dims).  value must be global batch x steps / the slowest rank's time."""
+    import json
+    import subprocess
+    import sys
+    world = 8
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(_BENCH_WORKER)
+    port = 26000 + os.getpid() % 3000
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   MPV_BENCH_DEVICE="cpu", OMP_NUM_THREADS="1")
+        env.pop("MPV_BENCH_FORCE_DIST", None)
+        procs.append(subprocess.Popen([sys.executable, str(script), root], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                      stdin=subprocess.DEVNULL))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, o, e))
+    for r, (rc, o, e) in enumerate(outs):
+        assert rc == 0, (r, e[-1500:])
+    for r in range(1, world):
+        assert outs[r][1].strip() == "", (r, outs[r][1][:300])            # only rank 0 speaks on stdout
+    lines = [ln for ln in outs[0][1].splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == world and rec["steps"] == 2 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["config"]["global_batch"] == world * 2 and rec["config"]["parallelism"] == "dp8"
+    assert rec["value"] == pytest.approx(world * 2 * 2 / (rec["ms_per_step"] * 2e-3), rel=1e-3)
+    assert rec["cpu_baseline"] is None                                      # rank 0 at N = 1 only
+    assert rec["roofline"] is not None and rec["roofline"]["launches_per_step"] > 0

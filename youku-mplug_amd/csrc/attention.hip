@@ -19,6 +19,7 @@
 // Softmax is exact two-pass (pass 1: row max / sum, pass 2: normalised P.V), fp32, which
 // reproduces the reference's "softmax then cast to bf16 then @V" numerics and leaves a
 // per-row log-sum-exp for the backward kernels.
+#include <string.h>
 #include <type_traits>
 
 #include "mpv_common.h"
@@ -1932,6 +1933,144 @@ extern "C" int mpv_attn_bwd(const mpv_attn_desc* d, const void* dO, void* dq, vo
   return mpv_check_launch("mpv_attn_bwd");
 }
 
+// ---- the same problem with its rows in LDS as bf16 (round 4; measured stand-alone in round 3: tools/probe/temporal_bf16_probe.hip,
+// profiles/r03_c26_temporal_bf16_probe.log).  The rows ARE bf16 values (q * scale is rounded to bf16 by the reference itself, :179),
+// so bf16 rows at the conflict-free 208-byte pitch hold the same numbers in half the LDS bytes -- LDS is what limits this kernel's
+// occupancy (a wave's fp32 rows are 10 / 13 KiB at 8 frames, 20 / 28 KiB at 16: 7 / 5 waves per CU there) -- and the two dot-product
+// phases (S = q k^T, dP = dO v^T) run on v_dot2c_f32_bf16 (two MACs per instruction, fp32 accumulate, no widening); the p-weighted row
+// sums widen their operand on the fly.  Outputs differ from the fp32-row kernel by the summation order only (2-4e-3 of the largest
+// element).  8 frames: forward -8 %, backward -4 %; 16 frames: -19 % / -34 %.  Compile-time instances only.
+__device__ __forceinline__ void tdot8(bf16x8 a, bf16x8 b, float& c0, float& c1) {
+  c0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1), c0, false);
+  c1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3), c1, false);
+  c0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 4, 5), __builtin_shufflevector(b, b, 4, 5), c0, false);
+  c1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 6, 7), __builtin_shufflevector(b, b, 6, 7), c1, false);
+}
+
+template <bool BWD, int T, int HD>
+constexpr int temporal_b16_wave_lds() {
+  return ((BWD ? 4 : 3) * T * (HD + 8) * 2 + (BWD ? 2 : 1) * T * (T + 1) * 4 + 15) & ~15;
+}
+
+template <bool BWD, int T, int HD>
+__global__ __launch_bounds__(256) void temporal_attn_b16_kernel(const TempArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float tsm[];
+  constexpr int LDB = HD + 8;                          // bf16 row pitch: 208 bytes at head_dim 96
+  constexpr int H4 = HD / 4, H8 = HD / 8;
+  constexpr int ROWS = (BWD ? 4 : 3) * T * LDB * 2;    // bytes of the bf16 images
+  constexpr int PER_WAVE = temporal_b16_wave_lds<BWD, T, HD>();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwv = (int)(blockDim.x >> 6);
+  const int D = p.heads * HD;
+  char* base = (char*)tsm + wave * PER_WAVE;
+  bf16* qs = (bf16*)base;
+  bf16* ks = qs + T * LDB;
+  bf16* vs = ks + T * LDB;
+  bf16* dos = vs + T * LDB;                            // BWD only
+  float* ps = (float*)(base + ROWS);                   // [T][T+1] probabilities
+  float* dss = ps + T * (T + 1);                       // BWD only: dS
+  const long long nprob = (long long)p.n_outer * p.n_inner * p.heads;
+  const long long pstride = (long long)gridDim.x * nwv;
+  constexpr int NX = (T * H4 + 63) / 64;
+  bf16x4 rq[NX], rk[NX], rv[NX], rd[BWD ? NX : 1];
+  auto row_of = [&](long long pr, int& h) {
+    h = (int)(pr % p.heads);
+    const long long seq = pr / p.heads;
+    const long long o = seq / p.n_inner, i = seq % p.n_inner;
+    return o * p.outer_stride + p.inner_offset + i;
+  };
+  auto request = [&](long long pr) {
+    int h;
+    const long long row0 = row_of(pr, h);
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int x = lane + 64 * j;
+      if (x < T * H4) {
+        const int t = x / H4, c4 = x - t * H4;
+        const bf16* src = p.qkv + (row0 + t * p.t_stride) * (3LL * D) + h * HD + c4 * 4;
+        rq[j] = *(const bf16x4*)src;
+        rk[j] = *(const bf16x4*)(src + D);
+        rv[j] = *(const bf16x4*)(src + 2 * D);
+        if constexpr (BWD) rd[j] = *(const bf16x4*)(p.dout + (row0 + t * p.t_stride) * (long long)D + h * HD + c4 * 4);
+      }
+    }
+  };
+  long long pr0 = (long long)blockIdx.x * nwv + wave;
+  if (pr0 < nprob) request(pr0);
+  for (long long pr = pr0; pr < nprob; pr += pstride) {
+    int h;
+    const long long row0 = row_of(pr, h);
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int x = lane + 64 * j;
+      if (x < T * H4) {
+        const int t = x / H4, c4 = x - t * H4;
+        *(bf16x4*)(qs + t * LDB + c4 * 4) = cvt4(cvt4(rq[j]) * p.scale);      // q * scale rounds to bf16 (reference :179)
+        *(bf16x4*)(ks + t * LDB + c4 * 4) = rk[j];
+        *(bf16x4*)(vs + t * LDB + c4 * 4) = rv[j];
+        if constexpr (BWD) *(bf16x4*)(dos + t * LDB + c4 * 4) = rd[j];
+      }
+    }
+    if (pr + pstride < nprob) request(pr + pstride);   // the next problem's operands travel while this one is computed
+    WAVE_SYNC();
+#pragma unroll
+    for (int x = lane; x < T * T; x += 64) {
+      const int a = x / T, bb = x - a * T;
+      float s0 = 0.f, s1 = 0.f, d0 = 0.f, d1 = 0.f;
+#pragma unroll
+      for (int c8 = 0; c8 < H8; ++c8) {
+        tdot8(*(const bf16x8*)(qs + a * LDB + c8 * 8), *(const bf16x8*)(ks + bb * LDB + c8 * 8), s0, s1);
+        if constexpr (BWD) tdot8(*(const bf16x8*)(dos + a * LDB + c8 * 8), *(const bf16x8*)(vs + bb * LDB + c8 * 8), d0, d1);
+      }
+      ps[a * (T + 1) + bb] = s0 + s1;
+      if constexpr (BWD) dss[a * (T + 1) + bb] = d0 + d1;                  // dP = dO V^T
+    }
+    WAVE_SYNC();
+    if (lane < T) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < T; ++j) mx = fmaxf(mx, ps[lane * (T + 1) + j]);
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < T; ++j) sum += __expf(ps[lane * (T + 1) + j] - mx);
+      const float inv = 1.0f / sum;
+      float dl = 0.f;
+#pragma unroll
+      for (int j = 0; j < T; ++j) {
+        const float pv = __expf(ps[lane * (T + 1) + j] - mx) * inv;
+        ps[lane * (T + 1) + j] = BWD ? pv : bf2f(f2bf(pv));              // forward: probabilities cast to bf16 (:201)
+        if constexpr (BWD) dl += pv * dss[lane * (T + 1) + j];
+      }
+      if constexpr (BWD)                                                   // dS = P * (dP - rowsum(P*dP))
+#pragma unroll
+        for (int j = 0; j < T; ++j) dss[lane * (T + 1) + j] = ps[lane * (T + 1) + j] * (dss[lane * (T + 1) + j] - dl);
+    }
+    WAVE_SYNC();
+#pragma unroll
+    for (int x = lane; x < T * H4; x += 64) {
+      const int a = x / H4, c4 = x - a * H4;
+      if constexpr (!BWD) {
+        f32x4 o4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < T; ++j) o4 += cvt4(*(const bf16x4*)(vs + j * LDB + c4 * 4)) * ps[a * (T + 1) + j];
+        *(bf16x4*)(p.out + (row0 + a * p.t_stride) * (long long)D + h * HD + c4 * 4) = cvt4(o4);
+      } else {
+        f32x4 dq = {0.f, 0.f, 0.f, 0.f}, dk = dq, dv = dq;
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+          dq += cvt4(*(const bf16x4*)(ks + j * LDB + c4 * 4)) * dss[a * (T + 1) + j];
+          dk += cvt4(*(const bf16x4*)(qs + j * LDB + c4 * 4)) * dss[j * (T + 1) + a];
+          dv += cvt4(*(const bf16x4*)(dos + j * LDB + c4 * 4)) * ps[j * (T + 1) + a];
+        }
+        bf16* dst = p.dqkv + (row0 + a * p.t_stride) * (3LL * D) + h * HD + c4 * 4;
+        *(bf16x4*)dst = cvt4(dq * p.scale);
+        *(bf16x4*)(dst + D) = cvt4(dk);
+        *(bf16x4*)(dst + 2 * D) = cvt4(dv);
+      }
+    }
+    WAVE_SYNC();
+  }
+}
+
 static int temporal_common(TempArgs& t, int n_outer, int64_t outer_stride, int n_inner, int64_t inner_offset,
                            int64_t t_stride, int T, int heads, int head_dim, float scale, const char* who) {
   MPV_REQUIRE(T >= 1 && T <= 16, MPV_E_SHAPE, "%s: T=%d must be in [1,16]", who, T);
@@ -1976,6 +2115,38 @@ static void temporal_set_attributes() {
   done = true;
 }
 
+// bf16-row instances (head_dim 96; 4 / 8 / 16 frames): the default; MPV_TEMPORAL_ROWS=fp32 keeps the fp32-row kernel (same-box A/B).
+static bool temporal_rows_bf16() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MPV_TEMPORAL_ROWS");
+    v = (e && !strcmp(e, "fp32")) ? 0 : 1;
+  }
+  return v == 1;
+}
+template <bool BWD, int T>
+static void temporal_b16_launch(const TempArgs& t, hipStream_t stream) {
+  constexpr int NWV = 2;                               // measured best (or tied) at 8 and at 16 frames in both directions
+  constexpr size_t lds = (size_t)NWV * temporal_b16_wave_lds<BWD, T, 96>();
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)temporal_attn_b16_kernel<BWD, T, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr = true;
+  }
+  const long long nprob = (long long)t.n_outer * t.n_inner * t.heads;
+  const int grid = (int)((nprob + NWV - 1) / NWV < 16384 ? (nprob + NWV - 1) / NWV : 16384);
+  hipLaunchKernelGGL((temporal_attn_b16_kernel<BWD, T, 96>), dim3(grid), dim3(64 * NWV), lds, stream, t);
+}
+template <bool BWD>
+static bool temporal_b16_dispatch(const TempArgs& t, hipStream_t stream) {
+  if (t.hd != 96 || !temporal_rows_bf16()) return false;
+  if (t.T == 8) temporal_b16_launch<BWD, 8>(t, stream);
+  else if (t.T == 16) temporal_b16_launch<BWD, 16>(t, stream);
+  else if (t.T == 4) temporal_b16_launch<BWD, 4>(t, stream);
+  else return false;
+  return true;
+}
+
 extern "C" int mpv_temporal_attn_fwd(const void* qkv, void* out, int n_outer, int64_t outer_stride, int n_inner,
                                      int64_t inner_offset, int64_t t_stride, int T, int heads, int head_dim,
                                      float scale, hipStream_t stream) {
@@ -1986,6 +2157,7 @@ extern "C" int mpv_temporal_attn_fwd(const void* qkv, void* out, int n_outer, in
   if (rc) return rc;
   t.qkv = (const bf16*)qkv;
   t.out = (bf16*)out;
+  if (temporal_b16_dispatch<false>(t, stream)) return mpv_check_launch("mpv_temporal_attn_fwd");
   const size_t wave_lds = sizeof(float) * (size_t)(((3 * T * (head_dim + 4) + T * (T + 1)) + 3) & ~3);
   const int nwv = temporal_waves_per_workgroup(wave_lds);
   const size_t lds = nwv * wave_lds;
@@ -2010,6 +2182,7 @@ extern "C" int mpv_temporal_attn_bwd(const void* qkv, const void* dout, void* dq
   t.qkv = (const bf16*)qkv;
   t.dout = (const bf16*)dout;
   t.dqkv = (bf16*)dqkv;
+  if (temporal_b16_dispatch<true>(t, stream)) return mpv_check_launch("mpv_temporal_attn_bwd");
   const size_t wave_lds = sizeof(float) * (size_t)(((4 * T * (head_dim + 4) + 2 * T * (T + 1)) + 3) & ~3);
   const int nwv = temporal_waves_per_workgroup(wave_lds);
   const size_t lds = nwv * wave_lds;

@@ -22,6 +22,7 @@ kernels exist only as HIP (no CPU fallback).
 """
 from __future__ import annotations
 
+import collections
 import math
 import os
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple
@@ -236,6 +237,10 @@ class FlatAdamW:
         self.flat.params[self.lo:self.hi].copy_(self.master)
 
 
+def _graph_queue_depth() -> int:
+    return int(os.environ.get("MPV_GRAPH_QUEUE_DEPTH", "2"))
+
+
 def init_process_group_for_dp(backend: Optional[str] = None, **kw):
     """torch.distributed.init_process_group with the one choice that matters for overlapping the gradient all-reduce with this
     backward: RCCL's kernels go on a HIGH-PRIORITY HIP stream.  The 256x256 GEMM workgroup owns a whole CU (160 KiB of LDS and all
@@ -315,6 +320,7 @@ class MplugEngine(nn.Module):
         self.global_steps = 0
         self._upload_seeds = True
         self._graph = None                    # graph_step(): (torch.cuda.CUDAGraph, static inputs, static loss)
+        self._graph_inflight = collections.deque()   # blocking-sync events of the replays still queued / running
         self._graph_calls = 0
         self._set_dropout_seed()              # rank-distinct masks from the very first micro-batch on
         ve = getattr(model, "visual_encoder", None)
@@ -490,11 +496,24 @@ class MplugEngine(nn.Module):
             (self.optimizer.step_count,) = counters          # the capture executed nothing
             self._graph = (g, static_in, static_loss)
         g, static_in, static_loss = self._graph
+        # Bounded host run-ahead.  hipGraphLaunch on a FULL launch queue busy-waits (measured r03: 72 ms of CPU per 77 ms step,
+        # where the eager path sleeps in the driver) -- on a host shared by eight ranks that spin is what starves the others.  So
+        # the host launches step k + 1 only once step k + 1 - depth has FINISHED, and waits for that asleep (a blocking-sync event:
+        # the thread is descheduled until the interrupt).  depth 2 keeps one whole step queued behind the running one, which is
+        # all the device needs (a replay is one launch); MPV_GRAPH_QUEUE_DEPTH=0 restores the unbounded queue.
+        depth = _graph_queue_depth()
+        if depth > 0:
+            while len(self._graph_inflight) >= depth:
+                self._graph_inflight.popleft().synchronize()
         for d, s_ in zip(static_in, inputs):
             copy_in(d, s_)
         self.optimizer.step_count += 1
         self.optimizer.upload_hyper()                        # this step's lr / bias corrections -> device
         g.replay()
+        if depth > 0:
+            ev = torch.cuda.Event(blocking=True)
+            ev.record()
+            self._graph_inflight.append(ev)
         after()
         return static_loss
 
