@@ -25,6 +25,7 @@ from __future__ import annotations
 import collections
 import math
 import os
+import time
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
 import torch
@@ -498,20 +499,24 @@ class MplugEngine(nn.Module):
         g, static_in, static_loss = self._graph
         # Bounded host run-ahead.  hipGraphLaunch on a FULL launch queue busy-waits (measured r03: 72 ms of CPU per 77 ms step,
         # where the eager path sleeps in the driver) -- on a host shared by eight ranks that spin is what starves the others.  So
-        # the host launches step k + 1 only once step k + 1 - depth has FINISHED, and waits for that asleep (a blocking-sync event:
-        # the thread is descheduled until the interrupt).  depth 2 keeps one whole step queued behind the running one, which is
-        # all the device needs (a replay is one launch); MPV_GRAPH_QUEUE_DEPTH=0 restores the unbounded queue.
+        # the host launches step k + 1 only once step k + 1 - depth has FINISHED, and waits for that ASLEEP: a query / sleep poll
+        # (measured r04 call 1: hipEventSynchronize on a blocking-sync event still spins on this stack -- 72.4 ms of CPU per
+        # 75.3 ms step -- so the wait is time.sleep between hipEventQuery calls; 0.2 ms of granularity against a 75 ms step, with a
+        # whole step still queued behind the running one).  depth 2 is all the device needs (a replay is one launch);
+        # MPV_GRAPH_QUEUE_DEPTH=0 restores the unbounded queue.
         depth = _graph_queue_depth()
         if depth > 0:
             while len(self._graph_inflight) >= depth:
-                self._graph_inflight.popleft().synchronize()
+                ev = self._graph_inflight.popleft()
+                while not ev.query():
+                    time.sleep(2e-4)
         for d, s_ in zip(static_in, inputs):
             copy_in(d, s_)
         self.optimizer.step_count += 1
         self.optimizer.upload_hyper()                        # this step's lr / bias corrections -> device
         g.replay()
         if depth > 0:
-            ev = torch.cuda.Event(blocking=True)
+            ev = torch.cuda.Event()
             ev.record()
             self._graph_inflight.append(ev)
         after()
