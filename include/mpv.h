@@ -86,8 +86,7 @@ typedef struct mpv_gemm_epilogue {
                              i.e. the bias gradient that goes with dW = dY^T X, fused into the same pass */
   int tile_hint;          /* 0: the library picks the tile kernel per problem; 128 / 256 pin the 128x128 or the
                              256x256 eight-phase kernel where it applies, 192 / 160 its 192- and 160-row tile variants
-                             257 = 256-row tiles walked by persistent workgroups whose DMA ring runs across tile
-                             boundaries, where the form allows it (tests and measurements)                     */
+                             (tests and measurements)                                                          */
   void* row_tap_out;      /* optional bf16 [ceil(M / row_tap_group)][N]: rows m with m % row_tap_group == 0 ALSO store
                              bf16(acc * alpha + bias) -- before activation / dropout / residual -- at row m / group.
                              The ViT block uses it to take the per-frame cls rows of the spatial projection out of the

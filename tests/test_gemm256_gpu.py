@@ -273,61 +273,3 @@ def test_gemm256_short_tile_rows_dgrad(dev, rows):
         out = ops.gemm(dy, w, M, N, K, trans_b=True, tile_hint=rows)
         close(out, dy.float() @ w.float(), 1e-2, f"{rows}-row dgrad tile")
         assert torch.equal(out, ops.gemm(dy, w, M, N, K, trans_b=True, tile_hint=256))
-
-
-@pytest.mark.parametrize("M,N,K,tb", [(50432, 3072, 768, 0), (50176, 2304, 768, 0), (50432, 3072, 768, 1), (8192, 1024, 256, 0), (4096, 1024, 512, 1),
-                                       (5000, 1100, 1024, 0), (20000, 768, 2304, 1), (66000, 256, 384, 0), (2048, 2048, 4096, 0)])
-def test_gemm256_persistent_walk(dev, M, N, K, tb):
-    """tile_hint=257: persistent workgroups walk the 256-row tiles of their XCD's range with the DMA ring running across the tile
-    boundary (the next tile's K-tile 0 is fetched by the last two K-tiles of the current one) and a quarter-tile staged epilogue
-    (csrc/gemm256.hip, PERSIST).  Every element keeps its K order, so every epilogue form must be BIT-IDENTICAL to the
-    one-workgroup-per-tile launch (tile_hint=256): plain, bias, erf-GELU + pre-activation copy, GELU', the generic finish (bias +
-    residual, dropout + residual); ragged M / N edges, fewer tiles than CUs, gathered A rows; and a 20-launch race screen (an
-    early read of a ring unit or of a staged quarter shows up as a rare differing tile)."""
-    from youku_mplug_amd import ops
-    from youku_mplug_amd.ops import ACT_GELU_ERF
-    a = rn(M, K, dev=dev, seed=101)
-    w = rn(K, N, dev=dev, seed=102, scale=0.1) if tb else rn(N, K, dev=dev, seed=102, scale=0.1)
-    bias, res = rn(N, dev=dev, seed=103), rn(M, N, dev=dev, seed=104)
-    kw = dict(trans_b=bool(tb))
-    o_ref = ops.gemm(a, w, M, N, K, tile_hint=256, **kw)
-    o = ops.gemm(a, w, M, N, K, tile_hint=257, **kw)
-    close(o, a.float() @ (w.float() if tb else w.float().t()), 1e-2, "persistent walk vs fp32")
-    assert torch.equal(o, o_ref), "plain"
-    assert torch.equal(ops.gemm(a, w, M, N, K, bias=bias, tile_hint=257, **kw), ops.gemm(a, w, M, N, K, bias=bias, tile_hint=256, **kw)), "bias"
-    z0, z1 = torch.empty_like(o), torch.empty_like(o)
-    h0 = ops.gemm(a, w, M, N, K, bias=bias, act=ACT_GELU_ERF, preact_out=z0, tile_hint=257, **kw)
-    h1 = ops.gemm(a, w, M, N, K, bias=bias, act=ACT_GELU_ERF, preact_out=z1, tile_hint=256, **kw)
-    assert torch.equal(h0, h1) and torch.equal(z0, z1), "erf-GELU + pre-activation"
-    assert torch.equal(ops.gemm(a, w, M, N, K, act_bwd_z=res, act_bwd=ACT_GELU_ERF, tile_hint=257, **kw),
-                       ops.gemm(a, w, M, N, K, act_bwd_z=res, act_bwd=ACT_GELU_ERF, tile_hint=256, **kw)), "GELU'"
-    assert torch.equal(ops.gemm(a, w, M, N, K, bias=bias, residual=res, tile_hint=257, **kw),
-                       ops.gemm(a, w, M, N, K, bias=bias, residual=res, tile_hint=256, **kw)), "bias + residual (generic finish)"
-    assert torch.equal(ops.gemm(a, w, M, N, K, bias=bias, residual=res, dropout_p=0.1, seed=5, offset=9, tile_hint=257, **kw),
-                       ops.gemm(a, w, M, N, K, bias=bias, residual=res, dropout_p=0.1, seed=5, offset=9, tile_hint=256, **kw)), "dropout + residual"
-    for _ in range(20):
-        assert torch.equal(o, ops.gemm(a, w, M, N, K, tile_hint=257, **kw)), "race screen"
-        assert torch.equal(h0, ops.gemm(a, w, M, N, K, bias=bias, act=ACT_GELU_ERF, preact_out=z0, tile_hint=257, **kw)), "race screen (two-output epilogue)"
-
-
-def test_gemm256_persistent_walk_mapped_rows_and_auto_choice(dev):
-    """The temporal qkv product of the ViT (gathered A rows: token rows around the per-frame cls slot) through the persistent
-    walk, bit-identical to the per-tile launch; and the library's own choice (tile_hint 0) for the two products the walk exists
-    for -- fc1 + erf-GELU + pre-activation and the qkv projection at config-B rows -- equals the pinned per-tile launch."""
-    from youku_mplug_amd import ops
-    from youku_mplug_amd.ops import ACT_GELU_ERF
-    BT, N1, D, Nout = 256, 197, 768, 2304
-    n = N1 - 1
-    rows = BT * n
-    tok = (n, N1, 1)
-    x, w, bias = rn(BT * N1, D, dev=dev, seed=111), rn(Nout, D, dev=dev, seed=112, scale=0.1), rn(Nout, dev=dev, seed=113)
-    o0 = ops.gemm(x, w, rows, Nout, D, bias=bias, amap=tok, tile_hint=256)
-    o1 = ops.gemm(x, w, rows, Nout, D, bias=bias, amap=tok, tile_hint=257)
-    o2 = ops.gemm(x, w, rows, Nout, D, bias=bias, amap=tok)
-    assert torch.equal(o0, o1) and torch.equal(o0, o2)
-    M, N, K = BT * N1, 3072, 768
-    w1, b1 = rn(N, K, dev=dev, seed=114, scale=0.1), rn(N, dev=dev, seed=115)
-    z0, z1 = torch.empty(M, N, dtype=torch.bfloat16, device=dev), torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-    h0 = ops.gemm(x, w1, M, N, K, bias=b1, act=ACT_GELU_ERF, preact_out=z0, tile_hint=256)
-    h1 = ops.gemm(x, w1, M, N, K, bias=b1, act=ACT_GELU_ERF, preact_out=z1)
-    assert torch.equal(h0, h1) and torch.equal(z0, z1)

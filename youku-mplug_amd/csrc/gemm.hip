@@ -776,7 +776,7 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
     {   // measured on MI355X (tools/gemm_ab.py): the 256x256 kernel wins on every eligible shape of the path, also when
         // its tiles fill only 5/8 of the CUs (M = 5120, N = 2048: 959 vs 764 TFLOP/s)
       GemmArgs h = g;
-      h.tile_rows = (variant == 160 || variant == 192 || variant == 256 || variant == 257) ? variant : 0;      // 257: 256-row tiles, persistent walk
+      h.tile_rows = (variant == 160 || variant == 192 || variant == 256) ? variant : 0;
       h.gm = (ep && ep->gm_hint > 0) ? ep->gm_hint : 0;
       h.splits = s256;
       h.k_per_split = (int)K;

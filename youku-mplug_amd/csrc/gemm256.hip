@@ -99,51 +99,6 @@ __device__ __forceinline__ f32x8 apply_act_grad(f32x8 v, f32x8 z) {
   return v;
 }
 
-// one 8-column chunk of the finish: zb = the staged bf16 (acc * alpha + bias), ex = the prefetched residual / pre-activation
-// chunk of the kinds that read one (EpExt), (m, n) = its global position (in range)
-template <int KIND>
-__device__ __forceinline__ void finish_chunk(const GemmArgs& p, const bf16x8 zb, const bf16x8 ex, const int m, const int n, const uint64_t seed_r) {
-  const long long crow = map_row(p.cmap, m);
-  bf16* cp = (bf16*)p.C + crow * p.ldc + n;
-  if constexpr (KIND == EP_PLAIN) {
-    *(bf16x8*)cp = zb;
-  } else if constexpr (KIND == EP_ERF_PRE || KIND == EP_TANH_PRE) {
-    *(bf16x8*)(p.preact + crow * p.ldc + n) = zb;
-    *(bf16x8*)cp = cvt8(apply_act<KIND == EP_ERF_PRE ? MPV_ACT_GELU_ERF : MPV_ACT_GELU_TANH>(cvt8(zb)));
-  } else if constexpr (KIND == EP_BWD_ERF || KIND == EP_BWD_TANH) {
-    *(bf16x8*)cp = cvt8(apply_act_grad<KIND == EP_BWD_ERF ? MPV_ACT_GELU_ERF : MPV_ACT_GELU_TANH>(cvt8(zb), cvt8(ex)));
-  } else if constexpr (KIND == EP_RES) {
-    if (p.tap_out && m % p.tap_group == 0) *(bf16x8*)(p.tap_out + (long long)(m / p.tap_group) * p.N + n) = zb;
-    *(bf16x8*)cp = cvt8(cvt8(zb) + cvt8(ex));
-  } else if constexpr (KIND == EP_DROP_RES) {
-    const uint64_t base = p.drop_offset + (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
-    const f32x8 v = mpv_dropout_vec<f32x8, 8>(cvt8(zb), seed_r, base, p.drop_thr, p.drop_scale);
-    *(bf16x8*)cp = cvt8(v + cvt8(ex));
-  } else if constexpr (KIND == EP_DROP) {       // dropout(acc + bias): the decoder's sublayer outputs (the residual add is the next LayerNorm's, in fp32)
-    const uint64_t base = p.drop_offset + (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
-    *(bf16x8*)cp = cvt8(mpv_dropout_vec<f32x8, 8>(cvt8(zb), seed_r, base, p.drop_thr, p.drop_scale));
-  } else {
-    f32x8 v = cvt8(zb);
-    if (p.tap_out && m % p.tap_group == 0) *(bf16x8*)(p.tap_out + (long long)(m / p.tap_group) * p.N + n) = zb;
-    if (p.act) {
-      if (p.preact) *(bf16x8*)(p.preact + crow * p.ldc + n) = zb;
-      v = p.act == MPV_ACT_GELU_ERF ? apply_act<MPV_ACT_GELU_ERF>(v) : p.act == MPV_ACT_GELU_TANH ? apply_act<MPV_ACT_GELU_TANH>(v) : apply_act<MPV_ACT_RELU>(v);
-    }
-    if (p.act_bwd) {
-      const f32x8 z = cvt8(*(const bf16x8*)(p.actz + (long long)m * p.ldz + n));
-      v = p.act_bwd == MPV_ACT_GELU_ERF ? apply_act_grad<MPV_ACT_GELU_ERF>(v, z)
-          : p.act_bwd == MPV_ACT_GELU_TANH ? apply_act_grad<MPV_ACT_GELU_TANH>(v, z) : apply_act_grad<MPV_ACT_RELU>(v, z);
-    }
-    if (p.drop_thr) {
-      const uint64_t base = p.drop_offset + (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
-      v = mpv_dropout_vec<f32x8, 8>(v, seed_r, base, p.drop_thr, p.drop_scale);
-    }
-    if (p.residual) v += cvt8(*(const bf16x8*)(p.residual + crow * p.ldr + n));
-    if (p.accumulate) v += cvt8(*(const bf16x8*)cp);
-    *(bf16x8*)cp = cvt8(v);
-  }
-}
-
 // second half of the epilogue: the staged bf16 tile (acc * alpha + bias, pitch CPITCH) -> global, 8 columns per thread.
 // Everything the finish reads from global memory (GELU' pre-activation, residual) is fetched for all 16 chunks of the
 // thread right after the main loop, before the accumulators are staged: interleaved with the stores each load sat behind `s_waitcnt vmcnt(0)` (stores
@@ -193,7 +148,45 @@ __device__ __forceinline__ void finish_rows(const GemmArgs& p, const EpExt<KIND,
     const int m = m0 + row, n = n0 + col;
     if (m < p.M && n < p.N) {
       const bf16x8 zb = *(const bf16x8*)(cb + row * CPITCH + col);
-      finish_chunk<KIND>(p, zb, ex, m, n, seed_r);
+      const long long crow = map_row(p.cmap, m);
+      bf16* cp = (bf16*)p.C + crow * p.ldc + n;
+      if constexpr (KIND == EP_PLAIN) {
+        *(bf16x8*)cp = zb;
+      } else if constexpr (KIND == EP_ERF_PRE || KIND == EP_TANH_PRE) {
+        *(bf16x8*)(p.preact + crow * p.ldc + n) = zb;
+        *(bf16x8*)cp = cvt8(apply_act<KIND == EP_ERF_PRE ? MPV_ACT_GELU_ERF : MPV_ACT_GELU_TANH>(cvt8(zb)));
+      } else if constexpr (KIND == EP_BWD_ERF || KIND == EP_BWD_TANH) {
+        *(bf16x8*)cp = cvt8(apply_act_grad<KIND == EP_BWD_ERF ? MPV_ACT_GELU_ERF : MPV_ACT_GELU_TANH>(cvt8(zb), cvt8(ex)));
+      } else if constexpr (KIND == EP_RES) {
+        if (p.tap_out && m % p.tap_group == 0) *(bf16x8*)(p.tap_out + (long long)(m / p.tap_group) * p.N + n) = zb;
+        *(bf16x8*)cp = cvt8(cvt8(zb) + cvt8(ex));
+      } else if constexpr (KIND == EP_DROP_RES) {
+        const uint64_t base = p.drop_offset + (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
+        const f32x8 v = mpv_dropout_vec<f32x8, 8>(cvt8(zb), seed_r, base, p.drop_thr, p.drop_scale);
+        *(bf16x8*)cp = cvt8(v + cvt8(ex));
+      } else if constexpr (KIND == EP_DROP) {       // dropout(acc + bias): the decoder's sublayer outputs (the residual add is the next LayerNorm's, in fp32)
+        const uint64_t base = p.drop_offset + (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
+        *(bf16x8*)cp = cvt8(mpv_dropout_vec<f32x8, 8>(cvt8(zb), seed_r, base, p.drop_thr, p.drop_scale));
+      } else {
+        f32x8 v = cvt8(zb);
+        if (p.tap_out && m % p.tap_group == 0) *(bf16x8*)(p.tap_out + (long long)(m / p.tap_group) * p.N + n) = zb;
+        if (p.act) {
+          if (p.preact) *(bf16x8*)(p.preact + crow * p.ldc + n) = zb;
+          v = p.act == MPV_ACT_GELU_ERF ? apply_act<MPV_ACT_GELU_ERF>(v) : p.act == MPV_ACT_GELU_TANH ? apply_act<MPV_ACT_GELU_TANH>(v) : apply_act<MPV_ACT_RELU>(v);
+        }
+        if (p.act_bwd) {
+          const f32x8 z = cvt8(*(const bf16x8*)(p.actz + (long long)m * p.ldz + n));
+          v = p.act_bwd == MPV_ACT_GELU_ERF ? apply_act_grad<MPV_ACT_GELU_ERF>(v, z)
+              : p.act_bwd == MPV_ACT_GELU_TANH ? apply_act_grad<MPV_ACT_GELU_TANH>(v, z) : apply_act_grad<MPV_ACT_RELU>(v, z);
+        }
+        if (p.drop_thr) {
+          const uint64_t base = p.drop_offset + (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
+          v = mpv_dropout_vec<f32x8, 8>(v, seed_r, base, p.drop_thr, p.drop_scale);
+        }
+        if (p.residual) v += cvt8(*(const bf16x8*)(p.residual + crow * p.ldr + n));
+        if (p.accumulate) v += cvt8(*(const bf16x8*)cp);
+        *(bf16x8*)cp = cvt8(v);
+      }
     }
   }
 }
@@ -217,17 +210,9 @@ __device__ __forceinline__ i32x4 raw_rsrc(const void* ptr, uint32_t bytes) {
 // on the same ring, DMA schedule and barriers: a wave row then owns 64 + 16*MB1 tile rows, the unused rows of the second
 // A unit are out-of-range DMA lanes (zero fill, no traffic) and their LDS reads / MFMAs are not issued.  For problems
 // whose 256-row tiling leaves CUs idle (M = 5120, N = 2048: 160 tiles on 256 CUs; 160-row tiles: exactly 256).
-// PERSIST (round 4): one workgroup per CU walks several tiles of its XCD's range, and the DMA ring runs ACROSS the tile
-// boundary: the last K-tiles of tile i issue, in the ring slots they free, the four units of K-tile 0 of tile i + 1 (the loop
-// already issues "unit 4t + j + 6"; with an even K-tile count K-tile nk IS the next tile's K-tile 0 and lands in buffer 0), so
-// that tile's 2.2 us prologue flies under this tile's epilogue.  The epilogue then cannot stage the whole 256 x 256 tile over
-// the ring: it stages QUARTERS (64 rows: row blocks {2mp, 2mp+1} of half mh of both wave rows) double-buffered in the 68 KiB
-// the ring does not need at that moment (buffer 1 + the tail of the allocation), each quarter finished row-contiguously while
-// the next one is staged.  Forward / dgrad forms with a k-contiguous A operand, whole 256-row tiles, no split-K.
-template <bool TA, bool TB, bool KMAP, int MB1 = 4, bool PERSIST = false>
+template <bool TA, bool TB, bool KMAP, int MB1 = 4>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   static_assert(MB1 == 4 || !TA, "short tiles exist for a k-contiguous A operand (forward / dgrad forms) only");
-  static_assert(!PERSIST || (!TA && !KMAP && MB1 == 4), "the persistent walk exists for the 256-row forward / dgrad forms");
   constexpr int WROWS = 64 + 16 * MB1;          // tile rows of one wave row
   constexpr int TME = 2 * WROWS;                // tile rows
   constexpr int NIT = TME / 16;
@@ -240,33 +225,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 
   // ---- workgroup -> (split, tile): XCD-aware bijective remap (workgroup b runs on XCD b % 8; each XCD walks a contiguous
   // range), then GM m-tiles per n-tile inside the range so the 32 workgroups resident on an XCD share panels in its L2.
-  // PERSIST: gridDim.x (a multiple of 8) workgroups; workgroup b takes positions (b >> 3) + i * (gridDim.x >> 3) of its XCD's
-  // range -- the order in which the hardware would have dispatched one workgroup per tile.
   const int nwg = p.nwg * p.splits;
   const int bid = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-  const int xbase = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-  const int xcount = q8 + (xcd < r8 ? 1 : 0);
-  const int wstride = PERSIST ? (int)(gridDim.x >> 3) : 1;
-  int wpos = bid >> 3;                          // position inside the XCD's range of the tile being computed
-  int split = 0, m0 = 0, n0 = 0;
-  auto locate = [&](int pos, int& sp, int& mm, int& nn) {
-    const int lin = xbase + pos;
-    sp = lin / p.nwg;
-    const int pid = lin - sp * p.nwg;
-    const int GM = p.gm;
-    const int gsz = GM * p.tiles_n;
-    const int grp = pid / gsz, rem = pid - grp * gsz;
-    const int gm = min(GM, p.tiles_m - grp * GM);
-    const int tile_n = rem / gm, tile_m = grp * GM + (rem - tile_n * gm);
-    mm = p.m_base + tile_m * TME;
-    nn = tile_n * TN;
-  };
-  locate(wpos, split, m0, n0);
+  const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int split = lin / p.nwg;
+  const int pid = lin - split * p.nwg;
+  const int GM = p.gm;
+  const int gsz = GM * p.tiles_n;
+  const int grp = pid / gsz, rem = pid - grp * gsz;
+  const int gm = min(GM, p.tiles_m - grp * GM);
+  const int tile_n = rem / gm, tile_m = grp * GM + (rem - tile_n * gm);
+  const int m0 = p.m_base + tile_m * TME, n0 = tile_n * TN;
 
   const int kbeg = split * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
-  const int nk = (kend - kbeg) / TK;            // launcher guarantees whole K-tiles (PERSIST: an even count >= 4, one split)
+  const int nk = (kend - kbeg) / TK;            // launcher guarantees whole K-tiles
 
   const i32x4 ra = raw_rsrc(p.A, p.a_bytes);
   const i32x4 rb = raw_rsrc(p.B, p.b_bytes);
@@ -276,40 +250,37 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   constexpr uint32_t OOB = 0x80000000u;
   uint32_t vo[4][2];
   constexpr bool kmapped = KMAP;
-  auto set_vo = [&](const int m0, const int n0, const int lane) {      // (shadows the tile origin and the lane id on purpose: PERSIST calls it for the NEXT tile)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if constexpr (!TA) {   // [128 rows][64 k] image: instruction (wave, j) covers unit rows 16*wave + 8*j + lane/8
-        const int ur = wave * 16 + j * 8 + (lane >> 3);
-        const int kc = (lane & 7) ^ (j * 4 + (lane >> 4));          // = chunk slot ^ ((ur >> 1) & 7)
-        const int mA = m0 + (ur >> 6) * WROWS + (ur & 63);
-        vo[0][j] = mA < p.M ? (uint32_t)((map_row(p.amap, mA) * p.lda + kc * 8) * 2) : OOB;
-        vo[3][j] = (ur & 63) < 16 * MB1 && mA + 64 < p.M ? (uint32_t)((map_row(p.amap, mA + 64) * p.lda + kc * 8) * 2) : OOB;
-      } else {               // [64 k][128 cols] image: instruction (wave, j) covers k rows 8*wave + 4*j + lane/16
-        const int f8 = (lane >> 4) | ((wave & 1) << 2);
-        const int c = ((((lane & 15) >> 1) ^ f8) << 4) + (lane & 1) * 8;     // unit column of this lane's 8 elements
-        const int mA = m0 + (c >> 6) * 128 + (c & 63);
-        const uint32_t kr = kmapped ? 0u : (uint32_t)((wave * 8 + j * 4 + (lane >> 4)) * p.lda * 2);
-        vo[0][j] = mA < p.M ? kr + (uint32_t)(mA * 2) : OOB;
-        vo[3][j] = mA + 64 < p.M ? kr + (uint32_t)((mA + 64) * 2) : OOB;
-      }
-      if constexpr (!TB) {
-        const int ur = wave * 16 + j * 8 + (lane >> 3);
-        const int kc = (lane & 7) ^ (j * 4 + (lane >> 4));
-        const int nB = n0 + (ur >> 5) * 64 + (ur & 31);
-        vo[1][j] = nB < p.N ? (uint32_t)(((long long)nB * p.ldb + kc * 8) * 2) : OOB;
-        vo[2][j] = nB + 32 < p.N ? (uint32_t)(((long long)(nB + 32) * p.ldb + kc * 8) * 2) : OOB;
-      } else {
-        const int f8 = (lane >> 4) | ((wave & 1) << 2);
-        const int c = ((((lane & 15) >> 1) ^ f8) << 4) + (lane & 1) * 8;
-        const int nB = n0 + (c >> 5) * 64 + (c & 31);
-        const uint32_t kr = kmapped ? 0u : (uint32_t)((wave * 8 + j * 4 + (lane >> 4)) * p.ldb * 2);
-        vo[1][j] = nB < p.N ? kr + (uint32_t)(nB * 2) : OOB;
-        vo[2][j] = nB + 32 < p.N ? kr + (uint32_t)((nB + 32) * 2) : OOB;
-      }
+  for (int j = 0; j < 2; ++j) {
+    if constexpr (!TA) {   // [128 rows][64 k] image: instruction (wave, j) covers unit rows 16*wave + 8*j + lane/8
+      const int ur = wave * 16 + j * 8 + (lane >> 3);
+      const int kc = (lane & 7) ^ (j * 4 + (lane >> 4));          // = chunk slot ^ ((ur >> 1) & 7)
+      const int mA = m0 + (ur >> 6) * WROWS + (ur & 63);
+      vo[0][j] = mA < p.M ? (uint32_t)((map_row(p.amap, mA) * p.lda + kc * 8) * 2) : OOB;
+      vo[3][j] = (ur & 63) < 16 * MB1 && mA + 64 < p.M ? (uint32_t)((map_row(p.amap, mA + 64) * p.lda + kc * 8) * 2) : OOB;
+    } else {               // [64 k][128 cols] image: instruction (wave, j) covers k rows 8*wave + 4*j + lane/16
+      const int f8 = (lane >> 4) | ((wave & 1) << 2);
+      const int c = ((((lane & 15) >> 1) ^ f8) << 4) + (lane & 1) * 8;     // unit column of this lane's 8 elements
+      const int mA = m0 + (c >> 6) * 128 + (c & 63);
+      const uint32_t kr = kmapped ? 0u : (uint32_t)((wave * 8 + j * 4 + (lane >> 4)) * p.lda * 2);
+      vo[0][j] = mA < p.M ? kr + (uint32_t)(mA * 2) : OOB;
+      vo[3][j] = mA + 64 < p.M ? kr + (uint32_t)((mA + 64) * 2) : OOB;
     }
-  };
-  set_vo(m0, n0, lane);
+    if constexpr (!TB) {
+      const int ur = wave * 16 + j * 8 + (lane >> 3);
+      const int kc = (lane & 7) ^ (j * 4 + (lane >> 4));
+      const int nB = n0 + (ur >> 5) * 64 + (ur & 31);
+      vo[1][j] = nB < p.N ? (uint32_t)(((long long)nB * p.ldb + kc * 8) * 2) : OOB;
+      vo[2][j] = nB + 32 < p.N ? (uint32_t)(((long long)(nB + 32) * p.ldb + kc * 8) * 2) : OOB;
+    } else {
+      const int f8 = (lane >> 4) | ((wave & 1) << 2);
+      const int c = ((((lane & 15) >> 1) ^ f8) << 4) + (lane & 1) * 8;
+      const int nB = n0 + (c >> 5) * 64 + (c & 31);
+      const uint32_t kr = kmapped ? 0u : (uint32_t)((wave * 8 + j * 4 + (lane >> 4)) * p.ldb * 2);
+      vo[1][j] = nB < p.N ? kr + (uint32_t)(nB * 2) : OOB;
+      vo[2][j] = nB + 32 < p.N ? kr + (uint32_t)((nB + 32) * 2) : OOB;
+    }
+  }
   // mapped reduction rows (temporal-branch wgrad): physical row of this lane's k row of the K-tile being issued
   uint32_t prow[2] = {0u, 0u};
   auto map_ktile = [&](int kt) {
@@ -319,26 +290,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     }
   };
 
-  // issue the two DMA instructions of unit X (0..3) of K-tile kt into ring slot `slot`.
-  // PERSIST: K-tile nk is K-tile 0 of the walk's next tile (`vo` holds that tile's offsets by then, see the K loop); anything
-  // further ahead is not issued at all (no zero-fill DMA may land in what is staging memory during the epilogue) -- the
-  // counted waits stay correct with fewer instructions in flight: they only ever require OLDER units to have landed.
-  bool has_next = false;                                             // wave-uniform; PERSIST only: the walk has another tile,
-  int nm0 = 0, nn0 = 0;                                              // ... and this is its origin
-  int relax_now = 0;                                                 // phases 0 / 1 of K-tile 0 of a tile the walk switched to (see phase)
-  auto issue_unit = [&](auto X, int kt, int slot, bool ahead = false) {
+  // issue the two DMA instructions of unit X (0..3) of K-tile kt into ring slot `slot`
+  auto issue_unit = [&](auto X, int kt, int slot) {
     constexpr int x = decltype(X)::value;
     constexpr bool isA = (x == 0 || x == 3);
     constexpr bool T = isA ? TA : TB;
-    bool live = kt < nk;                                           // wave-uniform
-    int kel = kbeg + kt * TK;                                      // first reduction element of the K-tile
-    if constexpr (PERSIST) {
-      if (!live) {                                                 // (ahead: the next tile's K-tile-1 pair, issued after the epilogue)
-        if (!(has_next && (kt == nk || ahead))) return;
-        live = true;
-        kel = (kt - nk) * TK;
-      }
-    }
+    const bool live = kt < nk;                                     // wave-uniform
     const uint32_t dead = live ? 0u : OOB;                         // units past the end: every lane out of range -> zero fill, no traffic
     const i32x4 r = isA ? ra : rb;
     const long long ld = isA ? p.lda : p.ldb;
@@ -346,9 +303,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     for (int j = 0; j < 2; ++j) {
       const uint32_t dst = smem_base + (uint32_t)(slot * UNIT + (wave * 2 + j) * 1024);
       if constexpr (!T) {
-        dma16(r, dst, vo[x][j] | dead, live ? (uint32_t)(kel * 2) : 0u);
+        dma16(r, dst, vo[x][j] | dead, live ? (uint32_t)((kbeg + kt * TK) * 2) : 0u);
       } else if constexpr (!kmapped) {
-        dma16(r, dst, vo[x][j] | dead, live ? (uint32_t)((long long)kel * ld * 2) : 0u);
+        dma16(r, dst, vo[x][j] | dead, live ? (uint32_t)((long long)(kbeg + kt * TK) * ld * 2) : 0u);
       } else {
         dma16(r, dst, (vo[x][j] == OOB ? OOB : vo[x][j] + (uint32_t)(prow[j] * ld * 2)) | dead, 0u);
       }
@@ -499,28 +456,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     SCHED_FENCE();
     // unit (4t + j + 6): K-tile t+1 for j < 2 (other buffer), t+2 for j >= 2 (this buffer); unit-in-buffer (j + 2) & 3
     if constexpr (j == 2) map_ktile(t + 2);
-    if constexpr (PERSIST && j == 2 && buf == 0) {
-      asm volatile("s_mov_b32 %0, 0" : "=s"(relax_now));      // (opaque: a phi that turns invariant after one iteration gets the iteration peeled)
-      // every unit of the current tile has been issued by now (U0 / U1 of its last K-tile at t = nk - 3, U2 / U3 in phases 0 and
-      // 1 of this K-tile): from this phase on the ring fetches the next tile of the walk -- its offsets replace the current ones
-      // in place (no second set of 8 VGPRs lives across the loop)
-      if (t == nk - 2 && has_next) {
-        // the lane id is recomputed (v_mbcnt), not kept: neither it nor the lane-derived terms of the offsets may live in VGPRs
-        // across the tile walk
-        set_vo(nm0, nn0, (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
-      }
-    }
     issue_unit(IC<((j + 2) & 3)>{}, t + (j < 2 ? 1 : 2), (j < 2 ? (buf ^ 1) : buf) * 4 + ((j + 2) & 3));
-    // vmcnt(6): everything but the three newest units of this wave has landed.  (relax: K-tile 0 of a tile the persistent walk
-    // switched to -- it landed whole during the previous tile's epilogue, so phases 0 and 1 wait for nothing; with vmcnt(6) they
-    // would wait for the ACKNOWLEDGEMENTS of that epilogue's last stores, which are older than the units in flight: no wait.)
-    if constexpr (PERSIST && j < 2 && buf == 0) {
-      // one opaque statement (a C-level branch on the flag made the compiler peel / duplicate the K loop: spills inside it):
-      // skip the wait when the flag is set
-      asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1\n\ts_waitcnt vmcnt(6)" : : "s"(relax_now) : "scc", "memory");
-    } else {
-      __builtin_amdgcn_s_waitcnt(0x0F76);
-    }
+    __builtin_amdgcn_s_waitcnt(0x0F76);   // vmcnt(6): everything but the three newest units of this wave has landed
     SCHED_FENCE();
     __builtin_amdgcn_s_barrier();
     SCHED_FENCE();
@@ -540,154 +477,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     phase(IC<2>{}, BUF, t);
     phase(IC<3>{}, BUF, t);
   };
-
-  if constexpr (PERSIST) {
-    // ============================================================================================ persistent tile walk
-    constexpr int QELEMS = 64 * CPITCH;                              // one staged quarter (64 rows), bf16 elements
-    static_assert(4 * UNIT + 2 * QELEMS * 2 <= SMEM_BYTES, "two staged quarters fit behind ring buffer 0");
-    bf16* const cbase = (bf16*)(smem + 4 * UNIT);
-    // tile row of local row lr (0..63) of quarter q = 2 * mh + mp: wave row lr >> 5, half mh, row blocks {2mp, 2mp + 1}
-    auto qrow = [&](int q, int lr) { return (lr >> 5) * 128 + (q >> 1) * 64 + (q & 1) * 32 + (lr & 31); };
-    auto epilogue_q = [&](auto kind) {
-      constexpr int KIND = decltype(kind)::value;
-      constexpr bool EXT = EpExt<KIND, 4>::EXT;
-      const uint64_t seed_r = p.drop_thr ? mpv_resolve_seed(p.seed) : 0;
-      // Everything the epilogue derives from the thread / lane id is loop-invariant over the tile walk; hoisted, it would live in
-      // VGPRs across the K loop (246 there already) and spill, and a scratch reload waits with vmcnt(0) -- i.e. for the next
-      // tile's DMAs.  Laundered ids keep those values inside the epilogue.
-      const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));     // recomputed, not kept (v_mbcnt)
-      const int tid = wave * 64 + lane_e, l15 = lane_e & 15, lg = lane_e >> 4;
-      bf16x8 ext[2][EXT ? 4 : 1];
-      auto prefetch = [&](auto Q) {
-        constexpr int q = decltype(Q)::value;
-        if constexpr (EXT) {
-#pragma unroll
-          for (int it = 0; it < 4; ++it) {
-            const int c = tid + 512 * it;
-            const int m = m0 + qrow(q, c >> 5), n = n0 + (c & 31) * 8;
-            ext[q & 1][it] = bf16x8{};
-            if (m < p.M && n < p.N) {
-              if constexpr (KIND == EP_BWD_ERF || KIND == EP_BWD_TANH) ext[q & 1][it] = *(const bf16x8*)(p.actz + (long long)m * p.ldz + n);
-              else ext[q & 1][it] = *(const bf16x8*)(p.residual + map_row(p.cmap, m) * p.ldr + n);
-            }
-          }
-        }
-      };
-      auto stage = [&](auto Q) {
-        constexpr int q = decltype(Q)::value, mh = q >> 1, mp = q & 1;
-        bf16* cb = cbase + (q & 1) * QELEMS;
-#pragma unroll
-        for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-          for (int nb = 0; nb < 2; ++nb) {
-            const int col = wc * 64 + nh * 32 + nb * 16 + lg * 4;
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias && n0 + col < p.N) bv = cvt4(*(const bf16x4*)(p.bias + n0 + col));
-#pragma unroll
-            for (int mbl = 0; mbl < 2; ++mbl)
-              *(bf16x4*)(cb + (wr * 32 + mbl * 16 + l15) * CPITCH + col) = cvt4(acc[mh][nh][2 * mp + mbl][nb] + bv);
-          }
-      };
-      auto finish = [&](auto Q) {
-        constexpr int q = decltype(Q)::value;
-        const bf16* cb = cbase + (q & 1) * QELEMS;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int c = tid + 512 * it;
-          const int lr = c >> 5, col = (c & 31) * 8;
-          const int m = m0 + qrow(q, lr), n = n0 + col;
-          if (m < p.M && n < p.N) {
-            const bf16x8 zb = *(const bf16x8*)(cb + lr * CPITCH + col);
-            bf16x8 ex = bf16x8{};
-            if constexpr (EXT) ex = ext[q & 1][it];
-            finish_chunk<KIND>(p, zb, ex, m, n, seed_r);
-          }
-        }
-      };
-      prefetch(IC<0>{});
-      stage(IC<0>{});
-      // this wave's share of the next tile's K-tile 0 (in flight since the last two K-tiles of the loop) and the prefetched rows
-      // have landed before its first store goes out; the barriers below make that true for every wave before the ring is read
-      __builtin_amdgcn_s_waitcnt(0x0F70);
-      __syncthreads();
-      prefetch(IC<1>{});
-      stage(IC<1>{});
-      finish(IC<0>{});
-      __syncthreads();
-      prefetch(IC<2>{});
-      stage(IC<2>{});
-      finish(IC<1>{});
-      __syncthreads();
-      prefetch(IC<3>{});
-      stage(IC<3>{});
-      finish(IC<2>{});
-      __syncthreads();                     // staging buffer 0 (ring slots 4, 5) has been read: the next tile's K-tile-1 pair may land there
-      issue_unit(IC<0>{}, nk + 1, 4, true);
-      issue_unit(IC<1>{}, nk + 1, 5, true);
-      finish(IC<3>{});
-      __syncthreads();                     // staging buffer 1 (ring slots 6, 7) has been read before phase 0 of the next tile refills slot 6
-    };
-
-    // first tile of the walk: the standard prologue
-    issue_unit(IC<0>{}, 0, 0);
-    issue_unit(IC<1>{}, 0, 1);
-    issue_unit(IC<2>{}, 0, 2);
-    issue_unit(IC<3>{}, 0, 3);
-    issue_unit(IC<0>{}, 1, 4);
-    issue_unit(IC<1>{}, 1, 5);
-    __builtin_amdgcn_s_waitcnt(0x0F74);
-    SCHED_FENCE();
-    __builtin_amdgcn_s_barrier();
-    SCHED_FENCE();
-    const float alpha = p.alpha * (p.alpha_dev ? *p.alpha_dev : 1.0f);
-    const int cfg = (p.act ? 1 : 0) | (p.act_bwd ? 2 : 0) | (p.drop_thr ? 4 : 0) | (p.residual ? 8 : 0) | (p.accumulate ? 16 : 0) |
-                    (p.preact ? 32 : 0) | (p.tap_out && !(p.residual && !p.act && !p.act_bwd && !p.drop_thr && !p.accumulate && !p.preact) ? 64 : 0);
-    while (true) {
-      has_next = wpos + wstride < xcount;
-      if (has_next) {
-        int sp;
-        locate(wpos + wstride, sp, nm0, nn0);
-      }
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (wr == 1) __builtin_amdgcn_s_barrier();   // stagger
-      SCHED_FENCE();
-      for (int t = 0; t + 2 <= nk; t += 2) {
-        ktile(IC<0>{}, t);
-        ktile(IC<1>{}, t + 1);
-      }
-      SCHED_FENCE();
-      if (wr == 0) __builtin_amdgcn_s_barrier();   // un-stagger
-      SCHED_FENCE();
-      __syncthreads();                             // every wave has read the last K-tile (buffer 1): its slots are staging memory now
-      if (alpha != 1.0f) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-              for (int d = 0; d < 2; ++d) acc[a][b][c][d] *= alpha;
-      }
-      if (cfg == 0) epilogue_q(IC<EP_PLAIN>{});
-      else if (cfg == (1 | 32) && p.act == MPV_ACT_GELU_ERF) epilogue_q(IC<EP_ERF_PRE>{});
-      else if (cfg == 2 && p.act_bwd == MPV_ACT_GELU_ERF) epilogue_q(IC<EP_BWD_ERF>{});
-      else epilogue_q(IC<EP_GENERIC>{});
-      if (!has_next) break;
-      m0 = nm0;
-      n0 = nn0;
-      wpos += wstride;
-      relax_now = 1;
-    }
-    return;
-  }
 
   // ---- prologue: units 0..5 (K-tile 0 and U0, U1 of K-tile 1)
   map_ktile(0);
@@ -927,32 +716,6 @@ bool mpv_gemm256_try_launch(const GemmArgs& g0, int transA, int transB, hipStrea
       ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     }
     nband = plan_bands(g.M, g.tiles_n, g.K, 1.0f + (g.preact ? 1.0f : 0.f) + ((g.residual || g.act_bwd) ? 0.5f : 0.f), ncu, plan);
-  }
-  // Persistent walk with the DMA ring running across tile boundaries (gemm256_kernel<.., PERSIST>): single-band launches of 256-row
-  // tiles that run MANY rounds on a SHORT reduction -- where the 2.2 us prologue is a tenth of a tile and the rounds are too many
-  // for row bands to help (the ViT's K = 768 products with N = 2304 / 3072: 7 and 9 rounds).  MPV_GEMM_PERSIST=0 off, 2 = wherever
-  // the form allows it (tests, A/B).
-  static const int env_persist = [] { const char* e = getenv("MPV_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
-  static int ncu_p = 0;
-  if (!ncu_p) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    ncu_p = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-  }
-  const int nk_all = g.K / TK;
-  const long long tiles_all = (long long)((g.M + 255) / 256) * g.tiles_n;
-  const bool persist_ok = !transA && !km && !g.out_f32 && g.splits == 1 && nband == 1 && plan[0].rows == 256 && nk_all >= 4 && nk_all % 2 == 0 &&
-                          tiles_all >= 16 && ncu_p >= 8;
-  const bool persist = persist_ok && (g.tile_rows == 257 || env_persist == 2 || (g.tile_rows == 0 && env_persist == 1 && g.K <= 1024 && tiles_all > 4ll * ncu_p));
-  if (persist) {
-    g.m_base = 0;
-    g.tiles_m = plan[0].m_tiles;
-    g.nwg = g.tiles_m * g.tiles_n;
-    const int grid_p = (int)std::min<long long>((long long)(ncu_p & ~7), tiles_all & ~7ll);
-    const dim3 grid((unsigned)grid_p), block(512);
-    if (!transB) hipLaunchKernelGGL((gemm256_kernel<false, false, false, 4, true>), grid, block, 0, stream, g);
-    else hipLaunchKernelGGL((gemm256_kernel<false, true, false, 4, true>), grid, block, 0, stream, g);
-    return true;
   }
   const int M_all = g.M;
   int m_base = 0;
