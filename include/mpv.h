@@ -43,6 +43,10 @@ typedef struct ihipStream_t* mpv_stream_t; /* == hipStream_t */
 #define MPV_ACT_GELU_ERF 1  /* nn.GELU, models/vision_transformer.py:94,99 */
 #define MPV_ACT_GELU_TANH 2 /* megatron bias_gelu_impl, models/modeling_distributed_gpt3.py:586-588 */
 #define MPV_ACT_RELU 3      /* nn.ReLU of cls_head, models/distributed_gpt3.py:526-530, 1081-1085 */
+#define MPV_ACT_DERIV 4     /* act_bwd only: act_bwd_z already HOLDS act'(z) (a forward launch with preact_deriv wrote it): the
+                               backward epilogue is one multiply.  The GELU' polynomial then runs in the forward epilogue, which
+                               is bound by its two stores and has the VALU slots free, instead of in the dgrad epilogue, which it
+                               bound (fc2-dgrad x GELU' at K = 768: 33 vs 26 us per round of tiles, r04) */
 
 /* Dropout seeds.  Every `seed` argument / field of this header is a 64-bit value.  A seed with bit 63 CLEAR is the seed itself.
  * A seed with bit 63 SET (MPV_SEED_FROM_DEVICE(ptr)) carries in its low 63 bits the device address of a uint64_t that holds the
@@ -94,6 +98,8 @@ typedef struct mpv_gemm_epilogue {
   int row_tap_group;
   int split_hint;         /* measurements: > 0 pins the split-K count of a wgrad product (0: the library picks)              */
   int gm_hint;            /* measurements: > 0 pins the m-tiles per n-tile of an XCD's tile walk in the 256x256 kernel       */
+  int preact_deriv;       /* with act (GELU kinds) and preact_out: preact_out receives bf16(act'(bf16(acc + bias))) instead of the
+                             pre-activation itself -- what the matching dgrad multiplies by (act_bwd = MPV_ACT_DERIV)               */
 } mpv_gemm_epilogue;
 
 size_t mpv_gemm_workspace_size(int64_t M, int64_t N, int64_t K, int transA, int transB);

@@ -68,8 +68,11 @@ gemm_calls = 0
 def gemm(a, b, M, N, K, *, out=None, trans_a=False, trans_b=False, lda=None, ldb=None, ldc=None, bias=None, act=0, preact_out=None,
          residual=None, ldr=0, act_bwd_z=None, act_bwd=0, ldz=0, dropout_p=0.0, seed=0, offset=0, alpha_dev=None, alpha=0.0,
          amap=IDENT, cmap=IDENT, kmap=IDENT, out_rows=None, accumulate=False, out_f32=False, colsum_out=None, tile_hint=0,
-         row_tap_out=None, row_tap_group=0, split_hint=0, gm_hint=0):
-    """include/mpv.h mpv_gemm_bf16: C[M,N] = epilogue(sum_k A(m,k) B(n,k))."""
+         row_tap_out=None, row_tap_group=0, split_hint=0, gm_hint=0, preact_deriv=False, z_is_deriv=False):
+    """include/mpv.h mpv_gemm_bf16: C[M,N] = epilogue(sum_k A(m,k) B(n,k)).  preact_deriv / z_is_deriv: the product's own pair of
+    switches (ops.gemm): preact_out receives bf16(act'(zb)) and the dgrad multiplies by that tensor (MPV_ACT_DERIV)."""
+    from youku_mplug_amd import ops as _ops
+    deriv_on = _ops.GELU_DERIV_FWD
     assert dropout_p == 0.0, "stand-ins do not model the hash dropout"
     assert not (trans_a and not trans_b)
     lda = lda if lda is not None else (M if trans_a else K)
@@ -102,11 +105,11 @@ def gemm(a, b, M, N, K, *, out=None, trans_a=False, trans_b=False, lda=None, ldb
         _wr(row_tap_out, torch.arange(len(sel)), N, zb[sel])
     if act:
         if preact_out is not None:
-            _wr(preact_out, crow, ldc, zb)
+            _wr(preact_out, crow, ldc, _act_grad(zb, act) if (preact_deriv and deriv_on) else zb)
         v = _act(v, act)
     if act_bwd_z is not None and act_bwd:
         zz = _rd(act_bwd_z, torch.arange(M), ldz if ldz else N, N)
-        v = v * _act_grad(zz, act_bwd)
+        v = v * (zz if (z_is_deriv and deriv_on) else _act_grad(zz, act_bwd))
     if residual is not None:
         v = v + _rd(residual, crow, ldr if ldr else ldc, N)
     if accumulate:

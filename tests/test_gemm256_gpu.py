@@ -273,3 +273,31 @@ def test_gemm256_short_tile_rows_dgrad(dev, rows):
         out = ops.gemm(dy, w, M, N, K, trans_b=True, tile_hint=rows)
         close(out, dy.float() @ w.float(), 1e-2, f"{rows}-row dgrad tile")
         assert torch.equal(out, ops.gemm(dy, w, M, N, K, trans_b=True, tile_hint=256))
+
+
+@pytest.mark.parametrize("hint", [256, 128, 160])
+def test_gemm_gelu_derivative_parked_by_the_forward(dev, hint):
+    """preact_deriv / MPV_ACT_DERIV (include/mpv.h): the MLP's first product parks bf16(GELU'(bf16(acc + bias))) instead of the
+    pre-activation, and the matching dgrad epilogue is one multiply by that tensor.  (a) the parked tensor against autograd's
+    GELU' of the rounded pre-activation, both GELU kinds, every tile kernel; (b) the dgrad through it against the dgrad that
+    evaluates GELU'(z) itself: they differ by ONE bf16 rounding of the derivative (<= 2^-8 relative per element)."""
+    from youku_mplug_amd import ops
+    M, N, K = 600, 512, 192
+    a, w, bias = rn(M, K, dev=dev, seed=7), rn(N, K, dev=dev, seed=8, scale=0.1), rn(N, dev=dev, seed=9)
+    dy, w2 = rn(M, K, dev=dev, seed=12), rn(K, N, dev=dev, seed=13, scale=0.1)
+    for act, approx in ((ops.ACT_GELU_ERF, "none"), (ops.ACT_GELU_TANH, "tanh")):
+        z = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        d = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        h0 = ops.gemm(a, w, M, N, K, bias=bias, act=act, preact_out=z, tile_hint=hint)
+        h1 = ops.gemm(a, w, M, N, K, bias=bias, act=act, preact_out=d, preact_deriv=True, tile_hint=hint)
+        assert torch.equal(h0, h1), "the activation output does not depend on what is parked"
+        zz = z.float().requires_grad_(True)
+        F.gelu(zz, approximate=approx).sum().backward()
+        if ops.GELU_DERIV_FWD:
+            assert (d.float() - zz.grad).abs().max().item() <= 6e-3, "parked GELU'(z): polynomial + one bf16 rounding"
+            g_ref = ops.gemm(dy, w2, M, N, K, trans_b=True, act_bwd_z=z, act_bwd=act, tile_hint=hint)
+            g_new = ops.gemm(dy, w2, M, N, K, trans_b=True, act_bwd_z=d, act_bwd=act, z_is_deriv=True, tile_hint=hint)
+            close(g_new, (dy.float() @ w2.float()) * zz.grad, 1e-2, "dgrad x parked derivative vs fp32")
+            assert rel_err(g_new, g_ref) <= 6e-3
+        else:
+            assert torch.equal(d, z)

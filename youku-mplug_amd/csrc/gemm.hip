@@ -433,15 +433,24 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
         if (p.tap_out && m % p.tap_group == 0) *(bf16x8*)(p.tap_out + (long long)(m / p.tap_group) * p.N + n) = cvt8(v);
         if (p.act) {
           const bf16x8 zb = cvt8(v);
-          if (p.preact) *(bf16x8*)(p.preact + crow * p.ldc + n) = zb;
           const f32x8 z = cvt8(zb);
+          if (p.preact) {
+            if (p.preact_deriv) {
+              f32x8 d;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) d[e] = p.act == 1 ? gelu_erf_grad_f(z[e]) : gelu_tanh_grad_f(z[e]);
+              *(bf16x8*)(p.preact + crow * p.ldc + n) = cvt8(d);
+            } else {
+              *(bf16x8*)(p.preact + crow * p.ldc + n) = zb;
+            }
+          }
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = p.act == 1 ? gelu_erf_f(z[e]) : p.act == 2 ? gelu_tanh_f(z[e]) : fmaxf(z[e], 0.f);
         }
         if (p.act_bwd) {
           const f32x8 z = cvt8(*(const bf16x8*)(p.actz + (long long)m * p.ldz + n));
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= p.act_bwd == 1 ? gelu_erf_grad_f(z[e]) : p.act_bwd == 2 ? gelu_tanh_grad_f(z[e]) : (z[e] > 0.f ? 1.f : 0.f);
+          for (int e = 0; e < 8; ++e) v[e] *= p.act_bwd == 1 ? gelu_erf_grad_f(z[e]) : p.act_bwd == 2 ? gelu_tanh_grad_f(z[e]) : p.act_bwd == MPV_ACT_DERIV ? z[e] : (z[e] > 0.f ? 1.f : 0.f);
         }
         if (p.drop_thr) {
           const uint64_t base = p.drop_offset + (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
@@ -700,6 +709,9 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
     g.actz = (const bf16*)ep->act_bwd_z;
     g.ldz = ep->ldz ? ep->ldz : N;
     g.act_bwd = ep->act_bwd_z ? ep->act_bwd : 0;
+    MPV_REQUIRE(!ep->preact_deriv || (ep->preact_out && (ep->act == MPV_ACT_GELU_ERF || ep->act == MPV_ACT_GELU_TANH)), MPV_E_ARG,
+                "mpv_gemm_bf16: preact_deriv needs preact_out and a GELU activation");
+    g.preact_deriv = ep->preact_deriv ? 1 : 0;
     if (ep->dropout_p > 0.f) {
       MPV_REQUIRE(ep->dropout_p < 1.f, MPV_E_ARG, "mpv_gemm_bf16: dropout_p must be < 1");
       g.drop_thr = mpv_drop_threshold(ep->dropout_p);

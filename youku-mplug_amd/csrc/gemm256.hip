@@ -66,7 +66,7 @@ __device__ __forceinline__ bf16x8 lds_read_tr8(const char* p) {
 }
 
 
-enum EpKind { EP_PLAIN, EP_ERF_PRE, EP_TANH_PRE, EP_BWD_ERF, EP_BWD_TANH, EP_RES, EP_DROP_RES, EP_DROP, EP_GENERIC };
+enum EpKind { EP_PLAIN, EP_ERF_PRE, EP_TANH_PRE, EP_BWD_ERF, EP_BWD_TANH, EP_RES, EP_DROP_RES, EP_DROP, EP_GENERIC, EP_MUL };
 
 template <int ACT>
 __device__ __forceinline__ f32x8 apply_act(f32x8 v) {
@@ -82,6 +82,18 @@ __device__ __forceinline__ f32x8 apply_act(f32x8 v) {
     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
   }
   return v;
+}
+// act'(z) itself (the forward launch that parks it for the dgrad: mpv.h preact_deriv)
+template <int ACT>
+__device__ __forceinline__ f32x8 act_deriv(f32x8 z) {
+  f32x8 d;
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    const f32x2 r = mpv_gelu_grad_mul_t<ACT == MPV_ACT_GELU_ERF ? 1 : 2>(f32x2{1.0f, 1.0f}, f32x2{z[e], z[e + 1]});
+    d[e] = r[0];
+    d[e + 1] = r[1];
+  }
+  return d;
 }
 template <int ACT>
 __device__ __forceinline__ f32x8 apply_act_grad(f32x8 v, f32x8 z) {
@@ -107,7 +119,7 @@ __device__ __forceinline__ f32x8 apply_act_grad(f32x8 v, f32x8 z) {
 // NIT = 16-byte chunks per thread = tile rows / 16 (16 for the 256-row tile, 12 / 10 for the 192 / 160-row variants)
 template <int KIND, int NIT>
 struct EpExt {
-  static constexpr bool EXT = KIND == EP_BWD_ERF || KIND == EP_BWD_TANH || KIND == EP_RES || KIND == EP_DROP_RES;
+  static constexpr bool EXT = KIND == EP_BWD_ERF || KIND == EP_BWD_TANH || KIND == EP_RES || KIND == EP_DROP_RES || KIND == EP_MUL;
   bf16x8 v[EXT ? NIT : 1];
 };
 template <int KIND, int NIT>
@@ -119,7 +131,7 @@ __device__ __forceinline__ void prefetch_rows(const GemmArgs& p, EpExt<KIND, NIT
       const int m = m0 + (c >> 5), n = n0 + (c & 31) * 8;
       x.v[it] = bf16x8{};
       if (m < p.M && n < p.N) {
-        if constexpr (KIND == EP_BWD_ERF || KIND == EP_BWD_TANH) x.v[it] = *(const bf16x8*)(p.actz + (long long)m * p.ldz + n);
+        if constexpr (KIND == EP_BWD_ERF || KIND == EP_BWD_TANH || KIND == EP_MUL) x.v[it] = *(const bf16x8*)(p.actz + (long long)m * p.ldz + n);
         else x.v[it] = *(const bf16x8*)(p.residual + map_row(p.cmap, m) * p.ldr + n);
       }
     }
@@ -153,10 +165,34 @@ __device__ __forceinline__ void finish_rows(const GemmArgs& p, const EpExt<KIND,
       if constexpr (KIND == EP_PLAIN) {
         *(bf16x8*)cp = zb;
       } else if constexpr (KIND == EP_ERF_PRE || KIND == EP_TANH_PRE) {
-        *(bf16x8*)(p.preact + crow * p.ldc + n) = zb;
-        *(bf16x8*)cp = cvt8(apply_act<KIND == EP_ERF_PRE ? MPV_ACT_GELU_ERF : MPV_ACT_GELU_TANH>(cvt8(zb)));
+        constexpr int A = KIND == EP_ERF_PRE ? MPV_ACT_GELU_ERF : MPV_ACT_GELU_TANH;
+        // preact_deriv: the second output is act'(z) for the dgrad to multiply by (one wave-uniform branch per 8-element chunk);
+        // this epilogue is bound by its two stores, the extra polynomial rides in its idle VALU slots
+        if (p.preact_deriv) {
+          if constexpr (A == MPV_ACT_GELU_TANH) {      // both from one polynomial (mpv_gelu_tanh_both_t)
+            const f32x8 zf = cvt8(zb);
+            f32x8 gv, dv;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+              f32x2 g2, d2;
+              mpv_gelu_tanh_both_t(f32x2{zf[e], zf[e + 1]}, g2, d2);
+              gv[e] = g2[0]; gv[e + 1] = g2[1];
+              dv[e] = d2[0]; dv[e + 1] = d2[1];
+            }
+            *(bf16x8*)(p.preact + crow * p.ldc + n) = cvt8(dv);
+            *(bf16x8*)cp = cvt8(gv);
+          } else {
+            *(bf16x8*)(p.preact + crow * p.ldc + n) = cvt8(act_deriv<A>(cvt8(zb)));
+            *(bf16x8*)cp = cvt8(apply_act<A>(cvt8(zb)));
+          }
+        } else {
+          *(bf16x8*)(p.preact + crow * p.ldc + n) = zb;
+          *(bf16x8*)cp = cvt8(apply_act<A>(cvt8(zb)));
+        }
       } else if constexpr (KIND == EP_BWD_ERF || KIND == EP_BWD_TANH) {
         *(bf16x8*)cp = cvt8(apply_act_grad<KIND == EP_BWD_ERF ? MPV_ACT_GELU_ERF : MPV_ACT_GELU_TANH>(cvt8(zb), cvt8(ex)));
+      } else if constexpr (KIND == EP_MUL) {          // act_bwd == MPV_ACT_DERIV: ex holds act'(z)
+        *(bf16x8*)cp = cvt8(cvt8(zb) * cvt8(ex));
       } else if constexpr (KIND == EP_RES) {
         if (p.tap_out && m % p.tap_group == 0) *(bf16x8*)(p.tap_out + (long long)(m / p.tap_group) * p.N + n) = zb;
         *(bf16x8*)cp = cvt8(cvt8(zb) + cvt8(ex));
@@ -171,13 +207,17 @@ __device__ __forceinline__ void finish_rows(const GemmArgs& p, const EpExt<KIND,
         f32x8 v = cvt8(zb);
         if (p.tap_out && m % p.tap_group == 0) *(bf16x8*)(p.tap_out + (long long)(m / p.tap_group) * p.N + n) = zb;
         if (p.act) {
-          if (p.preact) *(bf16x8*)(p.preact + crow * p.ldc + n) = zb;
+          if (p.preact) {
+            if (p.preact_deriv) *(bf16x8*)(p.preact + crow * p.ldc + n) = cvt8(p.act == MPV_ACT_GELU_ERF ? act_deriv<MPV_ACT_GELU_ERF>(v) : act_deriv<MPV_ACT_GELU_TANH>(v));
+            else *(bf16x8*)(p.preact + crow * p.ldc + n) = zb;
+          }
           v = p.act == MPV_ACT_GELU_ERF ? apply_act<MPV_ACT_GELU_ERF>(v) : p.act == MPV_ACT_GELU_TANH ? apply_act<MPV_ACT_GELU_TANH>(v) : apply_act<MPV_ACT_RELU>(v);
         }
         if (p.act_bwd) {
           const f32x8 z = cvt8(*(const bf16x8*)(p.actz + (long long)m * p.ldz + n));
           v = p.act_bwd == MPV_ACT_GELU_ERF ? apply_act_grad<MPV_ACT_GELU_ERF>(v, z)
-              : p.act_bwd == MPV_ACT_GELU_TANH ? apply_act_grad<MPV_ACT_GELU_TANH>(v, z) : apply_act_grad<MPV_ACT_RELU>(v, z);
+              : p.act_bwd == MPV_ACT_GELU_TANH ? apply_act_grad<MPV_ACT_GELU_TANH>(v, z)
+              : p.act_bwd == MPV_ACT_DERIV ? v * z : apply_act_grad<MPV_ACT_RELU>(v, z);
         }
         if (p.drop_thr) {
           const uint64_t base = p.drop_offset + (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
@@ -598,6 +638,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   else if (cfg == (1 | 32) && p.act == MPV_ACT_GELU_TANH) epilogue(IC<EP_TANH_PRE>{});
   else if (cfg == 2 && p.act_bwd == MPV_ACT_GELU_ERF) epilogue(IC<EP_BWD_ERF>{});
   else if (cfg == 2 && p.act_bwd == MPV_ACT_GELU_TANH) epilogue(IC<EP_BWD_TANH>{});
+  else if (cfg == 2 && p.act_bwd == MPV_ACT_DERIV) epilogue(IC<EP_MUL>{});
   else if (cfg == 8) epilogue(IC<EP_RES>{});
   else if (cfg == (4 | 8)) epilogue(IC<EP_DROP_RES>{});
   else if (cfg == 4) epilogue(IC<EP_DROP>{});

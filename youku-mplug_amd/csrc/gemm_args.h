@@ -19,6 +19,7 @@ struct GemmArgs {
   const bf16* actz;
   long long ldz;
   int act_bwd;
+  int preact_deriv;     // preact receives act'(z) instead of z (mpv.h: preact_deriv / MPV_ACT_DERIV)
   float drop_scale;
   uint32_t drop_thr;
   uint64_t seed, drop_offset;

@@ -216,6 +216,20 @@ __device__ __forceinline__ T mpv_gelu_grad_mul_t(T dy, T x) {
   const T xc = mpv_clamp_t(x);
   return mpv_fma_t(dy * xc, mpv_gelu_grad_poly<KIND>(xc * xc), dy * mpv_splat<T>(0.5f));
 }
+// tanh GELU and its derivative from ONE evaluation of the odd polynomial: with s = tanh(u) / 2 (u = 0.79788456 x (1 + 0.044715 x^2)),
+// GELU = x~ (1/2 + s) and GELU' = 1/2 + s + x/2 (1 - 4 s^2)(0.79788456 + 0.1070322243 x^2) -- four more packed FMAs instead of
+// the second degree-8 polynomial (the forward epilogue that parks GELU' for the dgrad: preact_deriv).  Same clamp as both.
+template <typename T>
+__device__ __forceinline__ void mpv_gelu_tanh_both_t(T x, T& gelu, T& deriv) {
+  const T xc = mpv_clamp_t(x);
+  const T w = xc * xc;
+  const T s = xc * mpv_gelu_cdf_poly<2>(w);
+  const T xe = mpv_tail_t(x);
+  gelu = mpv_fma_t(xe, s, xe * mpv_splat<T>(0.5f));
+  const T sech2h = mpv_fma_t(s * mpv_splat<T>(-2.0f), s, mpv_splat<T>(0.5f));                       // (1 - 4 s^2) / 2
+  const T du = mpv_fma_t(w, mpv_splat<T>(0.1070322243f), mpv_splat<T>(0.79788456f));                // u'(x)
+  deriv = mpv_fma_t(xc * sech2h, du, s + mpv_splat<T>(0.5f));
+}
 __device__ __forceinline__ float gelu_erf_f(float x) { return mpv_gelu_t<1>(x); }
 __device__ __forceinline__ float gelu_erf_grad_f(float x) { return mpv_gelu_grad_mul_t<1>(1.0f, x); }
 __device__ __forceinline__ float gelu_tanh_f(float x) { return mpv_gelu_t<2>(x); }

@@ -89,7 +89,7 @@ class EvaVisionTransformer(nn.Module):
             l2, s["m2"], s["r2"] = ops.layernorm_fwd(y, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, R, D)
             hid = blk.mlp.fc1.out_features
             z = torch.empty((R, hid), dtype=torch.bfloat16, device=x.device)
-            h1 = ops.gemm(l2, blk.mlp.fc1.weight, R, hid, D, bias=blk.mlp.fc1.bias, act=ACT_GELU_ERF, preact_out=z)
+            h1 = ops.gemm(l2, blk.mlp.fc1.weight, R, hid, D, bias=blk.mlp.fc1.bias, act=ACT_GELU_ERF, preact_out=z, preact_deriv=True)
             out = ops.gemm(h1, blk.mlp.fc2.weight, R, D, hid, bias=blk.mlp.fc2.bias, residual=y)           # :173
             s.update(x=x, l1=l1, qkv=qkv, a=a, lse=lse, y=y, l2=l2, z=z, h1=h1)
             blocks.append(s)
@@ -111,7 +111,7 @@ class EvaVisionTransformer(nn.Module):
             blk, s = self.blocks[bi], tape["blocks"][bi]
             hid = blk.mlp.fc1.out_features
             ops.gemm(dx, s["h1"], D, hid, R, trans_a=True, trans_b=True, out=grad_of(blk.mlp.fc2.weight), colsum_out=grad_of(blk.mlp.fc2.bias))
-            dz = ops.gemm(dx, blk.mlp.fc2.weight, R, hid, D, trans_b=True, act_bwd_z=s["z"], act_bwd=ACT_GELU_ERF)
+            dz = ops.gemm(dx, blk.mlp.fc2.weight, R, hid, D, trans_b=True, act_bwd_z=s["z"], act_bwd=ACT_GELU_ERF, z_is_deriv=True)
             ops.gemm(dz, s["l2"], hid, D, R, trans_a=True, trans_b=True, out=grad_of(blk.mlp.fc1.weight), colsum_out=grad_of(blk.mlp.fc1.bias))
             dl2 = ops.gemm(dz, blk.mlp.fc1.weight, R, D, hid, trans_b=True)
             dy = ops.layernorm_bwd(dl2, s["y"], blk.norm2.weight, s["m2"], s["r2"], R, D, dres=dx,

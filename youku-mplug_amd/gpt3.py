@@ -260,7 +260,7 @@ class DistributedGPT3(nn.Module):
                 x2, h1, m2, r2 = ops.ln_stream_fwd(stream, a1, l2.weight, l2.bias, l2.eps, Rl, H, hmap=tm, h_rows=R)
                 F4 = mlp.dense_h_to_4h.out_features
                 z = torch.empty((Rl, F4), dtype=torch.bfloat16, device=h.device)
-                g = ops.gemm(x2, mlp.dense_h_to_4h.weight, Rl, F4, H, bias=mlp.dense_h_to_4h.bias, act=ACT_GELU_TANH, preact_out=z)
+                g = ops.gemm(x2, mlp.dense_h_to_4h.weight, Rl, F4, H, bias=mlp.dense_h_to_4h.bias, act=ACT_GELU_TANH, preact_out=z, preact_deriv=True)
                 pending = ops.gemm(g, mlp.dense_4h_to_h.weight, Rl, H, F4, bias=mlp.dense_4h_to_h.bias, dropout_p=p_h, seed=seed,
                                    offset=_offset(ln, _SITE_DROP2))                                # compact [Rl, H]
                 ent = dict(h=h_in, s1=(m1, r1), qkv=qkv, ctx=ctx, lse=lse, h1=h1, s2=(m2, r2), z=z)
@@ -341,7 +341,7 @@ class DistributedGPT3(nn.Module):
                                                layer.post_attention_layernorm.eps, Rw, H, xmap=tm)
                 F4 = mlp.dense_h_to_4h.out_features
                 z = torch.empty((Rw, F4), dtype=torch.bfloat16, device=h.device)
-                g = ops.gemm(x2, mlp.dense_h_to_4h.weight, Rw, F4, H, bias=mlp.dense_h_to_4h.bias, act=ACT_GELU_TANH, preact_out=z)
+                g = ops.gemm(x2, mlp.dense_h_to_4h.weight, Rw, F4, H, bias=mlp.dense_h_to_4h.bias, act=ACT_GELU_TANH, preact_out=z, preact_deriv=True)
                 h2 = torch.empty((R, H), dtype=torch.bfloat16, device=h.device)
                 ops.gemm(g, mlp.dense_4h_to_h.weight, Rw, H, F4, bias=mlp.dense_4h_to_h.bias, residual=h1, dropout_p=p_h,
                          seed=seed, offset=_offset(ln, _SITE_DROP2), cmap=tm, out=h2)
@@ -354,7 +354,7 @@ class DistributedGPT3(nn.Module):
                                            layer.post_attention_layernorm.eps, R, H)
             F4 = mlp.dense_h_to_4h.out_features
             z = torch.empty((R, F4), dtype=torch.bfloat16, device=h.device)
-            g = ops.gemm(x2, mlp.dense_h_to_4h.weight, R, F4, H, bias=mlp.dense_h_to_4h.bias, act=ACT_GELU_TANH, preact_out=z)
+            g = ops.gemm(x2, mlp.dense_h_to_4h.weight, R, F4, H, bias=mlp.dense_h_to_4h.bias, act=ACT_GELU_TANH, preact_out=z, preact_deriv=True)
             h2 = ops.gemm(g, mlp.dense_4h_to_h.weight, R, H, F4, bias=mlp.dense_4h_to_h.bias, residual=h1, dropout_p=p_h,
                           seed=seed, offset=_offset(ln, _SITE_DROP2))
             ent = dict(h=h, s1=(m1, r1), qkv=qkv, ctx=ctx, lse=lse, h1=h1, s2=(m2, r2), z=z)
@@ -465,7 +465,7 @@ class DistributedGPT3(nn.Module):
                 # gradients of the other rows are exact zeros (dh1 feeds LN1's residual gradient, dctx the attention backward)
                 rm = s["rows"]
                 Rw = B * rm[0]
-                dz = self._dgrad(do, mlp.dense_4h_to_h.weight, Rw, F4, H, act_bwd_z=s["z"], act_bwd=ACT_GELU_TANH, amap=rm)
+                dz = self._dgrad(do, mlp.dense_4h_to_h.weight, Rw, F4, H, act_bwd_z=s["z"], act_bwd=ACT_GELU_TANH, z_is_deriv=True, amap=rm)
                 dx2 = self._dgrad(dz, mlp.dense_h_to_4h.weight, Rw, H, F4)
                 # the rows outside the window stay exact zeros: two buffers cleared once and kept across steps (only window rows
                 # are ever written), instead of two activation-sized clears per step
@@ -476,7 +476,7 @@ class DistributedGPT3(nn.Module):
                 da = dh1_m if drop else dh1
                 self._dgrad(da, att.dense.weight, Rw, H, H, amap=rm, cmap=rm, out=dctx)
             else:
-                dz = self._dgrad(do, mlp.dense_4h_to_h.weight, R, F4, H, act_bwd_z=s["z"], act_bwd=ACT_GELU_TANH)
+                dz = self._dgrad(do, mlp.dense_4h_to_h.weight, R, F4, H, act_bwd_z=s["z"], act_bwd=ACT_GELU_TANH, z_is_deriv=True)
                 if td:      # dense_4h_to_h: dW = do^T gelu(z), db = colsum(do); dense_h_to_4h: dW = dz^T x2, db = colsum(dz)
                     ops.gemm(do, s["g"], H, F4, R, trans_a=True, trans_b=True, out=grad_of(mlp.dense_4h_to_h.weight))
                     ops.colsum(do, R, H, out=grad_of(mlp.dense_4h_to_h.bias))

@@ -7,12 +7,17 @@ from __future__ import annotations
 import ctypes as C
 from typing import Optional, Tuple
 
+import os
+
 import torch
 
 from . import _lib
 from ._lib import AttnDesc, GemmEpilogue, check
 
-ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_RELU = 0, 1, 2, 3
+ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_RELU, ACT_DERIV = 0, 1, 2, 3, 4
+# MPV_GELU_DERIV=0 (measurement knob): the MLPs park the pre-activation z and the dgrad epilogue evaluates GELU'(z), as until round 3.
+# Default: the forward epilogue parks GELU'(z) itself and the dgrad epilogue is one multiply (include/mpv.h: preact_deriv, MPV_ACT_DERIV).
+GELU_DERIV_FWD = os.environ.get("MPV_GELU_DERIV", "1") != "0"
 RowMap = Tuple[int, int, int]
 IDENT: RowMap = (0, 0, 0)
 
@@ -53,8 +58,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: Optio
          act_bwd_z=None, act_bwd: int = 0, ldz: int = 0, dropout_p: float = 0.0, seed: int = 0, offset: int = 0,
          alpha_dev=None, alpha: float = 0.0, amap: RowMap = IDENT, cmap: RowMap = IDENT, kmap: RowMap = IDENT,
          out_rows: Optional[int] = None, accumulate: bool = False, out_f32: bool = False, colsum_out=None,
-         tile_hint: int = 0, row_tap_out=None, row_tap_group: int = 0, split_hint: int = 0, gm_hint: int = 0) -> torch.Tensor:
-    """C[M,N] = epilogue(sum_k A(m,k) B(n,k)).  See include/mpv.h:mpv_gemm_bf16."""
+         tile_hint: int = 0, row_tap_out=None, row_tap_group: int = 0, split_hint: int = 0, gm_hint: int = 0,
+         preact_deriv: bool = False, z_is_deriv: bool = False) -> torch.Tensor:
+    """C[M,N] = epilogue(sum_k A(m,k) B(n,k)).  See include/mpv.h:mpv_gemm_bf16.
+    preact_deriv (forward of an MLP's first product): preact_out receives act'(z) instead of z; z_is_deriv (the matching dgrad):
+    act_bwd_z is that tensor, multiply by it.  A call-site PAIR: both follow the one knob GELU_DERIV_FWD."""
     global gemm_calls
     gemm_calls += 1
     _need_cuda(a, b)
@@ -89,6 +97,9 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: Optio
     ep.row_tap_group = row_tap_group
     ep.split_hint = split_hint
     ep.gm_hint = gm_hint
+    ep.preact_deriv = int(bool(preact_deriv and GELU_DERIV_FWD and preact_out is not None))
+    if z_is_deriv and GELU_DERIV_FWD and act_bwd_z is not None:
+        ep.act_bwd = ACT_DERIV
     ws, wsn = None, 0
     if not out_f32:
         wsn = _lib.lib().mpv_gemm_workspace_size(M, N, K, int(trans_a), int(trans_b))

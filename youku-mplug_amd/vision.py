@@ -369,7 +369,7 @@ class TimeSformer(nn.Module):
             l2, s["m2"], s["r2"] = ops.layernorm_fwd(y, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, R, D)
             hid = blk.mlp.fc1.out_features
             z = torch.empty((R, hid), dtype=torch.bfloat16, device=x.device)
-            h1 = ops.gemm(l2, blk.mlp.fc1.weight, R, hid, D, bias=blk.mlp.fc1.bias, act=ACT_GELU_ERF, preact_out=z)
+            h1 = ops.gemm(l2, blk.mlp.fc1.weight, R, hid, D, bias=blk.mlp.fc1.bias, act=ACT_GELU_ERF, preact_out=z, preact_deriv=True)
             out = ops.gemm(h1, blk.mlp.fc2.weight, R, D, hid, bias=blk.mlp.fc2.bias, residual=y)
             s.update(x=x, lt=lt, qkv_t=qkv_t, at=at, pt=pt, xt=xt, l1=l1, qkv_s=qkv_s, a_s=a_s, lse=lse, lay=lay, y=y, l2=l2,
                      z=z, h1=h1)
@@ -415,7 +415,7 @@ class TimeSformer(nn.Module):
             # ---- MLP
             wl(lambda: ops.gemm(dout, s["h1"], D, hid, R, trans_a=True, trans_b=True, out=grad_of(blk.mlp.fc2.weight),
                                 colsum_out=grad_of(blk.mlp.fc2.bias)), dout)
-            dz = ops.gemm(dout, blk.mlp.fc2.weight, R, hid, D, trans_b=True, act_bwd_z=s["z"], act_bwd=ACT_GELU_ERF)
+            dz = ops.gemm(dout, blk.mlp.fc2.weight, R, hid, D, trans_b=True, act_bwd_z=s["z"], act_bwd=ACT_GELU_ERF, z_is_deriv=True)
             wl(lambda: ops.gemm(dz, s["l2"], hid, D, R, trans_a=True, trans_b=True, out=grad_of(blk.mlp.fc1.weight),
                                 colsum_out=grad_of(blk.mlp.fc1.bias)), dz)
             dl2 = ops.gemm(dz, blk.mlp.fc1.weight, R, D, hid, trans_b=True)
@@ -557,7 +557,7 @@ class AttentionPool(nn.Module):
         l2, m2, r2 = ops.layernorm_fwd(x2, self.norm2.weight, self.norm2.bias, self.norm2.eps, B * Q, D)
         hid = self.mlp.fc1.out_features
         z = torch.empty((B * Q, hid), dtype=torch.bfloat16, device=emb.device)
-        h1 = ops.gemm(l2, self.mlp.fc1.weight, B * Q, hid, D, bias=self.mlp.fc1.bias, act=ACT_GELU_ERF, preact_out=z)
+        h1 = ops.gemm(l2, self.mlp.fc1.weight, B * Q, hid, D, bias=self.mlp.fc1.bias, act=ACT_GELU_ERF, preact_out=z, preact_deriv=True)
         out = ops.gemm(h1, self.mlp.fc2.weight, B * Q, D, hid, bias=self.mlp.fc2.bias, residual=x2)
         tape.update(B=B, S=S, Q=Q, xin=xin, x=x, s1=(m1, r1), emb=emb, kn=kn, sk=(mk, rk), q=q, kv=kv, o=o, lse=lse, lay=lay,
                     x2=x2, l2=l2, s2=(m2, r2), z=z, h1=h1)
@@ -571,7 +571,7 @@ class AttentionPool(nn.Module):
         a = self.attn
         R = B * Q
         ops.gemm(dout, tape["h1"], D, hid, R, trans_a=True, trans_b=True, out=grad_of(self.mlp.fc2.weight), colsum_out=grad_of(self.mlp.fc2.bias))
-        dz = ops.gemm(dout, self.mlp.fc2.weight, R, hid, D, trans_b=True, act_bwd_z=tape["z"], act_bwd=ACT_GELU_ERF)
+        dz = ops.gemm(dout, self.mlp.fc2.weight, R, hid, D, trans_b=True, act_bwd_z=tape["z"], act_bwd=ACT_GELU_ERF, z_is_deriv=True)
         ops.gemm(dz, tape["l2"], hid, D, R, trans_a=True, trans_b=True, out=grad_of(self.mlp.fc1.weight), colsum_out=grad_of(self.mlp.fc1.bias))
         dl2 = ops.gemm(dz, self.mlp.fc1.weight, R, D, hid, trans_b=True)
         lnb = self.__dict__.setdefault("_ln_batch", ops.LnDparamBatch())      # the three dgamma/dbeta reductions: one launch at the end
