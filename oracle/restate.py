@@ -137,9 +137,12 @@ def attention_pool(queries, k, sd, cfg: PathConfig, p="attn_pool."):
     return x + vit_mlp(ln_fp32(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps), sd, p + "mlp.")
 
 
-def gpt_layer(h, sd, p, layer_number, cfg: PathConfig, causal_mask):
+def gpt_layer(h, sd, p, layer_number, cfg: PathConfig, causal_mask, drop=None):
     """models/modeling_distributed_gpt3.py:1034-1078 (pre-LN layer) with :868-938 attention and
-    :734-817 core attention, eval mode (dropout off).  h [s,b,H]."""
+    :734-817 core attention.  h [s,b,H].  Dropout: off (eval mode) unless `drop` supplies the three multipliers of the
+    layer -- keep / (1 - p) or 0 per element, i.e. torch.nn.functional.dropout with the MASK GIVEN instead of drawn:
+    "attn" [b,np,s,s] on the softmax output (:779-782), "h1" [s,b,H] on attention-dense output + bias (:1059-1062,
+    bias_dropout_add), "h2" [s,b,H] on the MLP output + bias (:1075-1078)."""
     s, b, H = h.shape
     np_, hn = cfg.heads, cfg.head_dim
     x = ln_fp32(h, sd[p + "input_layernorm.weight"], sd[p + "input_layernorm.bias"], cfg.gpt_ln_eps)
@@ -155,26 +158,38 @@ def gpt_layer(h, sd, p, layer_number, cfg: PathConfig, causal_mask):
     scores = scores * layer_number                                                               # coeff, :727
     scores = scores.masked_fill(causal_mask, -10000.0)                                           # :684-686
     probs = torch.softmax(scores, dim=-1)
+    if drop is not None:
+        probs = probs * drop["attn"].to(probs.dtype)
     ctx = torch.bmm(probs.view(b * np_, s, s), v).view(b, np_, s, hn).permute(2, 0, 1, 3).reshape(s, b, H)
     att = F.linear(ctx, sd[p + "self_attention.dense.weight"])                                   # bias returned separately
-    h1 = h + (att + sd[p + "self_attention.dense.bias"])                                         # :1059-1062
+    a1 = att + sd[p + "self_attention.dense.bias"]
+    if drop is not None:
+        a1 = a1 * drop["h1"].to(a1.dtype)
+    h1 = h + a1                                                                                  # :1059-1062
     x2 = ln_fp32(h1, sd[p + "post_attention_layernorm.weight"], sd[p + "post_attention_layernorm.bias"],
                  cfg.gpt_ln_eps)
     inter = F.linear(x2, sd[p + "mlp.dense_h_to_4h.weight"])
     inter = gelu_tanh(inter + sd[p + "mlp.dense_h_to_4h.bias"])                                  # :586-588
     out = F.linear(inter, sd[p + "mlp.dense_4h_to_h.weight"])
-    return h1 + (out + sd[p + "mlp.dense_4h_to_h.bias"])                                         # :1075-1078
+    o2 = out + sd[p + "mlp.dense_4h_to_h.bias"]
+    if drop is not None:
+        o2 = o2 * drop["h2"].to(o2.dtype)
+    return h1 + o2                                                                               # :1075-1078
 
 
 def gpt_forward(input_embeds, labels, loss_mask, sd, cfg: PathConfig,
-                p="text_decoder.dist_model.language_model."):
-    """models/modeling_distributed_gpt3.py:1309-1366 + :1589-1618.  input_embeds [B,S,H]."""
+                p="text_decoder.dist_model.language_model.", drop=None):
+    """models/modeling_distributed_gpt3.py:1309-1366 + :1589-1618.  input_embeds [B,S,H].  drop (train mode with GIVEN masks):
+    {"embed": [B,S,H] multiplier of the embedding dropout (:665), "layers": [gpt_layer's dict per layer]}."""
     B, S, H = input_embeds.shape
     pos = sd[p + "embedding.position_embeddings.weight"][:S]                                     # :1294-1296,649
-    h = (input_embeds + pos[None]).transpose(0, 1).contiguous()                                  # :650-653
+    e = input_embeds + pos[None]
+    if drop is not None:
+        e = e * drop["embed"].to(e.dtype)
+    h = e.transpose(0, 1).contiguous()                                                           # :650-653
     causal = torch.tril(torch.ones(1, 1, S, S)) < 0.5                                            # :1288-1292
     for i in range(cfg.layers):
-        h = gpt_layer(h, sd, f"{p}encoder.layers.{i}.", i + 1, cfg, causal)
+        h = gpt_layer(h, sd, f"{p}encoder.layers.{i}.", i + 1, cfg, causal, None if drop is None else drop["layers"][i])
     h = ln_fp32(h, sd[p + "encoder.final_layernorm.weight"], sd[p + "encoder.final_layernorm.bias"],
                 cfg.gpt_ln_eps)                                                                  # :1184
     logits = F.linear(h, sd[p + "embedding.word_embeddings.weight"])                             # :1348-1350 (tied)
@@ -199,8 +214,9 @@ def visual_connect(image_query, sd):
     return qf
 
 
-def pretrain_forward(video, ids, attn_mask, sd, cfg: PathConfig):
-    """models/distributed_gpt3.py:130-166 (use_contrastive False)."""
+def pretrain_forward(video, ids, attn_mask, sd, cfg: PathConfig, drop=None):
+    """models/distributed_gpt3.py:130-166 (use_contrastive False).  drop: the decoder's dropout multipliers (gpt_forward) -- train
+    mode with given masks; the vision tower and the abstractor have no active dropout (drop_rate 0, clip-b16.json:9-10)."""
     B = video.shape[0]
     image_embeds = timesformer(video, sd, cfg)
     queries = sd["learnable_queries"].repeat(B, 1, 1)                                            # :134
@@ -212,7 +228,7 @@ def pretrain_forward(video, ids, attn_mask, sd, cfg: PathConfig):
     emb = F.embedding(ids, sd["text_decoder.dist_model.language_model.embedding.word_embeddings.weight"])
     input_embeds = torch.cat([query_features, emb], dim=1)                                       # :155-156
     loss_mask = torch.cat([torch.zeros(B, Q, dtype=torch.long), attn_mask[:, 1:]], dim=1)        # :145,159
-    out = gpt_forward(input_embeds, targets, loss_mask, sd, cfg)
+    out = gpt_forward(input_embeds, targets, loss_mask, sd, cfg, drop=drop)
     out.update(image_embeds=image_embeds, image_query=image_query, query_features=query_features,
                input_embeds=input_embeds)
     return out

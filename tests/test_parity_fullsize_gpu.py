@@ -106,6 +106,48 @@ def test_configB_full_depth_vs_oracle(dev):
                    hidden_gate=HIDDEN_GATE_B)
 
 
+def test_configB_train_mode_full_depth_vs_oracle_through_the_kernels_own_masks(dev):
+    """The BENCHMARKED mode at the benchmarked dims: configs[1] exactly, train() with live dropout and the loss window, B = 2.
+    The decoder's dropout masks of the step (24 layers x {attention probabilities, two bias-dropout-adds} + the embedding) are
+    recovered from the kernels (tests/test_model_gpu.py::recover_decoder_dropout) and handed to the fp32 restatement, which then
+    evaluates the SAME function the HIP step evaluated: loss and seven gradient tensors at the eval-mode gates."""
+    import test_model_gpu as tm
+    from oracle import restate
+    from oracle.weights import CONFIG_B, make_inputs, make_state_dict
+    from youku_mplug_amd.pretrain import synthetic_model
+    t0 = time.time()
+    cfg, B, L = CONFIG_B, 2, 32
+    model = synthetic_model(cfg, device=dev)
+    sd = make_state_dict(cfg, 11)
+    model.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+    model.train()
+    seed0 = 0x2468ACE
+    model.text_decoder.step_seed = seed0
+    video, ids, mask = make_inputs(cfg, B, L, seed=31, ragged=True)
+    text = types.SimpleNamespace(input_ids=ids.to(dev), attention_mask=mask.to(dev))
+    loss, _ = model(video.to(dev).to(torch.bfloat16), text)
+    loss.backward()
+    torch.cuda.synchronize()
+    drop = tm.recover_decoder_dropout(model, cfg, B, L, seed0, dev)
+    sdr = {k: v.bfloat16().float() for k, v in sd.items()}
+    del sd
+    for k in GRAD_KEYS:
+        sdr[k].requires_grad_(True)
+    ref = restate.pretrain_forward(video.bfloat16().float(), ids, mask, sdr, cfg, drop=drop)
+    ref["loss"].backward()
+    e_loss = abs(loss.item() - ref["loss"].item()) / abs(ref["loss"].item())
+    params = dict(model.named_parameters())
+    worst, worst_norm = (0.0, ""), (0.0, "")
+    for k in GRAD_KEYS:
+        g, r = params[k].grad.float().cpu(), sdr[k].grad
+        worst = max(worst, (rel(g, r), k))
+        worst_norm = max(worst_norm, (abs(g.norm().item() - r.norm().item()) / r.norm().item(), k))
+    report(f"config B, TRAIN mode (dropout live, loss window) through the kernels' own masks: B={B} L={L} layers={cfg.layers}\n"
+           f"    HIP vs fp32 oracle with the same masks: loss {e_loss:.3e} worst-grad {worst[0]:.3e} ({worst[1]}) worst-grad-norm {worst_norm[0]:.3e} ({worst_norm[1]})\n"
+           f"    gates: loss <= 5.0e-03, worst-grad <= 4.0e-02, worst-grad-norm <= 1.0e-02 | {time.time() - t0:.0f} s")
+    assert e_loss <= 5e-3 and worst[0] <= 4e-2 and worst_norm[0] <= 1e-2, (e_loss, worst, worst_norm)
+
+
 def test_yaml_geometry_full_depth_vs_oracle(dev):
     """The geometry the shipped YAML runs (configs/pretrain/gpt3_1.3B/pretrain_gpt3_freezeGPT_youku_v0.yaml: 4 frames, titles of up
     to 80 tokens -> S = 128 + 80 = 208: seven 32-row tiles per decoder attention problem instead of five), 1.3B dims, full depth,
