@@ -72,7 +72,13 @@ def test_streaming_kernels_keep_their_waves(kernels):
               "20ln_bwd8_plain_kernelILi4ELb0EE": 168, "20ln_bwd8_plain_kernelILi4ELb1EE": 168, "20ln_stream_fwd_kernelILi4E": 168, "20temporal_attn_kernelILb0ELi8ELi96EE": 128, "20temporal_attn_kernelILb1ELi8ELi96EE": 128,
               # 4 frames (the shipped pre-train YAML) and 16 (the retrieval recipe; LDS allows 7 / 5 waves per CU there, registers are not the limit)
               "20temporal_attn_kernelILb0ELi4ELi96EE": 128, "20temporal_attn_kernelILb1ELi4ELi96EE": 128,
-              "20temporal_attn_kernelILb0ELi16ELi96EE": 192, "20temporal_attn_kernelILb1ELi16ELi96EE": 192}
+              "20temporal_attn_kernelILb0ELi16ELi96EE": 192, "20temporal_attn_kernelILb1ELi16ELi96EE": 192,
+              # round 4: the bf16-row temporal attention (v_dot2c): same budgets as the fp32-row instances it replaces
+              "24temporal_attn_b16_kernelILb0ELi8ELi96EE": 128, "24temporal_attn_b16_kernelILb1ELi8ELi96EE": 128,
+              "24temporal_attn_b16_kernelILb0ELi4ELi96EE": 128, "24temporal_attn_b16_kernelILb1ELi4ELi96EE": 128,
+              "24temporal_attn_b16_kernelILb0ELi16ELi96EE": 192, "24temporal_attn_b16_kernelILb1ELi16ELi96EE": 192,
+              # the 16-wave weight-streaming instance: 1024 threads = 4 waves per SIMD
+              "19gemm_small_m_kernelILb1ELi16ELi8EE": 128}
     for prefix, lim in budget.items():
         for n, k in _sel(ks, prefix).items():
             assert k["scratch"] == 0 and k["vgpr"] <= lim, (n, k, lim)
@@ -143,3 +149,13 @@ def test_gemm256_uses_the_cdna4_instructions_it_is_designed_on(kernels):
     assert len(re.findall(r"buffer_load_dwordx4 .* lds", asm)) >= 9 * 8, "LDS-DMA ring fills"
     assert asm.count("ds_read_b64_tr_b16") >= 100, "transposing LDS reads of the dgrad / wgrad forms"
     assert "scratch_" not in asm
+
+
+def test_temporal_attention_runs_on_the_packed_bf16_dot(kernels):
+    """The bf16-row temporal attention exists because of v_dot2c_f32_bf16 (two MACs per instruction on bf16 pairs, fp32 accumulate):
+    the instruction must be in the code objects, 6 * T per (T, forward) instance at head_dim 96 (12 chunks of 8 x 4 dot2 / 8) ..."""
+    ks, _ = kernels
+    f = next(k["file"] for n, k in ks.items() if "temporal_attn_b16_kernelILb0ELi8ELi96EE" in n)
+    name = next(n for n in ks if "temporal_attn_b16_kernelILb0ELi8ELi96EE" in n)
+    dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--disassemble-symbols=" + name, f], capture_output=True, text=True).stdout
+    assert dis.count("v_dot2c_f32_bf16") + dis.count("v_dot2_f32_bf16") >= 48, "the bf16 dot product instruction is gone"

@@ -54,3 +54,35 @@ def test_zimage_layout_simulation():
     spec.loader.exec_module(mod)
     assert mod.check(160, verbose=False) and mod.check(224, verbose=False) and mod.check(32, verbose=False)
     assert mod.check_rot192(224, verbose=False)      # the head_dim-96 images of csrc/attention_duo.inc
+
+
+def test_rocpd_gaps_on_a_synthetic_trace(tmp_path, capsys):
+    """tools/rocpd_gaps.py (idle time between dispatches, by the kernel that follows the gap) on a hand-built rocpd table: three
+    steady-state steps after the first optimizer launch, a 3 us gap in front of every `b` kernel, one 400 us host pause that must not
+    count as a launch gap."""
+    import sqlite3
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import rocpd_gaps
+    db = str(tmp_path / "t.db")
+    c = sqlite3.connect(db)
+    c.execute("create table kernels (name text, start integer, end integer)")
+    t = 0
+    rows = [("adamw_first", t, t + 1000)]
+    t += 1000
+    for step in range(3):
+        for name, dur, gap in (("a", 10000, 0), ("b", 20000, 3000), ("a", 10000, 0), ("adamw_grouped_kernel", 5000, 0)):
+            t += gap
+            rows.append((name, t, t + dur))
+            t += dur
+        t += 400000 if step == 0 else 0
+    c.executemany("insert into kernels values (?, ?, ?)", rows)
+    c.commit()
+    c.close()
+    sys.argv = ["rocpd_gaps.py", db, str(tmp_path / "o.md")]
+    rocpd_gaps.main()
+    out = open(tmp_path / "o.md").read()
+    assert "12 dispatches over 3 steady-state steps" in out
+    assert "idle between dispatches 0.00 ms/step" in out or "idle between dispatches 0.003 ms/step" in out or "0.00 ms/step" in out
+    assert "| `b` | 3 | 0.01 | 3.00 |" in out, out
+    assert "pauses > 200 us (host bookkeeping between steps): 0.4 ms" in out, out

@@ -41,6 +41,11 @@ def main():
     print(f"prefill ({Q}+{P} positions x {beam} beams): {steps[0]*1e3:.2f} ms")
     print(f"decode: {len(dec)} steps, {sum(dec)/len(dec)*1e3:.3f} ms/step (kernel path only), end-to-end {tot/len(steps)*1e3:.3f} ms/step incl. host search")
     print(f"weights streamed per step {wbytes/1e9:.2f} GB -> {wbytes/(sum(dec)/len(dec))/1e12:.2f} TB/s of 8 TB/s HBM peak; {beam/(tot/len(steps)):.0f} beam-tokens/s")
+    import json
+    print(json.dumps({"metric": "decode step (kernel path), GPT3-1.3B, beam 5, 256-query prefix", "ms_per_step": round(sum(dec) / len(dec) * 1e3, 3),
+                      "end_to_end_ms_per_step": round(tot / len(steps) * 1e3, 3),
+                      "roofline": {"bound": "hbm", "achieved": round(wbytes / (sum(dec) / len(dec)) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                   "frac": round(wbytes / (sum(dec) / len(dec)) / 8e12, 4), "algorithmic_bytes_per_step": int(wbytes)}}))
 
 
 if __name__ == "__main__":

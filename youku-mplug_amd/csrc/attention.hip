@@ -1551,15 +1551,30 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
   }
   const float sc = p.scale_q_bf16 ? 1.0f : p.scale;
   const bf16x8 zero8 = cvt8(f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
-  // ---- scores
+  // ---- scores.  The V rows of the first NPF chunks (NPF * 256 keys at head_dim 64: a caption's whole context) are requested in
+  // the same breath as their K rows (round 4): the step is a chain of dependent round trips -- q, K, [softmax], V, store -- and the
+  // V trip ran after the softmax's two workgroup barriers; now it flies under them.
+  constexpr int NPF = 2;
+  bf16x8 vpre[NPF][UN];
   float mx = -INFINITY;
   for (int j0 = 0; j0 < p.sk; j0 += UN * KPI) {
     bf16x8 kv[UN];
+    const int chunk = j0 / (UN * KPI);
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const int j = j0 + u * KPI + kg;
       kv[u] = (cok && j < p.sk) ? *(const bf16x8*)(kb + (long long)j * p.k_rs) : zero8;
     }
+    // (after the K rows: the counted wait for K then leaves these in flight)
+#pragma unroll
+    for (int c = 0; c < NPF; ++c)
+      if (c == chunk) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const int j = j0 + u * KPI + kg;
+          vpre[c][u] = (cok && j < p.sk) ? *(const bf16x8*)(vb + (long long)j * p.v_rs) : zero8;
+        }
+      }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const f32x8 kf = cvt8(kv[u]);
@@ -1595,11 +1610,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
   for (int j0 = 0; j0 < p.sk; j0 += UN * KPI) {
     bf16x8 vv[UN];
     float pj[UN];
+    const int chunk = j0 / (UN * KPI);
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const int j = j0 + u * KPI + kg;
       const bool ok = cok && j < p.sk;
-      vv[u] = ok ? *(const bf16x8*)(vb + (long long)j * p.v_rs) : zero8;
+      if (chunk == 0) vv[u] = vpre[0][u];
+      else if (chunk == 1) vv[u] = vpre[1][u];
+      else vv[u] = ok ? *(const bf16x8*)(vb + (long long)j * p.v_rs) : zero8;
       pj[u] = ok ? ps[j] : 0.f;
     }
 #pragma unroll

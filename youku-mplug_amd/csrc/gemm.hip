@@ -526,16 +526,21 @@ struct SmallMArgs {
   int act;
 };
 
-template <bool FULL>   // FULL: N % 16 == 0 and K % 64 == 0 -> branch-free main loop (unrolled 8x: 16 weight loads in flight per lane)
-__global__ __launch_bounds__(256) void gemm_small_m_kernel(const SmallMArgs p) {
-  __shared__ float part[4][16][17];
+// NW = waves per workgroup that split K (round 4).  With 4 waves a lane of the K = 8192 product (4h -> h of the decoder MLP: N = 2048,
+// so only 128 workgroups) walked 32 K-blocks = four dependent batches of 16 loads; with 16 waves every lane has its whole share in
+// flight at once (one batch) and the 128 workgroups put 8 waves on a CU instead of 2.
+// COLS = output columns per workgroup: 16, or 8 where N / 16 workgroups would leave CUs idle (N = 2048: 128 workgroups on 256 CUs; the
+// weight rows 8..15 of the MFMA operand are then masked lanes -- no traffic, the matrix pipe is nowhere near a limit here).
+template <bool FULL, int NW = 4, int COLS = 16>   // FULL: N % 16 == 0 and K % 64 == 0 -> branch-free main loop (unrolled 8x: 16 weight loads in flight per lane)
+__global__ __launch_bounds__(64 * NW) void gemm_small_m_kernel(const SmallMArgs p) {
+  __shared__ float part[NW][16][17];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.x * 16;
+  const int n0 = blockIdx.x * COLS;
   const int r = lane & 15, g = lane >> 4;                       // operand row (n for W, m for A), 16-wide k group
   const int kblocks = (p.K + 63) >> 6;
-  const int per = (kblocks + 3) >> 2;
+  const int per = (kblocks + NW - 1) / NW;
   const int kb0 = wave * per, kb1 = min(kblocks, kb0 + per);
-  const bool wok = (n0 + r) < p.N, aok = r < p.M;
+  const bool wok = r < COLS && (n0 + r) < p.N, aok = r < p.M;
   const bf16* wrow = p.W + (long long)(wok ? n0 + r : 0) * p.ldw + g * 16;
   const bf16* arow = p.A + (long long)(aok ? r : 0) * p.lda + g * 16;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -543,28 +548,29 @@ __global__ __launch_bounds__(256) void gemm_small_m_kernel(const SmallMArgs p) {
   union Frag { i32x4 i; bf16x8 b; };
   if constexpr (FULL) {
     int kb = kb0;
-    for (; kb + 8 <= kb1; kb += 8) {
-      Frag w0[8], w1[8], a0[8], a1[8];
+    constexpr int UN = NW > 4 ? 4 : 8;      // (16 waves: 128 VGPRs per wave -- four K-blocks = 8 weight + 8 activation chunks per batch)
+    for (; kb + UN <= kb1; kb += UN) {
+      Frag w0[UN], w1[UN], a0[UN], a1[UN];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        w0[u].i = *(const i32x4*)(wrow + (kb + u) * 64);
-        w1[u].i = *(const i32x4*)(wrow + (kb + u) * 64 + 8);
+      for (int u = 0; u < UN; ++u) {
+        w0[u].i = (COLS == 16 || wok) ? *(const i32x4*)(wrow + (kb + u) * 64) : zero;
+        w1[u].i = (COLS == 16 || wok) ? *(const i32x4*)(wrow + (kb + u) * 64 + 8) : zero;
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < UN; ++u) {
         a0[u].i = aok ? *(const i32x4*)(arow + (kb + u) * 64) : zero;
         a1[u].i = aok ? *(const i32x4*)(arow + (kb + u) * 64 + 8) : zero;
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < UN; ++u) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[u].b, w0[u].b, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[u].b, w1[u].b, acc, 0, 0, 0);
       }
     }
     for (; kb < kb1; ++kb) {
       Frag w0, w1, a0, a1;
-      w0.i = *(const i32x4*)(wrow + kb * 64);
-      w1.i = *(const i32x4*)(wrow + kb * 64 + 8);
+      w0.i = (COLS == 16 || wok) ? *(const i32x4*)(wrow + kb * 64) : zero;
+      w1.i = (COLS == 16 || wok) ? *(const i32x4*)(wrow + kb * 64 + 8) : zero;
       a0.i = aok ? *(const i32x4*)(arow + kb * 64) : zero;
       a1.i = aok ? *(const i32x4*)(arow + kb * 64 + 8) : zero;
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0.b, w0.b, acc, 0, 0, 0);
@@ -588,8 +594,11 @@ __global__ __launch_bounds__(256) void gemm_small_m_kernel(const SmallMArgs p) {
   for (int i = 0; i < 4; ++i) part[wave][4 * g + i][r] = acc[i];
   __syncthreads();
   const int m = tid >> 4, n = n0 + (tid & 15);
-  if (m < p.M && n < p.N) {
+  if (tid < 256 && (tid & 15) < COLS && m < p.M && n < p.N) {
     float v = (part[0][m][tid & 15] + part[1][m][tid & 15]) + (part[2][m][tid & 15] + part[3][m][tid & 15]);
+#pragma unroll
+    for (int w = 4; w < NW; w += 4)
+      v += (part[w][m][tid & 15] + part[w + 1][m][tid & 15]) + (part[w + 2][m][tid & 15] + part[w + 3][m][tid & 15]);
     if (p.bias) v += bf2f(p.bias[n]);
     if (p.act) {
       const float z = bf2f(f2bf(v));
@@ -740,7 +749,11 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
     sm.M = (int)M; sm.N = (int)N; sm.K = (int)K;
     sm.lda = lda; sm.ldw = ldb; sm.ldc = ldc; sm.ldr = g.ldr;
     sm.cmap = g.cmap; sm.bias = g.bias; sm.residual = g.residual; sm.act = g.act;
-    if (N % 16 == 0 && K % 64 == 0)
+    if (N % 16 == 0 && K % 64 == 0 && K >= 4096 && N / 16 <= 256)        // long reduction, few workgroups: 16 waves split K, 8 columns each
+      hipLaunchKernelGGL((gemm_small_m_kernel<true, 16, 8>), dim3((unsigned)(N / 8)), dim3(1024), 0, stream, sm);
+    else if (N % 16 == 0 && K % 64 == 0 && N / 16 <= 384)                  // workgroup counts that leave CUs idle or 2 : 1 unbalanced (N = 2048: 128, N = 6144: 384 on 256 CUs): 8 columns each
+      hipLaunchKernelGGL((gemm_small_m_kernel<true, 4, 8>), dim3((unsigned)(N / 8)), dim3(256), 0, stream, sm);
+    else if (N % 16 == 0 && K % 64 == 0)
       hipLaunchKernelGGL(gemm_small_m_kernel<true>, dim3((unsigned)(N / 16)), dim3(256), 0, stream, sm);
     else
       hipLaunchKernelGGL(gemm_small_m_kernel<false>, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, stream, sm);
