@@ -301,3 +301,25 @@ def test_gemm_gelu_derivative_parked_by_the_forward(dev, hint):
             assert rel_err(g_new, g_ref) <= 6e-3
         else:
             assert torch.equal(d, z)
+
+
+@pytest.mark.parametrize("M,N,K", [(2560, 2560, 10240), (1024, 2048, 8192), (512, 2560, 10240)])
+def test_gemm256_split_forward_with_bias_and_dropout_in_the_reduce(dev, M, N, K):
+    """Few output tiles, long reduction (the decoder's 4h -> h product at 2.7B dims: 100 tiles on 256 CUs): the forward product is split
+    along K like a weight gradient and -- round 4 -- its bias / bias + dropout epilogue moves into the reduce kernel.  Against the
+    unsplit 128x128 kernel: the SAME dropout mask (a function of seed / offset / element index only), values within the summation
+    order; against fp32 for the bias form."""
+    from youku_mplug_amd import ops
+    a, w, bias = rn(M, K, dev=dev, seed=131), rn(N, K, dev=dev, seed=132, scale=0.05), rn(N, dev=dev, seed=133)
+    ref = a.float() @ w.float().t() + bias.float()
+    o = ops.gemm(a, w, M, N, K, bias=bias)
+    close(o, ref, 1e-2, "split forward + bias")
+    kw = dict(bias=bias, dropout_p=0.1, seed=77, offset=5 << 36)
+    d_new = ops.gemm(a, w, M, N, K, **kw)
+    d_128 = ops.gemm(a, w, M, N, K, tile_hint=128, **kw)
+    assert torch.equal(d_new == 0, d_128 == 0) or ((d_new == 0) != (d_128 == 0)).float().mean().item() < 1e-5, "dropout masks differ"
+    kept = d_new != 0
+    assert abs(kept.float().mean().item() - 0.9) < 0.01
+    close(d_new[kept], (ref / 0.9)[kept], 1e-2, "split forward + bias + dropout")
+    for _ in range(5):
+        assert torch.equal(d_new, ops.gemm(a, w, M, N, K, **kw))

@@ -468,8 +468,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
 
 // sum split-K fp32 partials -> bf16 (optionally accumulating into the existing bf16 value); the trailing workgroups of
 // the same launch finish the fused bias gradient (column sums of dY over the K splits)
+// Epilogue of a split forward product (round 4: the decoder's 4h -> h product at 2.7B dims is 100 tiles on 256 CUs; its plain form was
+// split along K, its bias + dropout form could not be -- 162 against 117 us): bias (bf16 [N], N = row length of the [M, N] output) and
+// dropout on bf16(sum + bias), element index drop_offset + i, exactly as the unsplit epilogue orders them (gemm256.hip EP_DROP).
+struct ReduceEpi {
+  const bf16* bias;
+  int N;
+  uint32_t drop_thr;
+  float drop_scale;
+  uint64_t seed, drop_offset;
+};
 __global__ void splitk_reduce_kernel(const float* part, bf16* out, long long MN, int splits, int accumulate, int mn_blocks,
-                                     const float* colsum_part, bf16* colsum_out, int M) {
+                                     const float* colsum_part, bf16* colsum_out, int M, const ReduceEpi epi) {
   if ((int)blockIdx.x >= mn_blocks) {
     const int m = ((int)blockIdx.x - mn_blocks) * blockDim.x + threadIdx.x;
     if (m >= M) return;
@@ -493,6 +503,11 @@ __global__ void splitk_reduce_kernel(const float* part, bf16* out, long long MN,
     s += d;
   }
   for (; z < splits; ++z) s += *(const f32x4*)(part + (long long)z * MN + i);
+  if (epi.bias) s += cvt4(*(const bf16x4*)(epi.bias + (int)(i % epi.N)));       // N % 4 == 0: the four elements share a row
+  if (epi.drop_thr) {
+    s = cvt4(cvt4(s));                                                            // the unsplit epilogue drops bf16(acc + bias)
+    s = mpv_dropout_vec<f32x4, 4>(s, mpv_resolve_seed(epi.seed), epi.drop_offset + (uint64_t)i, epi.drop_thr, epi.drop_scale);
+  }
   if (accumulate) s += cvt4(*(const bf16x4*)(out + i));
   *(bf16x4*)(out + i) = cvt4(s);
 }
@@ -792,9 +807,10 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
       if (ep && ep->split_hint > 0 && K / ep->split_hint >= 64 &&
           (size_t)M * N * sizeof(float) * ep->split_hint + (size_t)ep->split_hint * M * sizeof(float) <= (workspace ? workspace_bytes : 0))
         s256 = ep->split_hint;
-    } else if (!g.out_f32 && t256 * 2 <= 256 && K >= 4096 && !g.bias && !g.act && !g.residual && !g.act_bwd && !g.drop_thr && !g.tap_out &&
-             !g.preact && g.cmap.group == 0 && ldc == N) {
-      // few tiles, long reduction, plain epilogue: split-K over the idle CUs (at most the 16 splits the workspace size allows for)
+    } else if (!g.out_f32 && t256 * 2 <= 256 && K >= 4096 && !g.act && !g.residual && !g.act_bwd && !g.tap_out &&
+             !g.preact && g.cmap.group == 0 && ldc == N && N % 4 == 0) {
+      // few tiles, long reduction, plain / bias / bias + dropout epilogue (applied by the reduce): split-K over the idle CUs (at most
+      // the 16 splits the workspace size allows for)
       s256 = choose_splitk256(t256, K, M, N, workspace ? workspace_bytes : 0);
       if (s256 > 16) s256 = 16;
     }
@@ -817,8 +833,15 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
         ok = workspace && workspace_bytes >= need;
         h.colsum_part = (float*)((char*)workspace + (size_t)(h.splits > 1 ? h.splits : 0) * M * N * sizeof(float));
       }
+      ReduceEpi repi = {};
       if (h.splits > 1) {
-        ok = ok && !g.bias && !g.act && !g.residual && !g.act_bwd && !g.drop_thr && g.cmap.group == 0 && ldc == N;
+        const bool wgrad = transA && transB;
+        ok = ok && (wgrad ? (!g.bias && !g.drop_thr) : N % 4 == 0) && !g.act && !g.residual && !g.act_bwd && g.cmap.group == 0 && ldc == N;
+        if (!wgrad) {       // forward / dgrad product split along K: bias and dropout move into the reduce
+          repi = ReduceEpi{g.bias, (int)N, g.drop_thr, g.drop_scale, g.seed, g.drop_offset};
+          h.bias = nullptr;
+          h.drop_thr = 0;
+        }
         h.C = workspace;
         h.out_f32 = 1;
         h.accumulate = 0;
@@ -830,7 +853,7 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
           const long long rblocks = (MN / 4 + thr - 1) / thr;
           const int cblocks = colsum_out ? (int)((M + thr - 1) / thr) : 0;
           hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(rblocks + cblocks)), dim3(thr), 0, stream, (const float*)workspace,
-                             (bf16*)user_c256, MN, h.splits, user_acc256, (int)rblocks, (const float*)h.colsum_part, (bf16*)colsum_out, (int)M);
+                             (bf16*)user_c256, MN, h.splits, user_acc256, (int)rblocks, (const float*)h.colsum_part, (bf16*)colsum_out, (int)M, repi);
         } else if (colsum_out) {
           hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, (const float*)h.colsum_part,
                              (bf16*)colsum_out, (int)M, 1);
@@ -892,7 +915,7 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
     const long long blocks = (MN / 4 + thr - 1) / thr;
     const int cblocks = colsum_out ? (int)((M + thr - 1) / thr) : 0;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(blocks + cblocks)), dim3(thr), 0, stream, (const float*)workspace,
-                       (bf16*)user_c, MN, splitk, user_acc, (int)blocks, (const float*)g.colsum_part, (bf16*)colsum_out, (int)M);
+                       (bf16*)user_c, MN, splitk, user_acc, (int)blocks, (const float*)g.colsum_part, (bf16*)colsum_out, (int)M, ReduceEpi{});
   } else if (colsum_out) {
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, (const float*)g.colsum_part,
                        (bf16*)colsum_out, (int)M, splitk);
