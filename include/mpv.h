@@ -151,6 +151,15 @@ int mpv_ln_stream_fwd(const void* h_in, int h_in_bf16, const void* add, float* h
                       float* mean, float* rstd, int64_t rows, int64_t cols, int64_t ldh, int64_t lda, int64_t ldy, float eps,
                       int h_group, int h_stride, int h_offset, int a_group, int a_stride, int a_offset, int y_group, int y_stride,
                       int y_offset, mpv_stream_t stream);
+/* The same with the dropout of `add` applied HERE (round 4): add_dropout_p > 0 drops the added tensor -- element index offset + (row of
+ * `add`) * cols + column, the index, threshold and bf16 rounding of mpv_gemm_bf16's dropout epilogue, so that a sublayer's GEMM can store
+ * bf16(acc + bias) with a plain epilogue and bias_dropout_add (models/modeling_distributed_gpt3.py:953-979, 1059-1078) completes in the
+ * LayerNorm that adds it into the stream: an HBM-bound kernel with idle VALU slots instead of a store-bound epilogue.  Bit-identical to
+ * dropping in the GEMM. */
+int mpv_ln_stream_fwd_drop(const void* h_in, int h_in_bf16, const void* add, float* h_out, const void* gamma, const void* beta, void* y,
+                           float* mean, float* rstd, int64_t rows, int64_t cols, int64_t ldh, int64_t lda, int64_t ldy, float eps,
+                           int h_group, int h_stride, int h_offset, int a_group, int a_stride, int a_offset, int y_group, int y_stride,
+                           int y_offset, float add_dropout_p, uint64_t seed, uint64_t offset, mpv_stream_t stream);
 int mpv_ln_stream_bwd(const void* dy, const float* x, const void* gamma, const float* mean, const float* rstd, const void* dres,
                       void* dx, void* dx_drop, float drop_p, uint64_t seed, uint64_t offset, int64_t rows, int64_t cols, int64_t ldx,
                       int64_t ldy, int x_group, int x_stride, int x_offset, int y_group, int y_stride, int y_offset, mpv_stream_t stream);

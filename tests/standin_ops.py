@@ -175,8 +175,9 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, rows, cols, *, dres=None, dx=None, d
     return dx
 
 
-def ln_stream_fwd(h_in, add, gamma, beta, eps, rows, cols, *, h_out=None, out=None, hmap=IDENT, amap=IDENT, ymap=IDENT, out_rows=None,
+def ln_stream_fwd(h_in, add, gamma, beta, eps, rows, cols, *, add_dropout_p=0.0, seed=0, offset=0, h_out=None, out=None, hmap=IDENT, amap=IDENT, ymap=IDENT, out_rows=None,
                   h_rows=None):
+    assert add_dropout_p == 0.0, "stand-ins do not model the hash dropout"
     if out is None:
         out = torch.zeros((out_rows if out_rows is not None else rows, cols), dtype=BF)
     hr = _rows(hmap, rows)

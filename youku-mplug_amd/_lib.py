@@ -56,6 +56,8 @@ _SIGS = {
                           [c_int64] * 4 + _RM + _RM + [c_void_p, c_size_t, c_void_p]),
     "mpv_ln_stream_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int64] * 5 +
                           [c_float] + _RM + _RM + _RM + [c_void_p]),
+    "mpv_ln_stream_fwd_drop": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int64] * 5 +
+                               [c_float] + _RM + _RM + _RM + [c_float, c_uint64, c_uint64, c_void_p]),
     "mpv_ln_stream_bwd": (c_int, [c_void_p] * 8 + [c_float, c_uint64, c_uint64] + [c_int64] * 4 + _RM + _RM + [c_void_p]),
     "mpv_attn_fwd": (c_int, [C.POINTER(AttnDesc), c_void_p]),
     "mpv_attn_bwd": (c_int, [C.POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -556,7 +556,17 @@ struct LnStreamArgs {
   long long ldh, lda, ldy;
   float eps;
   RowMap hmap, amap, ymap;
+  // dropout of the ADDED tensor (round 4: the bias-dropout of a decoder sublayer moves out of its GEMM's epilogue into the LayerNorm
+  // that adds it into the stream -- an HBM-bound kernel with idle VALU slots): element index offset + (row of `add`) * cols + column,
+  // the index the GEMM epilogue used, and the dropped value is rounded to bf16 as that epilogue stored it: bit-identical results
+  uint32_t drop_thr;
+  float drop_scale;
+  uint64_t seed, offset;
 };
+__device__ __forceinline__ bf16x8 ln_stream_drop(const LnStreamArgs& p, bf16x8 av, uint64_t seed_r, long long arow, int col) {
+  const f32x8 a = mpv_dropout_vec<f32x8, 8>(cvt8(av), seed_r, p.offset + (uint64_t)arow * (uint64_t)p.cols + (uint64_t)col, p.drop_thr, p.drop_scale);
+  return cvt8(a);
+}
 template <int MAXC, bool INBF>
 __global__ __launch_bounds__(256) void ln_stream_fwd_kernel(const LnStreamArgs p) {
   const int lane = threadIdx.x & 63;
@@ -574,7 +584,9 @@ __global__ __launch_bounds__(256) void ln_stream_fwd_kernel(const LnStreamArgs p
     const long long hrow = map_row(p.hmap, r);
     f32x8 v[MAXC];
     bf16x8 av[MAXC];
-    const bf16* ar = p.add ? p.add + map_row(p.amap, r) * p.lda : nullptr;
+    const long long arow = p.add ? map_row(p.amap, r) : 0;
+    const bf16* ar = p.add ? p.add + arow * p.lda : nullptr;
+    const uint64_t seed_r = p.drop_thr ? mpv_resolve_seed(p.seed) : 0;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {      // everything of the row requested before anything is reduced
       const int c = lane + 64 * i;
@@ -586,7 +598,10 @@ __global__ __launch_bounds__(256) void ln_stream_fwd_kernel(const LnStreamArgs p
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
-      if (ar) v[i] += cvt8(av[i]);
+      if (ar) {
+        if (p.drop_thr && lane + 64 * i < nchunk) av[i] = ln_stream_drop(p, av[i], seed_r, arow, (lane + 64 * i) * 8);
+        v[i] += cvt8(av[i]);
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) s += v[i][e];
     }
@@ -642,7 +657,11 @@ __global__ __launch_bounds__(1024) void ln_stream_fwd_wg_kernel(const LnStreamAr
     if (ok) {
       if constexpr (INBF) v = cvt8(*(const bf16x8*)((const bf16*)p.h_in + hrow * p.ldh + tid * 8));
       else v = *(const f32x8*)((const float*)p.h_in + hrow * p.ldh + tid * 8);
-      if (p.add) av = *(const bf16x8*)(p.add + map_row(p.amap, r) * p.lda + tid * 8);
+      if (p.add) {
+        const long long arow = map_row(p.amap, r);
+        av = *(const bf16x8*)(p.add + arow * p.lda + tid * 8);
+        if (p.drop_thr) av = ln_stream_drop(p, av, mpv_resolve_seed(p.seed), arow, tid * 8);
+      }
       gm = *(const bf16x8*)(p.gamma + tid * 8);
       bt = *(const bf16x8*)(p.beta + tid * 8);
     }
@@ -829,24 +848,26 @@ extern "C" int mpv_layernorm_bwd(const void* dy, const void* x, const void* gamm
   return mpv_check_launch("mpv_layernorm_bwd");
 }
 
-extern "C" int mpv_ln_stream_fwd(const void* h_in, int h_in_bf16, const void* add, float* h_out, const void* gamma, const void* beta, void* y,
-                                 float* mean, float* rstd, int64_t rows, int64_t cols, int64_t ldh, int64_t lda, int64_t ldy, float eps,
-                                 int h_group, int h_stride, int h_offset, int a_group, int a_stride, int a_offset, int y_group, int y_stride,
-                                 int y_offset, hipStream_t stream) {
-  MPV_REQUIRE(h_in && gamma && beta && y, MPV_E_ARG, "mpv_ln_stream_fwd: null pointer");
-  MPV_REQUIRE((add == nullptr) == (h_out == nullptr), MPV_E_ARG, "mpv_ln_stream_fwd: add and h_out come together");
+extern "C" int mpv_ln_stream_fwd_drop(const void* h_in, int h_in_bf16, const void* add, float* h_out, const void* gamma, const void* beta, void* y,
+                                      float* mean, float* rstd, int64_t rows, int64_t cols, int64_t ldh, int64_t lda, int64_t ldy, float eps,
+                                      int h_group, int h_stride, int h_offset, int a_group, int a_stride, int a_offset, int y_group, int y_stride,
+                                      int y_offset, float add_dropout_p, uint64_t seed, uint64_t offset, hipStream_t stream) {
+  MPV_REQUIRE(h_in && gamma && beta && y, MPV_E_ARG, "mpv_ln_stream_fwd_drop: null pointer");
+  MPV_REQUIRE((add == nullptr) == (h_out == nullptr), MPV_E_ARG, "mpv_ln_stream_fwd_drop: add and h_out come together");
   MPV_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= 4096 && ldh % 8 == 0 && lda % 8 == 0 && ldy % 8 == 0, MPV_E_SHAPE,
-              "mpv_ln_stream_fwd: cols=%lld and the leading dims must be multiples of 8, cols <= 4096", (long long)cols);
-  MPV_REQUIRE((((uintptr_t)h_in | (uintptr_t)h_out) & 31) == 0 || h_in_bf16, MPV_E_ALIGN, "mpv_ln_stream_fwd: the fp32 stream must be 32-byte aligned");
+              "mpv_ln_stream_fwd_drop: cols=%lld and the leading dims must be multiples of 8, cols <= 4096", (long long)cols);
+  MPV_REQUIRE((((uintptr_t)h_in | (uintptr_t)h_out) & 31) == 0 || h_in_bf16, MPV_E_ALIGN, "mpv_ln_stream_fwd_drop: the fp32 stream must be 32-byte aligned");
+  MPV_REQUIRE(add_dropout_p >= 0.f && add_dropout_p < 1.f && (add_dropout_p == 0.f || add), MPV_E_ARG, "mpv_ln_stream_fwd_drop: bad add_dropout_p");
   if (rows == 0) return MPV_OK;
   LnStreamArgs a = {h_in, (const bf16*)add, h_out, (const bf16*)gamma, (const bf16*)beta, (bf16*)y, mean, rstd, rows, (int)cols, ldh, lda, ldy, eps,
-                    RowMap{h_group, h_stride, h_offset}, RowMap{a_group, a_stride, a_offset}, RowMap{y_group, y_stride, y_offset}};
+                    RowMap{h_group, h_stride, h_offset}, RowMap{a_group, a_stride, a_offset}, RowMap{y_group, y_stride, y_offset},
+                    add_dropout_p > 0.f ? mpv_drop_threshold(add_dropout_p) : 0u, 1.0f / (1.0f - add_dropout_p), seed, offset};
   if (cols >= 1024) {      // wide rows: a workgroup per row
     const int threads = (int)((cols / 8 + 63) / 64 * 64);
     const int g = (int)(rows < 65536 ? rows : 65536);
     if (h_in_bf16) hipLaunchKernelGGL((ln_stream_fwd_wg_kernel<true>), dim3(g), dim3(threads), 0, stream, a);
     else hipLaunchKernelGGL((ln_stream_fwd_wg_kernel<false>), dim3(g), dim3(threads), 0, stream, a);
-    return mpv_check_launch("mpv_ln_stream_fwd");
+    return mpv_check_launch("mpv_ln_stream_fwd_drop");
   }
   const int grid = (int)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);
   const int n8 = (int)((cols / 8 + 63) / 64);
@@ -854,7 +875,15 @@ extern "C" int mpv_ln_stream_fwd(const void* h_in, int h_in_bf16, const void* ad
   else if (n8 <= 4) launch_stream_fwd<4>(a, h_in_bf16 != 0, grid, stream);
   else if (n8 <= 5) launch_stream_fwd<5>(a, h_in_bf16 != 0, grid, stream);
   else launch_stream_fwd<8>(a, h_in_bf16 != 0, grid, stream);
-  return mpv_check_launch("mpv_ln_stream_fwd");
+  return mpv_check_launch("mpv_ln_stream_fwd_drop");
+}
+
+extern "C" int mpv_ln_stream_fwd(const void* h_in, int h_in_bf16, const void* add, float* h_out, const void* gamma, const void* beta, void* y,
+                                 float* mean, float* rstd, int64_t rows, int64_t cols, int64_t ldh, int64_t lda, int64_t ldy, float eps,
+                                 int h_group, int h_stride, int h_offset, int a_group, int a_stride, int a_offset, int y_group, int y_stride,
+                                 int y_offset, hipStream_t stream) {
+  return mpv_ln_stream_fwd_drop(h_in, h_in_bf16, add, h_out, gamma, beta, y, mean, rstd, rows, cols, ldh, lda, ldy, eps, h_group, h_stride, h_offset,
+                                a_group, a_stride, a_offset, y_group, y_stride, y_offset, 0.f, 0, 0, stream);
 }
 
 extern "C" int mpv_ln_stream_bwd(const void* dy, const float* x, const void* gamma, const float* mean, const float* rstd, const void* dres,

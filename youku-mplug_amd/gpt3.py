@@ -154,6 +154,10 @@ _SITE_EMBED, _SITE_ATTN, _SITE_DROP1, _SITE_DROP2 = 0, 1, 2, 3
 # function in the logits (tools/parity_bisect.py: 0.87e-2 with the fp32 stream).  MPV_DECODER_STREAM=bf16 (measurement knob)
 # restores the bf16 stream with the residual adds in the GEMM epilogues.
 FP32_STREAM = os.environ.get("MPV_DECODER_STREAM", "fp32") != "bf16"
+# Round 4: in the fp32-stream form the dropout of a sublayer's output (bias_dropout_add, models/modeling_distributed_gpt3.py:953-979) is
+# applied by the LayerNorm that adds it into the stream (mpv_ln_stream_fwd_drop: same element index, threshold and bf16 rounding, so the
+# step is bit-identical) instead of by the sublayer GEMM's epilogue.  MPV_DROPOUT_IN_LN=0 (measurement knob) keeps it in the GEMM.
+DROPOUT_IN_LN = os.environ.get("MPV_DROPOUT_IN_LN", "1") != "0"
 
 
 def _offset(layer: int, site: int) -> int:
@@ -235,12 +239,16 @@ class DistributedGPT3(nn.Module):
             # stream = the residual stream (bf16 straight out of the embedding, fp32 from the first add on); `pending` = the last
             # sublayer output (bias + dropout applied by its GEMM) that the next LayerNorm adds into the stream in fp32
             stream, pending, pmap = h, None, ops.IDENT
+            pend_off = 0                   # dropout site of `pending` (applied by the LayerNorm that adds it: DROPOUT_IN_LN)
+            p_g = 0.0 if DROPOUT_IN_LN else p_h      # dropout probability the sublayer GEMMs apply themselves
+            p_l = p_h if DROPOUT_IN_LN else 0.0      # ... and the one the adding LayerNorm applies
             smap = ops.IDENT               # rows of `stream` the current layer works on (the loss window in the top layer)
             for li, layer in enumerate(lm.encoder.layers):
                 ln = li + 1
                 att, mlp = layer.self_attention, layer.mlp
                 l1 = layer.input_layernorm
-                x1, nxt, m1, r1 = ops.ln_stream_fwd(stream, pending, l1.weight, l1.bias, l1.eps, R, H, amap=pmap)
+                x1, nxt, m1, r1 = ops.ln_stream_fwd(stream, pending, l1.weight, l1.bias, l1.eps, R, H, amap=pmap,
+                                                    add_dropout_p=p_l, seed=seed, offset=pend_off)
                 stream = nxt if nxt is not None else stream
                 h_in = stream                                                   # x of LayerNorm 1 (for its backward)
                 qkv = ops.gemm(x1, att.query_key_value.weight, R, 3 * H, H, bias=att.query_key_value.bias)
@@ -254,15 +262,17 @@ class DistributedGPT3(nn.Module):
                 # compact).  K/V of all rows are still needed by the window's queries, so LN1, qkv and the attention stay whole.
                 tm = (window[1], S, window[0]) if top else ops.IDENT
                 Rl = B * window[1] if top else R
-                a1 = ops.gemm(ctx, att.dense.weight, Rl, H, H, bias=att.dense.bias, dropout_p=p_h, seed=seed,
+                a1 = ops.gemm(ctx, att.dense.weight, Rl, H, H, bias=att.dense.bias, dropout_p=p_g, seed=seed,
                               offset=_offset(ln, _SITE_DROP1), amap=tm)                            # compact [Rl, H]
                 l2 = layer.post_attention_layernorm
-                x2, h1, m2, r2 = ops.ln_stream_fwd(stream, a1, l2.weight, l2.bias, l2.eps, Rl, H, hmap=tm, h_rows=R)
+                x2, h1, m2, r2 = ops.ln_stream_fwd(stream, a1, l2.weight, l2.bias, l2.eps, Rl, H, hmap=tm, h_rows=R,
+                                                   add_dropout_p=p_l, seed=seed, offset=_offset(ln, _SITE_DROP1))
                 F4 = mlp.dense_h_to_4h.out_features
                 z = torch.empty((Rl, F4), dtype=torch.bfloat16, device=h.device)
                 g = ops.gemm(x2, mlp.dense_h_to_4h.weight, Rl, F4, H, bias=mlp.dense_h_to_4h.bias, act=ACT_GELU_TANH, preact_out=z, preact_deriv=True)
-                pending = ops.gemm(g, mlp.dense_4h_to_h.weight, Rl, H, F4, bias=mlp.dense_4h_to_h.bias, dropout_p=p_h, seed=seed,
-                                   offset=_offset(ln, _SITE_DROP2))                                # compact [Rl, H]
+                pending = ops.gemm(g, mlp.dense_4h_to_h.weight, Rl, H, F4, bias=mlp.dense_4h_to_h.bias, dropout_p=p_g, seed=seed,
+                                   offset=_offset(ln, _SITE_DROP2))
+                pend_off = _offset(ln, _SITE_DROP2)                                # compact [Rl, H]
                 ent = dict(h=h_in, s1=(m1, r1), qkv=qkv, ctx=ctx, lse=lse, h1=h1, s2=(m2, r2), z=z)
                 if top:
                     ent["rows"] = tm
@@ -270,7 +280,8 @@ class DistributedGPT3(nn.Module):
                 stream, smap = h1, tm
             fl = lm.encoder.final_layernorm
             Rf = B * window[1] if window is not None else R
-            xf, h, mf, rf = ops.ln_stream_fwd(stream, pending, fl.weight, fl.bias, fl.eps, Rf, H, hmap=smap, h_rows=R)
+            xf, h, mf, rf = ops.ln_stream_fwd(stream, pending, fl.weight, fl.bias, fl.eps, Rf, H, hmap=smap, h_rows=R,
+                                              add_dropout_p=p_l, seed=seed, offset=pend_off)
         else:
             h, xf, mf, rf = self._layers_bf16_stream(h, lay, scale, window, layers, seed, p_h, p_a, B, S, R, H, np_, hn)
         if hidden_only:     # only last_hidden_state is consumed (models/distributed_gpt3.py:958, 583-584, 1149-1150)

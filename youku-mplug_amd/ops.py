@@ -195,9 +195,11 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, rows: int, cols: int, *, dres=None, 
 
 
 def ln_stream_fwd(h_in, add, gamma, beta, eps: float, rows: int, cols: int, *, h_out=None, out=None, hmap: RowMap = IDENT,
-                  amap: RowMap = IDENT, ymap: RowMap = IDENT, out_rows: Optional[int] = None, h_rows: Optional[int] = None):
+                  amap: RowMap = IDENT, ymap: RowMap = IDENT, out_rows: Optional[int] = None, h_rows: Optional[int] = None,
+                  add_dropout_p: float = 0.0, seed: int = 0, offset: int = 0):
     """The decoder's residual stream in fp32 (include/mpv.h: mpv_ln_stream_fwd): h' = h_in + add in fp32, y = LN(h') in bf16.
     h_in is the fp32 stream, or the bf16 embedding output for the first LayerNorm; add None: plain LN of h_in.
+    add_dropout_p > 0: `add` is dropped here (mpv_ln_stream_fwd_drop: the index / threshold / rounding of the GEMM's dropout epilogue).
     -> (y, h' (fp32, None without add), mean, rstd)."""
     _need_cuda(h_in, gamma, beta)
     if out is None:
@@ -206,9 +208,9 @@ def ln_stream_fwd(h_in, add, gamma, beta, eps: float, rows: int, cols: int, *, h
         h_out = torch.empty((h_rows if h_rows is not None else h_in.shape[0], cols), dtype=torch.float32, device=h_in.device)
     mean = torch.empty(rows, dtype=torch.float32, device=h_in.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=h_in.device)
-    check(_lib.lib().mpv_ln_stream_fwd(h_in.data_ptr(), int(h_in.dtype == torch.bfloat16), _p(add), _p(h_out) if add is not None else None,
+    check(_lib.lib().mpv_ln_stream_fwd_drop(h_in.data_ptr(), int(h_in.dtype == torch.bfloat16), _p(add), _p(h_out) if add is not None else None,
                                        gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, cols,
-                                       cols, cols, cols, eps, *hmap, *amap, *ymap, _stream()), "mpv_ln_stream_fwd")
+                                       cols, cols, cols, eps, *hmap, *amap, *ymap, float(add_dropout_p) if add is not None else 0.0, seed, offset, _stream()), "mpv_ln_stream_fwd_drop")
     return out, (h_out if add is not None else None), mean, rstd
 
 
