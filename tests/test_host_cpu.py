@@ -438,14 +438,17 @@ def _reference_search(kind, stub, tokens, query_embeds, cfg_over, **kw):
 
 class _StubState:
     def __init__(self, stub, batch, max_len):
-        self.stub, self.prefix = stub, None
+        self.stub, self.prefix, self.q = stub, None, 0
 
     def step(self, tokens, query_embeds=None):
+        self.q += 0 if query_embeds is None else query_embeds.size(1)          # cached positions that are not token rows
         new = tokens.t().contiguous()
         self.prefix = new if self.prefix is None else torch.cat([self.prefix, new], dim=0)
         return torch.stack([self.stub.row(self.prefix[:, b].tolist()) for b in range(tokens.shape[0])])
 
-    def reorder(self, idx):
+    def reorder(self, idx, shared_prefix=0):
+        n = shared_prefix - self.q
+        assert n >= 0 and (self.prefix[:n] == self.prefix[:n, :1]).all(), "the promised shared prefix is not shared"
         self.prefix = self.prefix[:, idx]
 
 

@@ -546,6 +546,8 @@ struct SmallMArgs {
 // flight at once (one batch) and the 128 workgroups put 8 waves on a CU instead of 2.
 // COLS = output columns per workgroup: 16, or 8 where N / 16 workgroups would leave CUs idle (N = 2048: 128 workgroups on 256 CUs; the
 // weight rows 8..15 of the MFMA operand are then masked lanes -- no traffic, the matrix pipe is nowhere near a limit here).
+// Non-temporal weight loads (`global_load_dwordx4 ... nt`) were measured and are not used: 1.396 -> 1.422 ms per decode step
+// (profiles/r04_c19_decode_nt_ab.log) -- the five beams' rows of a step re-read nothing, but the NEXT step re-reads what L2 / MALL kept.
 template <bool FULL, int NW = 4, int COLS = 16>   // FULL: N % 16 == 0 and K % 64 == 0 -> branch-free main loop (unrolled 8x: 16 weight loads in flight per lane)
 __global__ __launch_bounds__(64 * NW) void gemm_small_m_kernel(const SmallMArgs p) {
   __shared__ float part[NW][16][17];

@@ -22,7 +22,8 @@
 //    six phases ahead; s_waitcnt vmcnt(6); s_barrier; 16 MFMAs (one 64x32 quadrant x K=64); s_barrier}.  The two wave
 //    rows run the same code offset by one barrier, so on every SIMD one wave is in its MFMA segment while the other
 //    one reads LDS and issues DMA.  vmcnt is never drained inside the loop: three units (6 DMA instructions per lane)
-//    stay in flight across the barriers; a unit is read two phases after the wait that retires it.
+//    stay in flight across the barriers; a unit is read two phases after the wait that retires it.  The prologue issues
+//    six units and releases phase 0 as soon as the first two are in (round 4: -0.16 ms per step, profiles/r04_c18_*).
 //  * MFMA operands are swapped (D = Bfrag x Afrag) so a lane owns 4 consecutive output columns of one row; the
 //    epilogue rounds (acc * alpha + bias) to bf16 in registers, stages the whole 256x256 tile in LDS and finishes it
 //    row-contiguously with 16-byte loads/stores (activation (+pre-activation copy), activation-backward multiply,
@@ -527,7 +528,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   map_ktile(1);
   issue_unit(IC<0>{}, 1, 4);
   issue_unit(IC<1>{}, 1, 5);
-  __builtin_amdgcn_s_waitcnt(0x0F74);     // vmcnt(4): K-tile 0 has landed (this wave's part)
+  // phase 0 reads U0 and U1 only, so it starts once THEY have landed (vmcnt(8): everything but the four newest units of this
+  // wave); U2 / U3 of K-tile 0 are retired by phase 0's own vmcnt(6) + barrier, one full barrier pair before phase 1 / 2 read
+  // them -- also for wave row 0, whose phase-0 MFMA barrier is wave row 1's phase-0 wait barrier (the stagger below)
+  __builtin_amdgcn_s_waitcnt(0x0F78);
   SCHED_FENCE();
   __builtin_amdgcn_s_barrier();           // ... and everybody else's
   SCHED_FENCE();

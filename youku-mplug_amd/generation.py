@@ -106,16 +106,28 @@ class DecodeState:
         self.pos += Q + L
         return logits
 
-    def reorder(self, batch_idx: torch.Tensor):
+    def reorder(self, batch_idx: torch.Tensor, shared_prefix: int = 0):
         """swap_key_value_dict(:1459-1473): sequence j continues from the cache of sequence batch_idx[j].  The layers
-        are one allocation, so the whole re-order is a single strided row gather over (layer, sequence) rows."""
-        if self.twin is None:
+        are one allocation, so the whole re-order is a single strided row gather over (layer, sequence) rows.
+        `shared_prefix`: the caller's promise that the first `shared_prefix` cached positions are the same in every
+        sequence (beam search: the visual prefix and the prompt, 264 of ~290 positions at the caption shapes).  Once both
+        copies of the cache hold them they are not moved again: the gather starts at that position (round 4: 122 -> 9 us
+        per step)."""
+        first = self.twin is None
+        if first:
             self.twin = torch.empty_like(self.cache)
             self._twin_ptrs = self._ptrs(self.twin)
+            self._layer_base = torch.arange(self.nl, device=self.cache.device, dtype=torch.int64)[:, None] * self.batch
+            self._twin_shared = 0                    # leading positions known to be identical in cache AND twin
         B, nl = self.batch, self.nl
-        idx = (torch.arange(nl, device=self.cache.device)[:, None] * B + batch_idx.to(torch.int64)[None]).reshape(-1).contiguous()
+        shared_prefix = min(int(shared_prefix), self.pos)
+        lo = shared_prefix if shared_prefix <= self._twin_shared else 0
+        idx = (self._layer_base + batch_idx.to(torch.int64)[None]).reshape(-1)
         pitch = self.max_len * 3 * self.H
-        ops.gather_rows_ld(self.cache, idx, self.twin, nl * B, self.pos * 3 * self.H, pitch, pitch)
+        if self.pos > lo:
+            off = lo * 3 * self.H
+            ops.gather_rows_ld(self.cache.view(-1)[off:], idx, self.twin.view(-1)[off:], nl * B, (self.pos - lo) * 3 * self.H, pitch, pitch)
+        self._twin_shared = shared_prefix            # after a gather from 0 the twin holds them too; the source did already
         self.cache, self.twin = self.twin, self.cache
         self._cache_ptrs, self._twin_ptrs = self._twin_ptrs, self._cache_ptrs
 
@@ -172,7 +184,7 @@ StepFn = Callable[[Optional[torch.Tensor], Optional[torch.Tensor]], torch.Tensor
 def beam_search_loop(cfg, make_state: Callable[[int, int], object], tokens: torch.Tensor, query_embeds=None, beam_size=5,
                      num_return_gen=1, stop_token=None, prompt_length=None, topk_fn=None):
     """models/modeling_distributed_gpt3.py:1737-1873.  `make_state(batch, max_len)` returns an object with
-    .step(tokens, query_embeds) -> logits [beams, V] and .reorder(batch_idx); `topk_fn(logits, k, add)` ->
+    .step(tokens, query_embeds) -> logits [beams, V] and .reorder(batch_idx, shared_prefix=n); `topk_fn(logits, k, add)` ->
     (values, indices) of log_softmax + add.  Both are injectable so the host logic can be driven from any logits source."""
     assert tokens.size(0) == 1
     dev = tokens.device
@@ -186,23 +198,27 @@ def beam_search_loop(cfg, make_state: Callable[[int, int], object], tokens: torc
     state = make_state(beam_size, final_len + Q)
     hyp = BeamHypotheses(beam_size)
     done = False
+    # The search state lives on the host (round 4): the token table and the beam scores are python-side bookkeeping in the
+    # reference too (:1799-1840 walks the candidates one .item() at a time); per step the device sees ONE [2, beams] int64
+    # upload (source beam, new token), the scores it adds to the log-probabilities, and two small downloads of the candidates.
+    scores_h = [0.0] * beam_size
     scores = torch.zeros(beam_size, dtype=torch.float32, device=dev)
-    tokens = tokens.repeat(beam_size, 1)
+    tokens_h = tokens.cpu().repeat(beam_size, 1)
     if query_embeds is not None:
         query_embeds = query_embeds.repeat(beam_size, 1, 1)
     prev, total_prompt, total_final = 0, prompt_length + Q, final_len + Q
     context_length = total_prompt
+    t2u = tokens_h[:, :total_prompt - Q].to(dev)
     for context_length in range(total_prompt, total_final):
-        t2u = tokens[:, max(prev - Q, 0):context_length - Q]
         logits = state.step(t2u, query_embeds if context_length == total_prompt else None)
         V = logits.size(-1)
         k2 = 2 * beam_size
         vals, idxs = topk_fn(logits, k2, scores)                                             # log_softmax + scores (:1790-1791)
-        vals, idxs = vals.cpu(), idxs.cpu()
+        vals, idxs = vals.tolist(), idxs.tolist()
         if context_length == total_prompt:                                                   # all beams identical: row 0 only (:1793-1795)
-            cand = [(vals[0, j].item(), 0, idxs[0, j].item()) for j in range(k2)]
+            cand = [(vals[0][j], 0, idxs[0][j]) for j in range(k2)]
         else:
-            cand = [(vals[b, j].item(), b, idxs[b, j].item()) for b in range(beam_size) for j in range(k2)]
+            cand = [(vals[b][j], b, idxs[b][j]) for b in range(beam_size) for j in range(k2)]
             cand.sort(key=lambda c: (-c[0], c[1] * V + c[2]))
             cand = cand[:k2]
         next_beams = []
@@ -210,7 +226,7 @@ def beam_search_loop(cfg, make_state: Callable[[int, int], object], tokens: torc
             if token_id == stop_token:
                 if rank >= beam_size:                                                        # :1809-1812
                     continue
-                hyp.add(tokens[beam_id].clone(), beam_score, context_length + 1 - total_prompt)
+                hyp.add(tokens_h[beam_id].clone(), beam_score, context_length + 1 - total_prompt)
             else:
                 next_beams.append((token_id, beam_score, beam_id))
             if len(next_beams) == beam_size:
@@ -218,18 +234,21 @@ def beam_search_loop(cfg, make_state: Callable[[int, int], object], tokens: torc
         if hyp.is_done(max(c[0] for c in cand), context_length + 1 - total_prompt):
             done = True
             break
-        best = torch.tensor([b[2] for b in next_beams], dtype=torch.long, device=dev)
-        tokens = tokens[best, :]
-        tokens[:, context_length - Q] = torch.tensor([b[0] for b in next_beams], dtype=torch.long, device=dev)
-        scores = torch.tensor([b[1] for b in next_beams], dtype=torch.float32, device=dev)
-        state.reorder(best)
+        best_h = [b[2] for b in next_beams]
+        tokens_h = tokens_h[best_h, :]
+        tokens_h[:, context_length - Q] = torch.tensor([b[0] for b in next_beams], dtype=torch.long)
+        scores_h = [b[1] for b in next_beams]
+        moved = torch.tensor([best_h, [b[0] for b in next_beams]], dtype=torch.long).to(dev)
+        scores = torch.tensor(scores_h, dtype=torch.float32).to(dev)
+        state.reorder(moved[0], shared_prefix=total_prompt)
+        t2u = moved[1].view(-1, 1)
         prev = context_length
     if not done:
         for b in range(beam_size):
-            hyp.add(tokens[b].clone(), scores[b].item(), context_length + 1 - total_prompt)
+            hyp.add(tokens_h[b].clone(), scores_h[b], context_length + 1 - total_prompt)
     ranked = sorted(hyp.beams, key=lambda x: x[0], reverse=True)
     num_return_gen = min(num_return_gen, len(ranked))
-    return SimpleNamespace(sequences=torch.stack([ranked[i][1] for i in range(num_return_gen)], dim=0),
+    return SimpleNamespace(sequences=torch.stack([ranked[i][1] for i in range(num_return_gen)], dim=0).to(dev),
                            scores=torch.tensor([ranked[i][0] for i in range(num_return_gen)], dtype=torch.float32))
 
 
