@@ -68,7 +68,8 @@ def test_gemm_kernels_fit_their_occupancy(kernels):
 
 def test_streaming_kernels_keep_their_waves(kernels):
     ks, _ = kernels
-    budget = {"14ln_fwd8_kernelILi2EE": 72, "14ln_fwd8_kernelILi4EE": 128, "14ln_bwd8_kernelILi2ELb1EE": 128,      # <2>, <4>, <2, true>
+    budget = {"14ln_fwd8_kernelILi2EE": 72, "14ln_fwd8_kernelILi4EE": 128, "14ln_bwd8_kernelILi2ELb1ELb0EE": 128,      # <2>, <4>, <2, true>
+              "14ln_bwd8_kernelILi2ELb1ELb1EE": 168,      # <2, true, PF>: two row sets, 3 waves per SIMD (768 workgroups)
               "20ln_bwd8_plain_kernelILi4ELb0EE": 168, "20ln_bwd8_plain_kernelILi4ELb1EE": 168, "20ln_stream_fwd_kernelILi4E": 168, "20temporal_attn_kernelILb0ELi8ELi96EE": 128, "20temporal_attn_kernelILb1ELi8ELi96EE": 128,
               # 4 frames (the shipped pre-train YAML) and 16 (the retrieval recipe; LDS allows 7 / 5 waves per CU there, registers are not the limit)
               "20temporal_attn_kernelILb0ELi4ELi96EE": 128, "20temporal_attn_kernelILb1ELi4ELi96EE": 128,
@@ -133,6 +134,24 @@ def test_persistent_attention_kernels_never_touch_scratch(kernels):
         loop = body[first_loop_dma[2]:]
         assert "scratch_" not in loop
         assert len(re.findall(r"s_waitcnt vmcnt\(", loop)) <= 2, (n, re.findall(r"s_waitcnt vmcnt\(\d+\)", loop))
+
+
+def test_layernorm_backward_keeps_its_prefetch_in_flight(kernels):
+    """ln_bwd8_kernel<2, true, PF>: the next row of a wave is requested before the current one is reduced.  That only works if the
+    compiler waits for the CURRENT row with a counted s_waitcnt -- which it can only do when every request of a row is branch-free
+    (buffer accesses; the statistics requested before the row's data): six 16-byte row loads per set, three sets in the code
+    (prologue + the loop unrolled by two), and inside the loop no vmcnt wait below the six requests of the row in flight except the
+    one at the loop head."""
+    ks, _ = kernels
+    name = next(n for n in ks if "14ln_bwd8_kernelILi2ELb1ELb1EE" in n)
+    dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--disassemble-symbols=" + name, ks[name]["file"]], capture_output=True, text=True).stdout
+    body = dis[:dis.index("s_endpgm")]
+    loads = [m.start() for m in re.finditer(r"buffer_load_dwordx4 ", body)]
+    assert len(loads) == 18, len(loads)
+    assert "scratch_" not in body and "global_load_dwordx4" not in body[loads[0]:]
+    loop = body[loads[5]:loads[17]]                                            # behind the prologue's requests .. last request of the third set
+    waits = [int(w) for w in re.findall(r"s_waitcnt vmcnt\((\d+)\)", loop)]
+    assert waits and sum(1 for w in waits if w < 6) <= 1, waits
 
 
 def test_no_other_kernel_spills(kernels):

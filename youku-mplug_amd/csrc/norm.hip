@@ -4,6 +4,7 @@
 // wave shuffles, affine fused, bf16 out.  Backward fuses the residual-gradient add, an
 // optional dropout-masked copy (for the bias_dropout_add that precedes the LN in the GPT
 // layer) and per-block partial dgamma/dbeta sums (finalised by a second tiny kernel).
+#include <cstdlib>
 #include "mpv_common.h"
 #include "mpv_kernels.h"
 
@@ -381,9 +382,10 @@ __global__ __launch_bounds__(256) void ln_bwd8_plain_kernel(const LnBwdArgs p) {
 }
 
 
-// waves per SIMD the register allocation is held to: 4 (128 VGPRs) where that fits without scratch
-template <int MAXC, bool DPARAM>
-__global__ __launch_bounds__(256, MAXC <= 2 ? 4 : MAXC <= 3 ? 2 : 1) void ln_bwd8_kernel(const LnBwdArgs p) {
+// waves per SIMD the register allocation is held to: 4 (128 VGPRs) where that fits without scratch; 3 (168) with the next row's
+// prefetch (PF, below)
+template <int MAXC, bool DPARAM, bool PF = false>
+__global__ __launch_bounds__(256, PF ? 3 : MAXC <= 2 ? 4 : MAXC <= 3 ? 2 : 1) void ln_bwd8_kernel(const LnBwdArgs p) {
   const uint64_t seed_r = p.drop_thr ? mpv_resolve_seed(p.seed) : 0;      // (bit 63 set: the seed lives in device memory, mpv_common.h)
   __shared__ float red[DPARAM ? 2 * MAXC * 512 : 1];
   const int lane = threadIdx.x & 63;
@@ -408,6 +410,98 @@ __global__ __launch_bounds__(256, MAXC <= 2 ? 4 : MAXC <= 3 ? 2 : 1) void ln_bwd
   // residual gradient used to be read after the two wave reductions -- a second, serial HBM latency per row), and they are
   // held as raw bf16 (12 VGPRs per chunk instead of 16 of fp32 x-hat / g), x-hat and g being recomputed for the output
   // sweep: identical arithmetic, fewer registers, more resident waves.
+  if constexpr (PF) {
+    // PF (round 4): the NEXT row of the wave is requested before the current one is reduced (two register sets, the loop
+    // unrolled by two) -- between a row's stores and the next row's data a wave had nothing in flight.  For the compiler to
+    // wait for the CURRENT row only (`s_waitcnt vmcnt(n)` counts the younger requests, and a request inside a branch it cannot
+    // count on) every load and store of a row is branch-free: buffer accesses over a descriptor of exactly the row, so chunks
+    // past the row read zeros and store nothing, an absent residual gradient is a descriptor of zero bytes, and past the
+    // wave's last row the prefetch re-requests the current one (cache hits).  No dropout-masked second output in this form (the
+    // launcher keeps such calls on the one-row form: the mask hash does not fit beside two row sets at 3 waves per SIMD).
+    union Ld { i32x4 i; bf16x8 b; };
+    const uint32_t rbytes = (uint32_t)p.cols * 2u;
+    // (the row's statistics are vector loads too -- requested FIRST, so that they are older than the row's data)
+    auto load_row = [&](long long r, bf16x8 (&xb)[MAXC], bf16x8 (&db)[MAXC], bf16x8 (&rb)[MAXC], float& mu, float& rs) {
+      mu = p.mean[r];
+      rs = p.rstd[r];
+      const long long xrow = map_row(p.xmap, r);
+      const __amdgpu_buffer_rsrc_t xs = make_rsrc(p.x + xrow * p.ldx, rbytes);
+      const __amdgpu_buffer_rsrc_t ds = make_rsrc(p.dy + map_row(p.ymap, r) * p.ldy, rbytes);
+      const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(p.dres ? p.dres + xrow * p.ldx : p.x, p.dres ? rbytes : 0u);
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i) {
+        const uint32_t off = (uint32_t)(lane + 64 * i) * 16u;
+        Ld a, b, c;
+        a.i = __builtin_amdgcn_raw_buffer_load_b128(xs, off, 0, 0);
+        b.i = __builtin_amdgcn_raw_buffer_load_b128(ds, off, 0, 0);
+        c.i = __builtin_amdgcn_raw_buffer_load_b128(rs_, off, 0, 0);
+        xb[i] = a.b;
+        db[i] = b.b;
+        rb[i] = c.b;
+      }
+    };
+    auto do_row = [&](long long r, bf16x8 (&xb)[MAXC], bf16x8 (&db)[MAXC], bf16x8 (&rb)[MAXC], const float mu, const float rs) {
+      const long long xrow = map_row(p.xmap, r);
+      float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i) {
+        const bool ok = lane + 64 * i < nchunk;       // chunks past the row hold x = dy = 0: g = 0, but x-hat = -mu * rs is not
+        const f32x8 xv = cvt8(xb[i]), dv = cvt8(db[i]), gm = cvt8(gmb[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (xv[e] - mu) * rs;
+          const float g = dv[e] * gm[e];
+          c1 += g;
+          c2 += g * xh;
+          if constexpr (DPARAM) {
+            gacc[i][e] += dv[e] * xh;
+            bacc[i][e] += dv[e];
+          }
+        }
+        (void)ok;
+      }
+      c1 = wave_sum(c1) * inv_n;
+      c2 = wave_sum(c2) * inv_n;
+      const __amdgpu_buffer_rsrc_t os = make_rsrc(p.dx + xrow * p.ldx, rbytes);
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i) {      // opaque: without this the fp32 conversions of the first sweep are kept live across the reductions
+        asm volatile("" : "+v"(xb[i]), "+v"(db[i]));
+      }
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        const f32x8 xv = cvt8(xb[i]), dv = cvt8(db[i]), gm = cvt8(gmb[i]);
+        f32x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (xv[e] - mu) * rs;
+          const float g = dv[e] * gm[e];
+          o[e] = rs * (g - c1 - xh * c2);
+        }
+        o += cvt8(rb[i]);                    // zeros without a residual gradient
+        Ld ob;
+        ob.b = cvt8(o);
+        __builtin_amdgcn_raw_buffer_store_b128(ob.i, os, (uint32_t)c * 16u, 0, 0);
+      }
+    };
+    const long long stride = (long long)gridDim.x * 4;
+    const long long r0 = (long long)blockIdx.x * 4 + wave;
+    const int nrow = r0 < p.rows ? (int)((p.rows - r0 + stride - 1) / stride) : 0;      // rows of this wave (scalar trip count)
+    if (nrow > 0) {
+      bf16x8 xa[MAXC], da[MAXC], ra[MAXC], xb[MAXC], db[MAXC], rb[MAXC];
+      float mua, rsa, mub, rsb;
+      load_row(r0, xa, da, ra, mua, rsa);
+      for (int k = 0;; k += 2) {
+        const long long r = r0 + (long long)k * stride;
+        load_row(k + 1 < nrow ? r + stride : r, xb, db, rb, mub, rsb);
+        do_row(r, xa, da, ra, mua, rsa);
+        if (k + 1 >= nrow) break;
+        load_row(k + 2 < nrow ? r + 2 * stride : r + stride, xa, da, ra, mua, rsa);
+        do_row(r + stride, xb, db, rb, mub, rsb);
+        if (k + 2 >= nrow) break;
+      }
+    }
+  } else
   for (long long r = (long long)blockIdx.x * 4 + wave; r < p.rows; r += (long long)gridDim.x * 4) {
     const long long xrow = map_row(p.xmap, r);
     const bf16* xr = p.x + xrow * p.ldx;
@@ -714,6 +808,17 @@ void launch_stream_fwd(const LnStreamArgs& a, bool inbf, int grid, hipStream_t s
 
 constexpr int LN_BWD_MAX_BLOCKS = 1024;   // measured at 50432 x 768 with dgamma/dbeta: 2048 blocks 82 us, 1024 blocks 73 us, 512 blocks 95 us
 constexpr int LN_L1_ROWS = (LN_BWD_MAX_BLOCKS + 63) / 64;
+// The parameter-gradient backward of rows <= 1024 columns prefetches each wave's next row (ln_bwd8_kernel<.., PF>): 3 waves per SIMD,
+// so launches with parameter gradients are capped at 768 workgroups (3 per CU) -- 50432 x 768: 58.0 -> 54.0 us per launch
+// (profiles/r04_c20_ln_bwd_prefetch.md).  MPV_LN_BWD_PF=0 (measurement knob, read once) restores the one-row form on 1024 workgroups.
+static bool ln_bwd_pf() {
+  static const bool v = [] { const char* e = getenv("MPV_LN_BWD_PF"); return !e || atoi(e) != 0; }();
+  return v;
+}
+static int ln_bwd_blocks(int64_t rows) {
+  const int cap = ln_bwd_pf() ? 768 : LN_BWD_MAX_BLOCKS;
+  return (int)((rows + 3) / 4 < cap ? (rows + 3) / 4 : cap);
+}
 
 template <int MAXC>
 void launch_fwd(const LnFwdArgs& a, int grid, hipStream_t s) {
@@ -725,7 +830,9 @@ void launch_fwd8(const LnFwdArgs& a, int grid, hipStream_t s) {
 }
 template <int MAXC>
 void launch_bwd8(const LnBwdArgs& a, bool dparam, int grid, hipStream_t s) {
-  if (dparam)
+  if (dparam && MAXC <= 2 && ln_bwd_pf() && !a.dx_drop)
+    hipLaunchKernelGGL((ln_bwd8_kernel<(MAXC <= 2 ? MAXC : 2), true, true>), dim3(grid), dim3(256), 0, s, a);
+  else if (dparam)
     hipLaunchKernelGGL((ln_bwd8_kernel<MAXC, true>), dim3(grid), dim3(256), 0, s, a);
   else
     hipLaunchKernelGGL((ln_bwd8_plain_kernel<MAXC>), dim3(grid), dim3(256), 0, s, a);
@@ -776,9 +883,7 @@ extern "C" size_t mpv_layernorm_bwd_workspace_size(int64_t cols) {
 
 // rows of per-workgroup partials [rows][2][cols] a deferred-mode call (accumulate_dparams == MPV_LN_DPARAM_DEFER) leaves at
 // the start of its workspace for mpv_layernorm_dparam_finish
-extern "C" int mpv_layernorm_bwd_partial_rows(int64_t rows) {
-  return (int)((rows + 3) / 4 < LN_BWD_MAX_BLOCKS ? (rows + 3) / 4 : LN_BWD_MAX_BLOCKS);
-}
+extern "C" int mpv_layernorm_bwd_partial_rows(int64_t rows) { return ln_bwd_blocks(rows); }
 
 extern "C" int mpv_layernorm_bwd(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
                                  const void* dres, void* dx, void* dx_drop, float drop_p, uint64_t seed,
@@ -793,7 +898,7 @@ extern "C" int mpv_layernorm_bwd(const void* dy, const void* x, const void* gamm
   MPV_REQUIRE(drop_p >= 0.f && drop_p < 1.f, MPV_E_ARG, "mpv_layernorm_bwd: bad dropout_p");
   if (rows == 0) return MPV_OK;
   const bool dparam = dgamma != nullptr;
-  int grid = (int)((rows + 3) / 4 < LN_BWD_MAX_BLOCKS ? (rows + 3) / 4 : LN_BWD_MAX_BLOCKS);
+  int grid = ln_bwd_blocks(rows);
   if (dparam)
     MPV_REQUIRE(workspace && workspace_bytes >= (size_t)(grid + LN_L1_ROWS) * 2 * cols * sizeof(float), MPV_E_ARG,
                 "mpv_layernorm_bwd: workspace too small (need %zu bytes)", (size_t)(grid + LN_L1_ROWS) * 2 * cols * sizeof(float));
