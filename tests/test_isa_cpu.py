@@ -60,7 +60,7 @@ def _sel(ks, frag):
 def test_gemm_kernels_fit_their_occupancy(kernels):
     ks, _ = kernels
     for n, k in _sel(ks, "14gemm256_kernelI").items():      # one 512-thread workgroup per CU = 2 waves per SIMD: 256 registers
-        assert k["scratch"] == 0 and k["vgpr"] + k["agpr"] <= 256 and k["lds"] == 135168, (n, k)
+        assert k["scratch"] == 0 and k["vgpr"] + k["agpr"] <= 256 and k["lds"] == 135168 + 1024, (n, k)      # ring / staged tile + the bias slice
     assert len(_sel(ks, "14gemm256_kernelI")) == 9          # fwd x {256,192,160}, dgrad x {256,192,160}, kmapped dgrad, wgrad, kmapped wgrad
     for n, k in _sel(ks, "16gemm_bf16_kernelI").items():    # two 256-thread workgroups per CU
         assert k["scratch"] == 0 and k["vgpr"] <= 256 and k["lds"] == 65536, (n, k)

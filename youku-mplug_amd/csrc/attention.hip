@@ -196,11 +196,16 @@ __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8
 template <int HD>
 __device__ __forceinline__ void load_row_frags(bf16x8 (&f)[HD / 16], const bf16* base, long long rs, int row, int nrows,
                                                int lane, int hd = HD) {
+  // Branch-free (round 4): a row past the end re-reads the last row and is zeroed by a select.  Behind `if (row < nrows) load` the
+  // compiler cannot count on the request having been issued, so every batch of fragments was waited for with vmcnt(0) before the next
+  // operand's batch went out -- Q, dO, the statistics and the O rows of a dQ block were four round trips in a row.
+  const bf16* rp = base + (long long)min(row, nrows - 1) * rs + (lane >> 5) * 8;
 #pragma unroll
   for (int s = 0; s < HD / 16; ++s) {
     union { i32x4 i; bf16x8 b; } u;
-    u.i = i32x4{0, 0, 0, 0};
-    if (row < nrows && s * 16 + (lane >> 5) * 8 < hd) u.i = *(const i32x4*)(base + (long long)row * rs + s * 16 + (lane >> 5) * 8);
+    const bool cok = s * 16 + (lane >> 5) * 8 < hd;
+    u.i = *(const i32x4*)(rp + (cok ? s * 16 : 0));
+    if (!(row < nrows && cok)) u.i = i32x4{0, 0, 0, 0};
     f[s] = u.b;
   }
 }
@@ -374,6 +379,18 @@ __device__ __forceinline__ float row_delta(const bf16x8 (&dof)[HD / 16], const b
   float s = 0.f;
 #pragma unroll
   for (int st = 0; st < HD / 16; ++st) {
+    const f32x8 a = cvt8(dof[st]), b = cvt8(of[st]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += a[e] * b[e];
+  }
+  return s + __shfl_xor(s, 32, 64);
+}
+// ... from O fragments the caller requested together with Q and dO (one round trip for the whole block instead of four)
+template <int N>
+__device__ __forceinline__ float row_delta_from(const bf16x8 (&dof)[N], const bf16x8 (&of)[N]) {
+  float s = 0.f;
+#pragma unroll
+  for (int st = 0; st < N; ++st) {
     const f32x8 a = cvt8(dof[st]), b = cvt8(of[st]);
 #pragma unroll
     for (int e = 0; e < 8; ++e) s += a[e] * b[e];
@@ -833,20 +850,22 @@ __global__ __launch_bounds__(THREADS, WPE) void attn_bwd_dq_res_kernel(const Att
   dma_rows<HD, ROWB>(vsrc, vl, p.sk, p.v_rs, wave, nwaves, lane, p.hd);
   const int q0 = (blockIdx.x * nwaves + wave) * 32;
   const int qrow = q0 + (lane & 31);
-  bf16x8 qf[NS], dof[NS];
+  bf16x8 qf[NS], dof[NS], of[NS];
   load_row_frags<HD>(qf, p.q + b * p.q_bs + h * p.q_hs, p.q_rs, qrow, p.sq, lane, p.hd);
   load_row_frags<HD>(dof, p.dO + b * p.o_bs + h * p.o_hs, p.o_rs, qrow, p.sq, lane, p.hd);
+  load_row_frags<HD>(of, p.o + b * p.o_bs + h * p.o_hs, p.o_rs, qrow, p.sq, lane, p.hd);
+  const bool qok = qrow < p.sq;
+  const float lse_any = p.lse[(long long)bh * p.sq + min(qrow, p.sq - 1)];      // (all requests of the block before the first use of any)
   float sc = p.scale;
   if (p.scale_q_bf16) {
     scale_frags_bf16(qf, p.scale);
     sc = 1.0f;
   }
-  const bool qok = qrow < p.sq;
-  const float lse = qok ? p.lse[(long long)bh * p.sq + qrow] : INFINITY;
-  const float dl = row_delta<HD>(dof, p.o + b * p.o_bs + h * p.o_hs, p.o_rs, qrow, p.sq, lane, p.hd);
-  if (qok && lane < 32) p.delta[(long long)bh * p.sq + qrow] = dl;
+  const float lse = qok ? lse_any : INFINITY;
+  const float dl = row_delta_from(dof, of);
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
+  if (qok && lane < 32) p.delta[(long long)bh * p.sq + qrow] = dl;      // (behind the barrier: its acknowledgement is not waited for with the images)
   if (q0 >= p.sq) return;
   const int my_last = last_visible_key(p, qrow);
   const int nt = NTC ? NTC : last_visible_key(p, min(p.sq - 1, q0 + 31)) / 32 + 1;
@@ -962,20 +981,28 @@ __global__ __launch_bounds__(THREADS, WPE) void attn_bwd_dkv_res_kernel(const At
   char* ql = dl + region_bytes(p.sq, ROWB);                                  // Q  [sq][208 B]
   const __amdgpu_buffer_rsrc_t qsrc = make_rsrc(p.q + b * p.q_bs + h * p.q_hs, (uint32_t)(((long long)(p.sq - 1) * p.q_rs + p.hd) * 2));
   const __amdgpu_buffer_rsrc_t dosrc = make_rsrc(p.dO + b * p.o_bs + h * p.o_hs, (uint32_t)(((long long)(p.sq - 1) * p.o_rs + p.hd) * 2));
+  // The wave's K rows and the thread's first pair of statistics are requested BEFORE the LDS-DMA of the images: the compiler puts
+  // s_waitcnt vmcnt(0) between a pending buffer_load..lds and everything it cannot disambiguate from it (the statistics' LDS stores,
+  // and with them their loads) -- three round trips in a row where one does.
+  const int k0 = (blockIdx.x * nwaves + wave) * 32;
+  const int krow = k0 + (lane & 31);
+  bf16x8 kf[NS];
+  load_row_frags<HD>(kf, p.k + b * p.k_bs + h * p.k_hs, p.k_rs, krow, p.sk, lane, p.hd);
+  const float lse_first = p.lse[(long long)bh * p.sq + min(tid, p.sq - 1)], delta_first = p.delta[(long long)bh * p.sq + min(tid, p.sq - 1)];
   dma_rows<HD, ROWB>(qsrc, ql, p.sq, p.q_rs, wave, nwaves, lane, p.hd);
   dma_rows<HD, ROWB>(dosrc, dl, p.sq, p.o_rs, wave, nwaves, lane, p.hd);
   if constexpr (HD > 64) {
     const __amdgpu_buffer_rsrc_t vsrc = make_rsrc(p.v + b * p.v_bs + h * p.v_hs, (uint32_t)(((long long)(p.sk - 1) * p.v_rs + p.hd) * 2));
     dma_rows<HD, ROWB>(vsrc, vl, p.sk, p.v_rs, wave, nwaves, lane, p.hd);
   }
-  for (int r = tid; r < qrows; r += blockDim.x) {   // lse pre-multiplied by log2(e): probabilities are 2^(s*c2 - lse2)
+  if (tid < qrows) {                                // lse pre-multiplied by log2(e): probabilities are 2^(s*c2 - lse2)
+    sl[tid] = tid < p.sq ? lse_first * 1.4426950408889634f : 1e30f;
+    sl[qrows + tid] = tid < p.sq ? delta_first : 0.f;
+  }
+  for (int r = tid + blockDim.x; r < qrows; r += blockDim.x) {
     sl[r] = r < p.sq ? p.lse[(long long)bh * p.sq + r] * 1.4426950408889634f : 1e30f;
     sl[qrows + r] = r < p.sq ? p.delta[(long long)bh * p.sq + r] : 0.f;
   }
-  const int k0 = (blockIdx.x * nwaves + wave) * 32;
-  const int krow = k0 + (lane & 31);
-  bf16x8 kf[NS];
-  load_row_frags<HD>(kf, p.k + b * p.k_bs + h * p.k_hs, p.k_rs, krow, p.sk, lane, p.hd);
   const float sc = p.scale_q_bf16 ? 1.0f : p.scale;
   const float c2 = sc * 1.4426950408889634f;
   const bool kok = krow < p.sk;

@@ -44,7 +44,9 @@ constexpr int TM = 256, TN = 256, TK = 64;
 constexpr int UNIT = 16384;                    // bytes per ring unit
 constexpr int CPITCH = 264;                    // bf16 staging pitch (elements): 528-byte rows keep 16-byte alignment
 constexpr int FPITCH = 260;                    // fp32 staging pitch (floats) of a 64-row pass
-constexpr int SMEM_BYTES = TM * CPITCH * 2;    // 135168 >= 8 * UNIT
+constexpr int STAGE_BYTES = TM * CPITCH * 2;   // 135168 >= 8 * UNIT: ring, then the staged output tile
+constexpr int BIAS_LDS = STAGE_BYTES;          // behind it: the tile's 256 bias values (one 1 KiB DMA instruction: 512 bytes + zero fill)
+constexpr int SMEM_BYTES = STAGE_BYTES + 1024;
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -519,6 +521,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     phase(IC<3>{}, BUF, t);
   };
 
+  // ---- the tile's bias slice goes to LDS by one DMA instruction of wave 0, ahead of everything else (so it is the oldest request:
+  // every counted wait below retires it, and the prologue barrier publishes it).  The epilogue used to fetch it from global memory
+  // where it needs it -- eight dependent L2 round trips per tile, each behind its own s_waitcnt vmcnt(0), inside the staging pass.
+  const bool lds_bias = p.bias != nullptr && !p.out_f32;
+  if (lds_bias && wave == 0) {
+    const int nb0 = n0 + lane * 8;
+    dma16(raw_rsrc(p.bias, (uint32_t)p.N * 2u), smem_base + BIAS_LDS, (lane < 32 && nb0 < p.N) ? (uint32_t)(nb0 * 2) : OOB, 0u);
+  }
+
   // ---- prologue: units 0..5 (K-tile 0 and U0, U1 of K-tile 1)
   map_ktile(0);
   issue_unit(IC<0>{}, 0, 0);
@@ -624,8 +635,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
           const int col = wc * 64 + nh * 32 + nb * 16 + lg * 4;
-          f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-          if (p.bias && n0 + col < p.N) bv = cvt4(*(const bf16x4*)(p.bias + n0 + col));
+          f32x4 bv = {0.f, 0.f, 0.f, 0.f};       // (past column N: the DMA's zero fill)
+          if (lds_bias) bv = cvt4(*(const bf16x4*)(smem + BIAS_LDS + col * 2));
 #pragma unroll
           for (int mb = 0; mb < (mh == 1 ? MB1 : 4); ++mb) {
             const int row = wr * WROWS + mh * 64 + mb * 16 + l15;
@@ -734,6 +745,7 @@ bool mpv_gemm256_try_launch(const GemmArgs& g0, int transA, int transB, hipStrea
   GemmArgs g = g0;
   if (g.K % TK != 0 || g.k_per_split % TK != 0) return false;
   if (g.tail_g > 1) return false;
+  if (g.bias && ((uintptr_t)g.bias & 15) != 0) return false;      // the bias slice of a tile is fetched by 16-byte LDS-DMA
   g.tiles_n = (g.N + TN - 1) / TN;
   // MPV_GEMM_GM / MPV_GEMM_BANDS=0: measurement knobs (XCD walk width; row bands off), read once
   static const int env_gm = [] { const char* e = getenv("MPV_GEMM_GM"); return e ? atoi(e) : 0; }();

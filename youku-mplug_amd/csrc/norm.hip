@@ -280,103 +280,89 @@ __global__ __launch_bounds__(256) void ln_fwd8_kernel(const LnFwdArgs p) {
 // shape (5.3 TB/s: reads and writes alternating suit the HBM better than a read burst followed by a write burst).
 // XF32: x is the decoder's fp32 residual stream (mpv_ln_stream_bwd); dy / dres / dx stay bf16.
 template <int MAXC, bool XF32 = false>
-__global__ __launch_bounds__(256) void ln_bwd8_plain_kernel(const LnBwdArgs p) {
+__global__ __launch_bounds__(256, MAXC <= 4 ? 3 : MAXC <= 5 ? 2 : 1) void ln_bwd8_plain_kernel(const LnBwdArgs p) {
+  // Round 4: every access of a row is a branch-free buffer access over a descriptor of exactly the row (chunks past the row read
+  // zeros / store nothing; an absent residual gradient or dropout output is a descriptor of zero bytes).  With `c < nchunk ? load : 0`
+  // in a branch the compiler could not count on a request having been issued and waited with vmcnt(0) behind every one of them:
+  // the residual-gradient chunks came in one at a time, each behind the previous chunk's store acknowledgement.
   const uint64_t seed_r = p.drop_thr ? mpv_resolve_seed(p.seed) : 0;      // (bit 63 set: the seed lives in device memory, mpv_common.h)
-  constexpr bool DPARAM = false;
-  __shared__ float red[DPARAM ? 2 * MAXC * 512 : 1];
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nchunk = p.cols >> 3;
   const float inv_n = 1.0f / (float)p.cols;
-  f32x8 gacc[DPARAM ? MAXC : 1], bacc[DPARAM ? MAXC : 1];
-  if constexpr (DPARAM) {
-#pragma unroll
-    for (int i = 0; i < MAXC; ++i)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) gacc[i][e] = bacc[i][e] = 0.f;
-  }
+  union Ld { i32x4 i; bf16x8 b; f32x4 f; };
+  const uint32_t rbytes = (uint32_t)p.cols * 2u;
+  const __amdgpu_buffer_rsrc_t gs = make_rsrc(p.gamma, rbytes);
   for (long long r = (long long)blockIdx.x * 4 + wave; r < p.rows; r += (long long)gridDim.x * 4) {
     const long long xrow = map_row(p.xmap, r);
-    const bf16* xr = p.x + xrow * p.ldx;
-    const float* xr32 = (const float*)p.x + xrow * p.ldx;
-    const bf16* dyr = p.dy + map_row(p.ymap, r) * p.ldy;
     const float mu = p.mean[r], rs = p.rstd[r];
+    const __amdgpu_buffer_rsrc_t xs = XF32 ? make_rsrc((const float*)p.x + xrow * p.ldx, rbytes * 2u) : make_rsrc(p.x + xrow * p.ldx, rbytes);
+    const __amdgpu_buffer_rsrc_t ds = make_rsrc(p.dy + map_row(p.ymap, r) * p.ldy, rbytes);
     f32x8 xh[MAXC], g[MAXC];
+    Ld xa[MAXC], xb[MAXC], dd[MAXC], gg[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const uint32_t c = (uint32_t)(lane + 64 * i);
+      if constexpr (XF32) {
+        xa[i].i = __builtin_amdgcn_raw_buffer_load_b128(xs, c * 32u, 0, 0);
+        xb[i].i = __builtin_amdgcn_raw_buffer_load_b128(xs, c * 32u + 16u, 0, 0);
+      } else {
+        xa[i].i = __builtin_amdgcn_raw_buffer_load_b128(xs, c * 16u, 0, 0);
+      }
+      dd[i].i = __builtin_amdgcn_raw_buffer_load_b128(ds, c * 16u, 0, 0);
+      gg[i].i = __builtin_amdgcn_raw_buffer_load_b128(gs, c * 16u, 0, 0);
+    }
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
-      const int c = lane + 64 * i;
-      if (c < nchunk) {
-        f32x8 xv;
-        if constexpr (XF32) xv = *(const f32x8*)(xr32 + c * 8);
-        else xv = cvt8(*(const bf16x8*)(xr + c * 8));
-        const f32x8 dv = cvt8(*(const bf16x8*)(dyr + c * 8));
-        const f32x8 gm = cvt8(*(const bf16x8*)(p.gamma + c * 8));
+      const bool ok = lane + 64 * i < nchunk;
+      f32x8 xv;
+      if constexpr (XF32) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          xh[i][e] = (xv[e] - mu) * rs;
-          g[i][e] = dv[e] * gm[e];
-          c1 += g[i][e];
-          c2 += g[i][e] * xh[i][e];
-          if constexpr (DPARAM) {
-            gacc[i][e] += dv[e] * xh[i][e];
-            bacc[i][e] += dv[e];
-          }
+        for (int e = 0; e < 4; ++e) {
+          xv[e] = xa[i].f[e];
+          xv[4 + e] = xb[i].f[e];
         }
       } else {
+        xv = cvt8(xa[i].b);
+      }
+      const f32x8 dv = cvt8(dd[i].b), gm = cvt8(gg[i].b);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) xh[i][e] = g[i][e] = 0.f;
+      for (int e = 0; e < 8; ++e) {
+        xh[i][e] = ok ? (xv[e] - mu) * rs : 0.f;        // (past the row x reads 0: x-hat would be -mu * rs)
+        g[i][e] = dv[e] * gm[e];
+        c1 += g[i][e];
+        c2 += g[i][e] * xh[i][e];
       }
     }
     c1 = wave_sum(c1) * inv_n;
     c2 = wave_sum(c2) * inv_n;
-    bf16* dxr = p.dx + xrow * p.ldx;
-    const bf16* drr = p.dres ? p.dres + xrow * p.ldx : nullptr;
-    bf16* ddr = p.dx_drop ? p.dx_drop + xrow * p.ldx : nullptr;
+    // the residual gradient is read behind the reductions (interleaved reads and writes measured faster on the decoder's shape than
+    // one read burst: 19.9 vs 23.0 us at 5120 x 2048) -- all chunks of the row requested together
+    const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.dres ? p.dres + xrow * p.ldx : p.dy, p.dres ? rbytes : 0u);
+    const __amdgpu_buffer_rsrc_t os = make_rsrc(p.dx + xrow * p.ldx, rbytes);
+    const __amdgpu_buffer_rsrc_t qs = make_rsrc(p.dx_drop ? p.dx_drop + xrow * p.ldx : p.dx, p.dx_drop ? rbytes : 0u);
+    Ld rv[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) rv[i].i = __builtin_amdgcn_raw_buffer_load_b128(rr, (uint32_t)(lane + 64 * i) * 16u, 0, 0);
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
       const int c = lane + 64 * i;
-      if (c < nchunk) {
-        f32x8 o;
+      f32x8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
-        if (drr) o += cvt8(*(const bf16x8*)(drr + c * 8));
-        const bf16x8 ob = cvt8(o);
-        *(bf16x8*)(dxr + c * 8) = ob;
-        if (ddr) {
-          const f32x8 of = cvt8(ob);
-          const uint64_t base = p.offset + (uint64_t)r * (uint64_t)p.cols + (uint64_t)(c * 8);
-          const f32x8 od = p.drop_thr ? mpv_dropout_vec<f32x8, 8>(of, seed_r, base, p.drop_thr, p.drop_scale) : of * p.drop_scale;
-          *(bf16x8*)(ddr + c * 8) = cvt8(od);
-        }
+      for (int e = 0; e < 8; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
+      o += cvt8(rv[i].b);
+      Ld ob;
+      ob.b = cvt8(o);
+      __builtin_amdgcn_raw_buffer_store_b128(ob.i, os, (uint32_t)c * 16u, 0, 0);
+      if (p.dx_drop) {
+        const f32x8 of = cvt8(ob.b);
+        const uint64_t base = p.offset + (uint64_t)r * (uint64_t)p.cols + (uint64_t)(c * 8);
+        const f32x8 od = p.drop_thr ? mpv_dropout_vec<f32x8, 8>(of, seed_r, base, p.drop_thr, p.drop_scale) : of * p.drop_scale;
+        Ld q;
+        q.b = cvt8(od);
+        __builtin_amdgcn_raw_buffer_store_b128(q.i, qs, (uint32_t)c * 16u, 0, 0);
       }
-    }
-  }
-  if constexpr (DPARAM) {
-#pragma unroll 1
-    for (int w = 0; w < 4; ++w) {
-      if (wave == w) {
-#pragma unroll
-        for (int i = 0; i < MAXC; ++i) {
-          const int c = lane + 64 * i;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            if (w == 0) {
-              red[c * 8 + e] = gacc[i][e];
-              red[MAXC * 512 + c * 8 + e] = bacc[i][e];
-            } else {
-              red[c * 8 + e] += gacc[i][e];
-              red[MAXC * 512 + c * 8 + e] += bacc[i][e];
-            }
-          }
-        }
-      }
-      __syncthreads();
-    }
-    float* out = p.part + (long long)blockIdx.x * 2 * p.cols;
-    for (int c = threadIdx.x; c < p.cols; c += 256) {
-      out[c] = red[c];
-      out[p.cols + c] = red[MAXC * 512 + c];
     }
   }
 }
@@ -737,6 +723,12 @@ __global__ __launch_bounds__(256) void ln_stream_fwd_kernel(const LnStreamArgs p
 // One WORKGROUP per row, one 16-byte chunk (8 columns) per lane: the decoder's streams are few rows (5120 at config B) of many
 // columns, and a wave-per-row kernel holds a whole fp32 row in registers (161 VGPRs at 2048 columns: 3 waves per SIMD, two
 // rounds of workgroups).  Here a lane holds 8 fp32 values; the two row reductions go through LDS (one float per wave).
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is also a release fence for global memory: with stores in
+// flight the compiler puts `s_waitcnt vmcnt(0)` in front of it, i.e. the row reductions of the kernel below waited for the
+// write acknowledgements of the fp32 stream (and a finished workgroup kept its slot until its last stores were acknowledged).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 template <bool INBF>
 __global__ __launch_bounds__(1024) void ln_stream_fwd_wg_kernel(const LnStreamArgs p) {
   __shared__ float red[2][16];
@@ -749,6 +741,10 @@ __global__ __launch_bounds__(1024) void ln_stream_fwd_wg_kernel(const LnStreamAr
     f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     bf16x8 av = {}, gm = {}, bt = {};
     if (ok) {
+      // gamma / beta first: behind the (conditional) dropout of `add` the compiler requested them only after the row had arrived --
+      // a second, serial round trip per row
+      gm = *(const bf16x8*)(p.gamma + tid * 8);
+      bt = *(const bf16x8*)(p.beta + tid * 8);
       if constexpr (INBF) v = cvt8(*(const bf16x8*)((const bf16*)p.h_in + hrow * p.ldh + tid * 8));
       else v = *(const f32x8*)((const float*)p.h_in + hrow * p.ldh + tid * 8);
       if (p.add) {
@@ -756,19 +752,14 @@ __global__ __launch_bounds__(1024) void ln_stream_fwd_wg_kernel(const LnStreamAr
         av = *(const bf16x8*)(p.add + arow * p.lda + tid * 8);
         if (p.drop_thr) av = ln_stream_drop(p, av, mpv_resolve_seed(p.seed), arow, tid * 8);
       }
-      gm = *(const bf16x8*)(p.gamma + tid * 8);
-      bt = *(const bf16x8*)(p.beta + tid * 8);
     }
-    if (p.add) {
-      v += cvt8(av);
-      if (ok) *(f32x8*)(p.h_out + hrow * p.ldh + tid * 8) = v;
-    }
+    if (p.add) v += cvt8(av);
     float s = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) s += v[e];
     s = wave_sum(s);
     if (lane == 0) red[0][wave] = s;
-    __syncthreads();
+    lds_barrier();
     float tot = 0.f;
     for (int w = 0; w < nwaves; ++w) tot += red[0][w];
     const float mu = tot * inv_n;
@@ -781,11 +772,12 @@ __global__ __launch_bounds__(1024) void ln_stream_fwd_wg_kernel(const LnStreamAr
       }
     s2 = wave_sum(s2);
     if (lane == 0) red[1][wave] = s2;
-    __syncthreads();
+    lds_barrier();
     float tot2 = 0.f;
     for (int w = 0; w < nwaves; ++w) tot2 += red[1][w];
     const float rs = rsqrtf(tot2 * inv_n + p.eps);
     if (ok) {
+      if (p.add) *(f32x8*)(p.h_out + hrow * p.ldh + tid * 8) = v;      // (behind the reductions: no store is pending at a barrier)
       const f32x8 g = cvt8(gm), b = cvt8(bt);
       f32x8 o;
 #pragma unroll
@@ -796,7 +788,7 @@ __global__ __launch_bounds__(1024) void ln_stream_fwd_wg_kernel(const LnStreamAr
       if (p.mean) p.mean[r] = mu;
       if (p.rstd) p.rstd[r] = rs;
     }
-    __syncthreads();      // red[] is reused by the next row of this workgroup
+    if (r + gridDim.x < p.rows) lds_barrier();      // red[] is reused by the next row of this workgroup
   }
 }
 
