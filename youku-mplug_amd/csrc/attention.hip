@@ -1571,11 +1571,11 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
   const bool cok = ch * 8 < hd;
   const bf16* kb = p.k + b * p.k_bs + h * p.k_hs + ch * 8;
   const bf16* vb = p.v + b * p.v_bs + h * p.v_hs + ch * 8;
-  f32x8 qv = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (cok) {
-    qv = cvt8(*(const bf16x8*)(p.q + b * p.q_bs + h * p.q_hs + ch * 8));
-    if (p.scale_q_bf16) qv = cvt8(cvt8(qv * p.scale));
-  }
+  // q is requested unconditionally (a chunk past head_dim re-reads chunk 0 and is zeroed) and first USED behind the first batch of
+  // K / V requests: inside `if (cok)` the compiler waited for it before anything else went out -- one more round trip in a chain of five
+  const bf16x8 q_raw = *(const bf16x8*)(p.q + b * p.q_bs + h * p.q_hs + (cok ? ch * 8 : 0));
+  f32x8 qv;
+  bool q_ready = false;
   const float sc = p.scale_q_bf16 ? 1.0f : p.scale;
   const bf16x8 zero8 = cvt8(f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
   // ---- scores.  The V rows of the first NPF chunks (NPF * 256 keys at head_dim 64: a caption's whole context) are requested in
@@ -1602,6 +1602,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
           vpre[c][u] = (cok && j < p.sk) ? *(const bf16x8*)(vb + (long long)j * p.v_rs) : zero8;
         }
       }
+    if (!q_ready) {
+      qv = cvt8(q_raw);
+      if (p.scale_q_bf16) qv = cvt8(cvt8(qv * p.scale));
+      if (!cok) qv = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      q_ready = true;
+    }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const f32x8 kf = cvt8(kv[u]);

@@ -83,26 +83,51 @@ __global__ __launch_bounds__(256) void adamw_grouped_kernel(bf16* __restrict__ p
     if (coef < 1.0f) gs *= coef;
   }
   const int lane4 = threadIdx.x & 63;       // 64 lanes x 4 elements = one 256-element tile per wave
-  const int wave = threadIdx.x >> 6;
-  for (long long t = (long long)blockIdx.x * 4 + wave; t < ntiles; t += (long long)gridDim.x * 4) {
-    const int grp = tile_group[t];
-    if (grp >= 8) continue;                  // padding / frozen tile
-    const float lr = hp.lr[grp], wd = hp.wd[grp];
-    const long long i = t * 256 + lane4 * 4;
-    f32x4 pp = *(const f32x4*)(p + i), mm = *(const f32x4*)(m + i), vv = *(const f32x4*)(v + i);
-    const f32x4 gg = cvt4(*(const bf16x4*)(g + i)) * gs;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // Two tiles per wave and iteration, every load unconditional (round 4): the tile's group id used to be fetched first and waited for
+  // (the `continue` of a padding tile made the data loads depend on it) -- two round trips per 3.5 KB of a wave.  Now the ids of the
+  // NEXT pair are requested with the current pair's data, padding tiles (rare) are loaded and computed like any other and only their
+  // stores are skipped.
+  const long long stride = (long long)gridDim.x * 8;
+  long long t = ((long long)blockIdx.x * 4 + wave) * 2;
+  if (t >= ntiles) return;
+  const long long last = ntiles - 1;
+  int g0 = tile_group[t], g1 = tile_group[min(t + 1, last)];
+  for (; t < ntiles; t += stride) {
+    const long long tn = t + stride;
+    const int n0 = tile_group[min(tn, last)], n1 = tile_group[min(tn + 1, last)];
+    const bool two = t + 1 < ntiles;
+    const long long i0 = t * 256 + lane4 * 4, i1 = (two ? t + 1 : t) * 256 + lane4 * 4;
+    f32x4 pa = *(const f32x4*)(p + i0), ma = *(const f32x4*)(m + i0), va = *(const f32x4*)(v + i0);
+    f32x4 pb = *(const f32x4*)(p + i1), mb = *(const f32x4*)(m + i1), vb = *(const f32x4*)(v + i1);
+    const f32x4 ga = cvt4(*(const bf16x4*)(g + i0)) * gs, gb = cvt4(*(const bf16x4*)(g + i1)) * gs;
+    auto upd = [&](f32x4& pp, f32x4& mm, f32x4& vv, const f32x4& gg, int grp) {
+      const float lr = hp.lr[grp & 7], wd = hp.wd[grp & 7];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      pp[e] *= (1.0f - lr * wd);
-      mm[e] = mm[e] * b1 + (1.0f - b1) * gg[e];
-      vv[e] = vv[e] * b2 + (1.0f - b2) * gg[e] * gg[e];
-      const float denom = sqrtf(vv[e]) * inv_sqrt_bc2 + eps;
-      pp[e] -= (lr * inv_bc1) * mm[e] / denom;
+      for (int e = 0; e < 4; ++e) {
+        pp[e] *= (1.0f - lr * wd);
+        mm[e] = mm[e] * b1 + (1.0f - b1) * gg[e];
+        vv[e] = vv[e] * b2 + (1.0f - b2) * gg[e] * gg[e];
+        const float denom = sqrtf(vv[e]) * inv_sqrt_bc2 + eps;
+        pp[e] -= (lr * inv_bc1) * mm[e] / denom;
+      }
+    };
+    upd(pa, ma, va, ga, g0);
+    upd(pb, mb, vb, gb, g1);
+    if (g0 < 8) {                            // (>= 8: padding / frozen tile)
+      *(f32x4*)(p + i0) = pa;
+      *(f32x4*)(m + i0) = ma;
+      *(f32x4*)(v + i0) = va;
+      *(bf16x4*)(p16 + i0) = cvt4(pa);
     }
-    *(f32x4*)(p + i) = pp;
-    *(f32x4*)(m + i) = mm;
-    *(f32x4*)(v + i) = vv;
-    *(bf16x4*)(p16 + i) = cvt4(pp);
+    if (two && g1 < 8) {
+      *(f32x4*)(p + i1) = pb;
+      *(f32x4*)(m + i1) = mb;
+      *(f32x4*)(v + i1) = vb;
+      *(bf16x4*)(p16 + i1) = cvt4(pb);
+    }
+    g0 = n0;
+    g1 = n1;
   }
 }
 
@@ -125,7 +150,7 @@ extern "C" int mpv_adamw_step_grouped(void* param_bf16, float* master, float* ex
   }
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   const long long ntiles = n / 256;
-  long long blocks = (ntiles + 3) / 4;
+  long long blocks = (ntiles + 7) / 8;      // a wave takes two tiles per iteration
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(adamw_grouped_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (bf16*)param_bf16, master, exp_avg,
                      exp_avg_sq, (const bf16*)grad_bf16, ntiles, tile_group, hp, beta1, beta2, eps, (float)(1.0 / bc1),
@@ -155,7 +180,7 @@ extern "C" int mpv_adamw_step_grouped_dev(void* param_bf16, float* master, float
   if (n == 0) return MPV_OK;
   GroupHyper hp = {};
   const long long ntiles = n / 256;
-  long long blocks = (ntiles + 3) / 4;
+  long long blocks = (ntiles + 7) / 8;      // a wave takes two tiles per iteration
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(adamw_grouped_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (bf16*)param_bf16, master, exp_avg,
                      exp_avg_sq, (const bf16*)grad_bf16, ntiles, tile_group, hp, beta1, beta2, eps, 1.0f, 1.0f, grad_scale, sumsq,
