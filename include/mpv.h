@@ -72,7 +72,8 @@ typedef struct mpv_gemm_epilogue {
   int a_group, a_stride, a_offset; /* row map on A rows (transA=0 only)                     */
   int c_group, c_stride, c_offset; /* row map on C / residual / preact rows                  */
   int k_group, k_stride, k_offset; /* row map on the reduction rows (transposed operands)    */
-  const void* bias;                /* bf16 [N] or NULL                                        */
+  const void* bias;                /* bf16 [N] or NULL (16-byte aligned for the 256x256 kernel, which fetches a tile's slice by
+                                      LDS-DMA; any other alignment is taken by the 128x128 kernel) */
   int act;                         /* MPV_ACT_*: y = act(bf16(acc + bias))                    */
   void* preact_out;                /* optional bf16 copy of (acc + bias) before act (ldc)     */
   const void* residual;            /* optional bf16 [.,N] added last (leading dim ldr)        */
