@@ -323,3 +323,21 @@ def test_gemm256_split_forward_with_bias_and_dropout_in_the_reduce(dev, M, N, K)
     close(d_new[kept], (ref / 0.9)[kept], 1e-2, "split forward + bias + dropout")
     for _ in range(5):
         assert torch.equal(d_new, ops.gemm(a, w, M, N, K, **kw))
+
+
+@pytest.mark.parametrize("M,N,K", [(1576, 768, 768), (520, 1032, 2048)])
+def test_gemm_bias_slice_of_any_alignment(dev, M, N, K):
+    """The 256x256 kernel fetches a tile's bias slice by 16-byte LDS-DMA (csrc/gemm256.hip, round 4); a bias that is only 8-byte
+    aligned -- a slice of a packed bias vector, as the packed q / k / v biases are -- is taken by the 128x128 kernel instead
+    (include/mpv.h).  Both must give the fp32 answer, and a 16-byte aligned slice at a non-zero offset must be bit-identical to a
+    private copy of it (ragged N: the slice's tail past column N is zero-filled by the DMA, never read from the neighbour)."""
+    from youku_mplug_amd import ops
+    a, w = rn(M, K, dev=dev, seed=31), rn(N, K, dev=dev, seed=32, scale=0.1)
+    packed = rn(3 * N + 16, dev=dev, seed=33)
+    ref = a.float() @ w.float().t()
+    for off in (0, 8, 4, N + 8):                        # 16-byte aligned: 0, 8, N + 8; 8-byte aligned only: 4
+        b = packed[off:off + N]
+        o = ops.gemm(a, w, M, N, K, bias=b)
+        close(o, ref + b.float(), 1e-2, f"bias slice at element {off}")
+        if off % 8 == 0:
+            assert torch.equal(o, ops.gemm(a, w, M, N, K, bias=b.clone())), off
