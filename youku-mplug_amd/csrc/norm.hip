@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256, PF ? 3 : MAXC <= 2 ? 4 : MAXC <= 3 ? 2 : 1) vo
       float c1 = 0.f, c2 = 0.f;
 #pragma unroll
       for (int i = 0; i < MAXC; ++i) {
-        const bool ok = lane + 64 * i < nchunk;       // chunks past the row hold x = dy = 0: g = 0, but x-hat = -mu * rs is not
+        // (chunks past the row hold x = dy = 0: g = 0 and dy * x-hat = 0 -- they add nothing to the sums although their x-hat = -mu * rs is not 0)
         const f32x8 xv = cvt8(xb[i]), dv = cvt8(db[i]), gm = cvt8(gmb[i]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -444,7 +444,6 @@ __global__ __launch_bounds__(256, PF ? 3 : MAXC <= 2 ? 4 : MAXC <= 3 ? 2 : 1) vo
             bacc[i][e] += dv[e];
           }
         }
-        (void)ok;
       }
       c1 = wave_sum(c1) * inv_n;
       c2 = wave_sum(c2) * inv_n;
