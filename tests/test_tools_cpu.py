@@ -86,3 +86,14 @@ def test_rocpd_gaps_on_a_synthetic_trace(tmp_path, capsys):
     assert "idle between dispatches 0.00 ms/step" in out or "idle between dispatches 0.003 ms/step" in out or "0.00 ms/step" in out
     assert "| `b` | 3 | 0.01 | 3.00 |" in out, out
     assert "pauses > 200 us (host bookkeeping between steps): 0.4 ms" in out, out
+
+
+def test_g256p_probe_layout_model():
+    """tools/probe/sim_g256p_layout.py: the index arithmetic of the persistent 4-wave GEMM probe (tools/probe/g256p_probe.hip, not
+    a product path, not yet run on a GPU) -- DMA image / fragment reads / bank conflicts / the permlane way out -- holds on the host."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sim_g256p_layout", os.path.join(ROOT, "tools", "probe", "sim_g256p_layout.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert m.check_fragments() == 1          # conflict-free under the hardware lane groups of ds_read_b128
+    assert m.check_way_out(768) and m.check_way_out(2304)
