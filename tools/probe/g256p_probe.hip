@@ -205,12 +205,12 @@ __global__ __launch_bounds__(256) void g256p(const bf16* __restrict__ A, const b
     __builtin_amdgcn_raw_buffer_store_b128(v.i, c_prev, cl + (uint32_t)(p * 64), (uint32_t)(mb * 16 * ldc * 2), 0);
   };
 
-  // bias of a tile as raw bf16 (16 registers), requested one K-tile before the tile ends
+  // bias of a tile as raw bf16 (16 registers), requested one K-step before the tile ends
   bf16x4 braw[8];
   const __amdgpu_buffer_rsrc_t bias_rs = make_rsrc(bias, (uint32_t)N * 2u);
   // Inline asm on purpose: a load the compiler knows about is waited for with ITS count of younger requests -- it cannot see the
   // LDS-DMA instructions, so `s_waitcnt vmcnt(0)` in front of the first use drained the whole ring once per tile.  These are
-  // requested in front of a K-step's DMA batch; that step's own vmcnt(8) retires them, two K-steps before they are used.
+  // requested in front of the last K-step's DMA batch; that step's own vmcnt(8) retires them, right before they are used.
   auto load_bias = [&](int t) __attribute__((always_inline)) {
     const int tn = t % tiles_n;
     const uint32_t lo = (uint32_t)((wc * 128 + (fresh_lane() >> 4) * 4) * 2), so = (uint32_t)(tn * TN * 2);
@@ -367,8 +367,8 @@ __global__ __launch_bounds__(256) void g256p(const bf16* __restrict__ A, const b
       substep(IC<0>{}, IC<-1>{});
       substep(IC<1>{}, IC<-1>{});
     }
-    load_bias(tile);                                     // this tile's bias, one K-tile before its conversion (unconditional: see first_step)
     substep(IC<0>{}, IC<-1>{});
+    load_bias(tile);                                     // this tile's bias, one K-step before its conversion, in front of that step's DMA batch
     last_substep();
     // this tile becomes the one on its way out
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
