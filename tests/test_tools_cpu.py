@@ -97,3 +97,9 @@ def test_g256p_probe_layout_model():
     spec.loader.exec_module(m)
     assert m.check_fragments() == 1          # conflict-free under the hardware lane groups of ds_read_b128
     assert m.check_way_out(768) and m.check_way_out(2304)
+    spec = importlib.util.spec_from_file_location("sim_g256p_ring", os.path.join(ROOT, "tools", "probe", "sim_g256p_ring.py"))
+    r = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(r)
+    for tiles in (1, 2, 4):                  # the ring protocol: no refill without a barrier behind the last read, no read before a counted wait + barrier
+        for nk in (10, 12, 37):
+            assert r.run(tiles, nk) > 0
