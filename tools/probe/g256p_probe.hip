@@ -174,6 +174,7 @@ __global__ __launch_bounds__(256) void g256p(const bf16* __restrict__ A, const b
 #pragma unroll
     for (int i = 0; i < 8; ++i) fa[buf][i] = *(const bf16x8*)(nbase + a_lane + i * 1024);
   };
+  auto read_a_one = [&](auto BUF, int i) __attribute__((always_inline)) { fa[decltype(BUF)::value][i] = *(const bf16x8*)(nbase + a_lane + i * 1024); };
   auto read_b = [&](int nb) __attribute__((always_inline)) { fb[nb] = *(const bf16x8*)(nbase + b_lane + nb * 1024); };      // nb < 7
   auto read_b7 = [&](auto BUF) __attribute__((always_inline)) { fb7[decltype(BUF)::value] = *(const bf16x8*)(nbase + b_lane + 7 * 1024); };
   f32x4 acc[8][8];
@@ -225,52 +226,54 @@ __global__ __launch_bounds__(256) void g256p(const bf16* __restrict__ A, const b
   };
 
   // ---- one K-step: issue three ahead, carry two parked pieces out, read the next step's fragments, 64 MFMAs, counted wait, barrier
-  auto mma_col = [&](auto BUF, auto NB, auto PF) __attribute__((always_inline)) {      // column block nb: eight MFMAs, then its refill for the next K-step and one DMA instruction
-    constexpr int buf = decltype(BUF)::value, nb = decltype(NB)::value;
+  // column block nb of a K-step: eight MFMAs, and in their shadow (one wave feeds its SIMD: whatever is issued in FRONT of a step's
+  // first MFMA idles the matrix pipe) one of everything the step owes: the refill of this column's B fragment and of A fragment nb
+  // for the next K-step, one DMA instruction, and -- behind columns 1 and 2 -- one parked piece of the previous tile on its way out
+  auto mma_col = [&](auto BUF, auto NB, auto PF, auto TRK) __attribute__((always_inline)) {
+    constexpr int buf = decltype(BUF)::value, nb = decltype(NB)::value, trk = decltype(TRK)::value;
     constexpr bool pf = decltype(PF)::value != 0;
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) {
       if constexpr (nb < 7) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nb], fa[buf][mb], acc[mb][nb], 0, 0, 0);
       else acc[mb][7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb7[buf], fa[buf][mb], acc[mb][7], 0, 0, 0);
     }
-    if constexpr (nb < 7 && pf) read_b(nb);
+    if constexpr (pf) {
+      if constexpr (nb < 7) read_b(nb);
+      if constexpr (nb == 0) {           // (nothing is read behind the LAST column: the step's closing lgkmcnt(0) would wait for it)
+        read_a_one(IC<buf ^ 1>{}, 0);
+        read_b7(IC<buf ^ 1>{});
+      }
+      if constexpr (nb < 7) read_a_one(IC<buf ^ 1>{}, nb + 1);
+    }
+    if constexpr (trk >= 0 && (nb == 1 || nb == 2)) {
+      if (prev_valid) store_piece(IC<(trk >= 0 ? trk : 0) + (nb - 1)>{}, park_addr(), c_lane_off());
+    }
     issue_one(NB);
   };
-  auto mma = [&](auto BUF, auto PF) __attribute__((always_inline)) {    // 64 MFMAs of the current K-step; B fragments of the next one roll in behind them
-    mma_col(BUF, IC<0>{}, PF); mma_col(BUF, IC<1>{}, PF); mma_col(BUF, IC<2>{}, PF); mma_col(BUF, IC<3>{}, PF);
-    mma_col(BUF, IC<4>{}, PF); mma_col(BUF, IC<5>{}, PF); mma_col(BUF, IC<6>{}, PF); mma_col(BUF, IC<7>{}, PF);
+  auto mma = [&](auto BUF, auto PF, auto TRK) __attribute__((always_inline)) {
+    mma_col(BUF, IC<0>{}, PF, TRK); mma_col(BUF, IC<1>{}, PF, TRK); mma_col(BUF, IC<2>{}, PF, TRK); mma_col(BUF, IC<3>{}, PF, TRK);
+    mma_col(BUF, IC<4>{}, PF, TRK); mma_col(BUF, IC<5>{}, PF, TRK); mma_col(BUF, IC<6>{}, PF, TRK); mma_col(BUF, IC<7>{}, PF, TRK);
     issue_end();
   };
   auto end_step = [&]() __attribute__((always_inline)) {
     SB();
-    __builtin_amdgcn_s_waitcnt(0x0078);      // vmcnt(8): everything older than the eight DMA instructions just issued has landed -- the
-                                             // trickled stores go out BEFORE those, so the count is exact whatever order stores and
-                                             // loads complete in; lgkmcnt(0): this wave's fragment reads of the slot the next K-step
-                                             // refills are done
+    __builtin_amdgcn_s_waitcnt(0x0078);      // vmcnt(8): at most the eight youngest requests are still out -- this step's DMA batch (its first
+                                             // two instructions too must have landed in a step that also trickled two stores: harmless,
+                                             // they are ~900 clocks old); loads complete in order, so everything older has landed whatever
+                                             // the stores do; lgkmcnt(0): this wave's reads of the slot the next K-step refills are done
     __builtin_amdgcn_s_barrier();
     SB();
   };
   auto substep = [&](auto BUF, auto TRK) __attribute__((always_inline)) {
-    constexpr int buf = decltype(BUF)::value, trk = decltype(TRK)::value;
-    if constexpr (trk >= 0) {
-      if (prev_valid) {
-        const char* pk = park_addr();
-        const uint32_t cl = c_lane_off();
-        store_piece(IC<trk>{}, pk, cl);
-        store_piece(IC<trk + 1>{}, pk, cl);
-      }
-    }
     issue_begin();
     next_slot();
-    read_a(IC<buf ^ 1>{});
-    read_b7(IC<buf ^ 1>{});
-    mma(BUF, IC<1>{});
+    mma(BUF, IC<1>{}, TRK);
     end_step();
   };
   // the last K-step of a tile does NOT fetch the next tile's first fragments: the conversion that follows needs the 64 registers
   auto last_substep = [&]() __attribute__((always_inline)) {
     issue_begin();
-    mma(IC<1>{}, IC<0>{});
+    mma(IC<1>{}, IC<0>{}, IC<-1>{});
     end_step();
   };
   // K-step 0 of a tile: column pair by column pair, the finished accumulators of the previous tile are converted and parked right
@@ -308,6 +311,9 @@ __global__ __launch_bounds__(256) void g256p(const bf16* __restrict__ A, const b
       }
       read_b(2 * p);
       if constexpr (p < 3) read_b(2 * p + 1);
+      read_a_one(IC<1>{}, 2 * p);
+      read_a_one(IC<1>{}, 2 * p + 1);
+      if constexpr (p == 0) read_b7(IC<1>{});
       issue_one(IC<2 * p>{});
       issue_one(IC<2 * p + 1>{});
     };
@@ -328,8 +334,6 @@ __global__ __launch_bounds__(256) void g256p(const bf16* __restrict__ A, const b
     }
     if (have_next) {
       issue_end();
-      read_b7(IC<1>{});
-      read_a(IC<1>{});      // (behind the conversion, not in front of it: this step is where the register file is fullest -- K-step 1 pays ~one LDS latency for it)
       end_step();
     }
   };
