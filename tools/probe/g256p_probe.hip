@@ -21,7 +21,7 @@
 //    merged into 8 consecutive columns per lane by v_permlane16_swap (odd 16-lane rows of one register <-> even rows of the other).
 //  * The bias is added at the conversion (as the C operand of a tile's first MFMAs it would have to sit in AGPRs, which are full).
 // NT form only (A [M][K], B [N][K], both k-contiguous), M % 256 == N % 256 == 0, K % 64 == 0, K >= 640.
-// Build: hipcc --offload-arch=gfx950 -O3 -o g256p_probe g256p_probe.hip ; run: ./g256p_probe M N K
+// Build: hipcc --offload-arch=gfx950 -O3 -o g256p_probe g256p_probe.hip ; run: timeout 30 ./g256p_probe M N K [0|1]  (both variants, or one)
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -94,6 +94,10 @@ __device__ __forceinline__ Piece make_piece(f32x4 x, f32x4 y, f32x4 bx, f32x4 by
   return p;
 }
 
+// PARK = 1: the full scheme.  PARK = 0: the same persistent ring and main loop, but a finished tile is converted and stored at once
+// (exposed) -- the reference point that separates "does the ring / the way out work" from "does the parked epilogue work", and the
+// denominator of what parking buys.
+template <int PARK>
 __global__ __launch_bounds__(256) void g256p(const bf16* __restrict__ A, const bf16* __restrict__ B, const bf16* __restrict__ bias,
                                              bf16* __restrict__ C, int M, int N, int K, int tiles_n, int ntiles) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(256) void g256p(const bf16* __restrict__ A, const b
       }
       if constexpr (nb < 7) read_a_one(IC<buf ^ 1>{}, nb + 1);
     }
-    if constexpr (trk >= 0 && (nb == 1 || nb == 2)) {
+    if constexpr (PARK && trk >= 0 && (nb == 1 || nb == 2)) {
       if (prev_valid) store_piece(IC<(trk >= 0 ? trk : 0) + (nb - 1)>{}, park_addr(), c_lane_off());
     }
     issue_one(NB);
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(256) void g256p(const bf16* __restrict__ A, const b
   };
   // K-step 0 of a tile: column pair by column pair, the finished accumulators of the previous tile are converted and parked right
   // before the new tile's first MFMAs (C operand = its bias) overwrite them
-  auto first_step = [&](bool have_next) __attribute__((always_inline)) {
+  auto first_step = [&](bool have_next, bool convert) __attribute__((always_inline)) {
     char* pk_w = park_addr();
     // v0: the conversion is a phase of its own (~2k VALU clocks per tile, exposed).  Interleaved column pair by column pair with the new
     // tile's first MFMAs into the same registers it overlaps half of that, but hipcc then keeps old and new accumulators apart and
@@ -296,10 +300,12 @@ __global__ __launch_bounds__(256) void g256p(const bf16* __restrict__ A, const b
       }
       SB();
     };
-    convert_pair(IC<2>{});      // the LDS-parked pairs first: their bias registers are dead before the 64 park registers fill up
-    convert_pair(IC<3>{});
-    convert_pair(IC<0>{});
-    convert_pair(IC<1>{});
+    if (convert) {
+      convert_pair(IC<2>{});      // the LDS-parked pairs first: their bias registers are dead before the 64 park registers fill up
+      convert_pair(IC<3>{});
+      convert_pair(IC<0>{});
+      convert_pair(IC<1>{});
+    }
     auto first_pair = [&](auto P) __attribute__((always_inline)) {      // K-step 0 of the new tile: C = 0
       constexpr int p = decltype(P)::value;
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -338,6 +344,19 @@ __global__ __launch_bounds__(256) void g256p(const bf16* __restrict__ A, const b
     }
   };
 
+  auto flush_all = [&]() __attribute__((always_inline)) {
+    const char* pk = park_addr();
+    const uint32_t cl = c_lane_off();
+    store_piece(IC<0>{}, pk, cl); store_piece(IC<1>{}, pk, cl); store_piece(IC<2>{}, pk, cl); store_piece(IC<3>{}, pk, cl);
+    store_piece(IC<4>{}, pk, cl); store_piece(IC<5>{}, pk, cl); store_piece(IC<6>{}, pk, cl); store_piece(IC<7>{}, pk, cl);
+    store_piece(IC<8>{}, pk, cl); store_piece(IC<9>{}, pk, cl); store_piece(IC<10>{}, pk, cl); store_piece(IC<11>{}, pk, cl);
+    store_piece(IC<12>{}, pk, cl); store_piece(IC<13>{}, pk, cl); store_piece(IC<14>{}, pk, cl); store_piece(IC<15>{}, pk, cl);
+    store_piece(IC<16>{}, pk, cl); store_piece(IC<17>{}, pk, cl); store_piece(IC<18>{}, pk, cl); store_piece(IC<19>{}, pk, cl);
+    store_piece(IC<20>{}, pk, cl); store_piece(IC<21>{}, pk, cl); store_piece(IC<22>{}, pk, cl); store_piece(IC<23>{}, pk, cl);
+    store_piece(IC<24>{}, pk, cl); store_piece(IC<25>{}, pk, cl); store_piece(IC<26>{}, pk, cl); store_piece(IC<27>{}, pk, cl);
+    store_piece(IC<28>{}, pk, cl); store_piece(IC<29>{}, pk, cl); store_piece(IC<30>{}, pk, cl); store_piece(IC<31>{}, pk, cl);
+  };
+
   // ---- prologue (once per workgroup): K-steps 0, 1, 2 of the first tile; fragments of K-step 0
   issue_next();
   issue_next();
@@ -347,7 +366,7 @@ __global__ __launch_bounds__(256) void g256p(const bf16* __restrict__ A, const b
   __builtin_amdgcn_s_barrier();
 
   for (int tile = blockIdx.x; tile < ntiles; tile += G) {
-    first_step(true);                        // K-step 0 (+ the previous tile's conversion)
+    first_step(true, PARK != 0);             // K-step 0 (+ the previous tile's conversion)
     substep(IC<1>{}, IC<0>{});               // K-step 1: pieces 0, 1
     // K-steps 2 .. 16: pieces 2 (s - 1), 2 (s - 1) + 1
     substep(IC<0>{}, IC<2>{});
@@ -378,20 +397,15 @@ __global__ __launch_bounds__(256) void g256p(const bf16* __restrict__ A, const b
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     c_prev = make_rsrc(C + ((long long)tm * TM * ldc + tn * TN), tile_bytes);
     prev_valid = true;
+    if constexpr (!PARK) {                   // reference point: convert and store the tile here, exposed
+      first_step(false, true);
+      flush_all();
+    }
   }
   // ---- after the last tile: convert, park and store everything (exposed: nothing left to hide it under)
-  first_step(false);
-  {
-    const char* pk = park_addr();
-    const uint32_t cl = c_lane_off();
-    store_piece(IC<0>{}, pk, cl); store_piece(IC<1>{}, pk, cl); store_piece(IC<2>{}, pk, cl); store_piece(IC<3>{}, pk, cl);
-    store_piece(IC<4>{}, pk, cl); store_piece(IC<5>{}, pk, cl); store_piece(IC<6>{}, pk, cl); store_piece(IC<7>{}, pk, cl);
-    store_piece(IC<8>{}, pk, cl); store_piece(IC<9>{}, pk, cl); store_piece(IC<10>{}, pk, cl); store_piece(IC<11>{}, pk, cl);
-    store_piece(IC<12>{}, pk, cl); store_piece(IC<13>{}, pk, cl); store_piece(IC<14>{}, pk, cl); store_piece(IC<15>{}, pk, cl);
-    store_piece(IC<16>{}, pk, cl); store_piece(IC<17>{}, pk, cl); store_piece(IC<18>{}, pk, cl); store_piece(IC<19>{}, pk, cl);
-    store_piece(IC<20>{}, pk, cl); store_piece(IC<21>{}, pk, cl); store_piece(IC<22>{}, pk, cl); store_piece(IC<23>{}, pk, cl);
-    store_piece(IC<24>{}, pk, cl); store_piece(IC<25>{}, pk, cl); store_piece(IC<26>{}, pk, cl); store_piece(IC<27>{}, pk, cl);
-    store_piece(IC<28>{}, pk, cl); store_piece(IC<29>{}, pk, cl); store_piece(IC<30>{}, pk, cl); store_piece(IC<31>{}, pk, cl);
+  if constexpr (PARK) {
+    first_step(false, true);
+    flush_all();
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);        // the dead DMA units have been zero-filled before the workgroup leaves
 }
@@ -428,39 +442,49 @@ int main(int argc, char** argv) {
   hipMemcpy(dB, hb.data(), hb.size() * 2, hipMemcpyHostToDevice);
   hipMemcpy(dBias, hbias.data(), hbias.size() * 2, hipMemcpyHostToDevice);
   hipMemset(dC, 0xff, hc.size() * 2);
-  (void)hipFuncSetAttribute((const void*)g256p, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+  (void)hipFuncSetAttribute((const void*)g256p<0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+  (void)hipFuncSetAttribute((const void*)g256p<1>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
   int dev = 0, ncu = 256;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
   const int tiles_m = M / TM, tiles_n = N / TN, ntiles = tiles_m * tiles_n;
   const int grid = ntiles < ncu ? ntiles : ncu;
-  auto launch = [&]() __attribute__((always_inline)) { hipLaunchKernelGGL(g256p, dim3(grid), dim3(256), SMEM, 0, dA, dB, dBias, dC, M, N, K, tiles_n, ntiles); };
-  launch();
-  hipError_t e = hipDeviceSynchronize();
-  if (e != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(e)); return 1; }
-  hipMemcpy(hc.data(), dC, hc.size() * 2, hipMemcpyDeviceToHost);
-  double maxerr = 0;
-  for (int t = 0; t < 6000; ++t) {
-    st = st * 1664525u + 1013904223u; int m = (st >> 4) % M;
-    st = st * 1664525u + 1013904223u; int n = (st >> 4) % N;
-    if (t < 512) { m = (t & 1) ? M - 1 - (t >> 1) % 256 : (t >> 1) % 256; n = (t * 37) % N; }      // first and last tile rows, every column class
-    double ref = bf2f_host(hbias[n]);
-    for (int k = 0; k < K; ++k) ref += (double)bf2f_host(ha[(size_t)m * K + k]) * bf2f_host(hb[(size_t)n * K + k]);
-    const double err = fabs(ref - bf2f_host(hc[(size_t)m * N + n])) / (fabs(ref) + 1.0);
-    if (!(err <= maxerr)) maxerr = err;
+  const int only = argc > 4 ? atoi(argv[4]) : -1;            // 0 / 1: run one variant only
+  for (int park = 0; park < 2; ++park) {
+    if (only >= 0 && only != park) continue;
+    auto launch = [&]() {
+      if (park) hipLaunchKernelGGL(g256p<1>, dim3(grid), dim3(256), SMEM, 0, dA, dB, dBias, dC, M, N, K, tiles_n, ntiles);
+      else hipLaunchKernelGGL(g256p<0>, dim3(grid), dim3(256), SMEM, 0, dA, dB, dBias, dC, M, N, K, tiles_n, ntiles);
+    };
+    hipMemset(dC, 0xff, hc.size() * 2);
+    launch();
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) { printf("park=%d: launch failed: %s\n", park, hipGetErrorString(e)); return 1; }
+    hipMemcpy(hc.data(), dC, hc.size() * 2, hipMemcpyDeviceToHost);
+    double maxerr = 0;
+    uint32_t sv = 777;
+    for (int t = 0; t < 6000; ++t) {
+      sv = sv * 1664525u + 1013904223u; int m = (sv >> 4) % M;
+      sv = sv * 1664525u + 1013904223u; int n = (sv >> 4) % N;
+      if (t < 512) { m = (t & 1) ? M - 1 - (t >> 1) % 256 : (t >> 1) % 256; n = (t * 37) % N; }      // first and last tile rows, every column class
+      double ref = bf2f_host(hbias[n]);
+      for (int k = 0; k < K; ++k) ref += (double)bf2f_host(ha[(size_t)m * K + k]) * bf2f_host(hb[(size_t)n * K + k]);
+      const double err = fabs(ref - bf2f_host(hc[(size_t)m * N + n])) / (fabs(ref) + 1.0);
+      if (!(err <= maxerr)) maxerr = err;
+    }
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) launch();
+    hipEventRecord(e0);
+    const int it = 20;
+    for (int i = 0; i < it; ++i) launch();
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double t = ms / it * 1e-3;
+    printf("g256p<park=%d> (4 waves x 128x128, persistent ring%s; %d workgroups for %d tiles) M=%d N=%d K=%d: %.1f us  %.1f TFLOP/s  max rel err %.3g %s\n", park,
+           park ? ", parked epilogue" : ", exposed epilogue", grid, ntiles, M, N, K, t * 1e6, 2.0 * M * N * K / t / 1e12, maxerr, maxerr < 2e-2 ? "(ok)" : "(WRONG)");
   }
-  hipEvent_t e0, e1;
-  hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 3; ++i) launch();
-  hipEventRecord(e0);
-  const int it = 20;
-  for (int i = 0; i < it; ++i) launch();
-  hipEventRecord(e1);
-  hipEventSynchronize(e1);
-  float ms;
-  hipEventElapsedTime(&ms, e0, e1);
-  const double t = ms / it * 1e-3;
-  printf("g256p (4 waves x 128x128, persistent, parked epilogue; %d workgroups for %d tiles) M=%d N=%d K=%d: %.1f us  %.1f TFLOP/s  max rel err %.3g %s\n", grid, ntiles, M, N,
-         K, t * 1e6, 2.0 * M * N * K / t / 1e12, maxerr, maxerr < 2e-2 ? "(ok)" : "(WRONG)");
   return 0;
 }
