@@ -12,8 +12,8 @@
 //    parked in 64 KiB of LDS (a wave-private spill area: no barrier).  The workgroup is PERSISTENT: the LDS-DMA ring keeps running
 //    across tile boundaries (the next tile's first K-steps arrive while the current tile finishes: no prologue), and the parked
 //    tile leaves through two 16-byte stores per K-step under the next tile's MFMAs (store issue: 8 per 1024 clocks per CU against
-//    the ~74-clock limit).  The conversion of the finished accumulators is interleaved, column pair by column pair, with the next
-//    tile's first MFMAs into the same registers.
+//    the ~74-clock limit).  The conversion of the finished accumulators happens DURING the tile's last K-step: a column pair is final
+//    once its MFMAs of that step are issued and is converted in the shadow of the later columns' MFMAs (only the last pair is exposed).
 //  * K-steps of 32 through a ring of THREE slots of (A 256 x 32, B 256 x 32) = 96 KiB; one barrier per K-step (the production
 //    kernel: eight per 64).  Image of a unit: [256 rows][64 B], 16-byte chunk c of row r at position c ^ f4((r >> 2) & 3) (applied to
 //    the DMA's global source address and to the ds_read_b128 fragment address; tools/probe/sim_g256p_layout.py checks both).
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void g256p(const bf16* __restrict__ A, const b
   const __amdgpu_buffer_rsrc_t bias_rs = make_rsrc(bias, (uint32_t)N * 2u);
   // Inline asm on purpose: a load the compiler knows about is waited for with ITS count of younger requests -- it cannot see the
   // LDS-DMA instructions, so `s_waitcnt vmcnt(0)` in front of the first use drained the whole ring once per tile.  These are
-  // requested in front of the last K-step's DMA batch; that step's own vmcnt(8) retires them, right before they are used.
+  // requested in front of the second-to-last K-step's DMA batch; that step's own vmcnt(8) retires them, one K-step before they are used.
   auto load_bias = [&](int t) __attribute__((always_inline)) {
     const int tn = t % tiles_n;
     const uint32_t lo = (uint32_t)((wc * 128 + (fresh_lane() >> 4) * 4) * 2), so = (uint32_t)(tn * TN * 2);
@@ -274,39 +274,47 @@ __global__ __launch_bounds__(256) void g256p(const bf16* __restrict__ A, const b
     mma(BUF, IC<1>{}, TRK);
     end_step();
   };
-  // the last K-step of a tile does NOT fetch the next tile's first fragments: the conversion that follows needs the 64 registers
+  // The finished tile leaves the accumulators DURING its last K-step: a column pair is final as soon as its sixteen MFMAs of that step
+  // are issued, and is converted (AGPR -> VGPR, + bias, -> bf16, two column blocks merged into 16-byte row pieces) one pair behind, in
+  // the shadow of the later pairs' MFMAs -- only the last pair's conversion is exposed.  (Converting in front of the NEXT tile's first
+  // MFMAs into the same registers is what one would write in assembly; hipcc keeps old and new accumulators apart and spills.)
+  // Pieces of pairs 0, 1 stay in registers, those of pairs 2, 3 go to the wave's LDS park.
+  auto convert_pair = [&](auto P, char* pk_w) __attribute__((always_inline)) {
+    constexpr int p = decltype(P)::value;
+    const f32x4 b0 = cvt4(braw[2 * p]), b1 = cvt4(braw[2 * p + 1]);
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+      const Piece v = make_piece(acc[mb][2 * p], acc[mb][2 * p + 1], b0, b1);
+      if constexpr (p < 2) park[p * 8 + mb] = v;
+      else *(i32x4*)(pk_w + ((p - 2) * 8 + mb) * 1024) = v.i;
+    }
+  };
+  // the last K-step of a tile: no fragments fetched ahead (the first step of the next tile reads its own), conversion in the shadow
   auto last_substep = [&]() __attribute__((always_inline)) {
     issue_begin();
-    mma(IC<1>{}, IC<0>{}, IC<-1>{});
+    char* pk_w = park_addr();
+    mma_col(IC<1>{}, IC<0>{}, IC<0>{}, IC<-1>{});
+    mma_col(IC<1>{}, IC<1>{}, IC<0>{}, IC<-1>{});
+    SB();
+    mma_col(IC<1>{}, IC<2>{}, IC<0>{}, IC<-1>{});
+    mma_col(IC<1>{}, IC<3>{}, IC<0>{}, IC<-1>{});
+    convert_pair(IC<0>{}, pk_w);
+    SB();
+    mma_col(IC<1>{}, IC<4>{}, IC<0>{}, IC<-1>{});
+    mma_col(IC<1>{}, IC<5>{}, IC<0>{}, IC<-1>{});
+    convert_pair(IC<1>{}, pk_w);
+    SB();
+    mma_col(IC<1>{}, IC<6>{}, IC<0>{}, IC<-1>{});
+    convert_pair(IC<2>{}, pk_w);
+    SB();
+    mma_col(IC<1>{}, IC<7>{}, IC<0>{}, IC<-1>{});
+    issue_end();
+    convert_pair(IC<3>{}, pk_w);                         // (exposed: the last pair is only final now)
     end_step();
   };
-  // K-step 0 of a tile: column pair by column pair, the finished accumulators of the previous tile are converted and parked right
-  // before the new tile's first MFMAs (C operand = its bias) overwrite them
-  auto first_step = [&](bool have_next, bool convert) __attribute__((always_inline)) {
-    char* pk_w = park_addr();
-    // v0: the conversion is a phase of its own (~2k VALU clocks per tile, exposed).  Interleaved column pair by column pair with the new
-    // tile's first MFMAs into the same registers it overlaps half of that, but hipcc then keeps old and new accumulators apart and
-    // spills (tools/probe/README.md); to be redone in assembly once the rest is validated.
-    auto convert_pair = [&](auto P) __attribute__((always_inline)) {
-      constexpr int p = decltype(P)::value;
-      const f32x4 b0 = cvt4(braw[2 * p]), b1 = cvt4(braw[2 * p + 1]);      // the FINISHED tile's bias (requested one K-tile before its end)
-#pragma unroll
-      for (int mb = 0; mb < 8; ++mb) {
-        // (unconditional: before the first tile this parks garbage that is never stored -- a conditional write would keep the 64 park
-        // registers live around the whole loop)
-        const Piece v = make_piece(acc[mb][2 * p], acc[mb][2 * p + 1], b0, b1);
-        if constexpr (p < 2) park[p * 8 + mb] = v;
-        else *(i32x4*)(pk_w + ((p - 2) * 8 + mb) * 1024) = v.i;
-      }
-      SB();
-    };
-    if (convert) {
-      convert_pair(IC<2>{});      // the LDS-parked pairs first: their bias registers are dead before the 64 park registers fill up
-      convert_pair(IC<3>{});
-      convert_pair(IC<0>{});
-      convert_pair(IC<1>{});
-    }
-    auto first_pair = [&](auto P) __attribute__((always_inline)) {      // K-step 0 of the new tile: C = 0
+  // K-step 0 of a tile: its fragments are read here (the previous step fetched nothing ahead), C = 0
+  auto first_step = [&]() __attribute__((always_inline)) {
+    auto first_pair = [&](auto P) __attribute__((always_inline)) {
       constexpr int p = decltype(P)::value;
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -323,25 +331,21 @@ __global__ __launch_bounds__(256) void g256p(const bf16* __restrict__ A, const b
       issue_one(IC<2 * p>{});
       issue_one(IC<2 * p + 1>{});
     };
-    if (have_next) {
-      next_slot();                                     // K-step 0 of the new tile (landed and published two barriers ago)
-      read_a(IC<0>{});
+    next_slot();                                       // K-step 0 of the new tile (landed and published two barriers ago)
+    read_a(IC<0>{});
 #pragma unroll
-      for (int nb = 0; nb < 7; ++nb) read_b(nb);
-      read_b7(IC<0>{});
-      __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0) + barrier: this step's DMA batch refills the very slot just read
-      __builtin_amdgcn_s_barrier();                    // (in every other K-step the fragments were read one step -- one barrier -- earlier)
-      issue_begin();
-      next_slot();                                     // ... and K-step 1 rolls in behind its MFMAs
-      first_pair(IC<0>{});
-      first_pair(IC<1>{});
-      first_pair(IC<2>{});
-      first_pair(IC<3>{});
-    }
-    if (have_next) {
-      issue_end();
-      end_step();
-    }
+    for (int nb = 0; nb < 7; ++nb) read_b(nb);
+    read_b7(IC<0>{});
+    __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0) + barrier: this step's DMA batch refills the very slot just read
+    __builtin_amdgcn_s_barrier();                      // (in every other K-step the fragments were read one step -- one barrier -- earlier)
+    issue_begin();
+    next_slot();                                       // ... and K-step 1 rolls in behind its MFMAs
+    first_pair(IC<0>{});
+    first_pair(IC<1>{});
+    first_pair(IC<2>{});
+    first_pair(IC<3>{});
+    issue_end();
+    end_step();
   };
 
   auto flush_all = [&]() __attribute__((always_inline)) {
@@ -361,12 +365,11 @@ __global__ __launch_bounds__(256) void g256p(const bf16* __restrict__ A, const b
   issue_next();
   issue_next();
   issue_next();
-  load_bias(blockIdx.x);      // (defines the registers: the first conversion adds it to garbage that is never stored)
   __builtin_amdgcn_s_waitcnt(0x0F70);        // (vmcnt(0): simple, once)
   __builtin_amdgcn_s_barrier();
 
   for (int tile = blockIdx.x; tile < ntiles; tile += G) {
-    first_step(true, PARK != 0);             // K-step 0 (+ the previous tile's conversion)
+    first_step();                            // K-step 0
     substep(IC<1>{}, IC<0>{});               // K-step 1: pieces 0, 1
     // K-steps 2 .. 16: pieces 2 (s - 1), 2 (s - 1) + 1
     substep(IC<0>{}, IC<2>{});
@@ -390,23 +393,17 @@ __global__ __launch_bounds__(256) void g256p(const bf16* __restrict__ A, const b
       substep(IC<0>{}, IC<-1>{});
       substep(IC<1>{}, IC<-1>{});
     }
+    load_bias(tile);                                     // this tile's bias, in front of the second-to-last K-step's DMA batch (that step's vmcnt(8) retires it)
     substep(IC<0>{}, IC<-1>{});
-    load_bias(tile);                                     // this tile's bias, one K-step before its conversion, in front of that step's DMA batch
-    last_substep();
+    last_substep();                                      // ... and converts the finished tile
     // this tile becomes the one on its way out
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     c_prev = make_rsrc(C + ((long long)tm * TM * ldc + tn * TN), tile_bytes);
     prev_valid = true;
-    if constexpr (!PARK) {                   // reference point: convert and store the tile here, exposed
-      first_step(false, true);
-      flush_all();
-    }
+    if constexpr (!PARK) flush_all();        // reference point: the tile is stored here, exposed
   }
   // ---- after the last tile: convert, park and store everything (exposed: nothing left to hide it under)
-  if constexpr (PARK) {
-    first_step(false, true);
-    flush_all();
-  }
+  if constexpr (PARK) flush_all();
   __builtin_amdgcn_s_waitcnt(0x0F70);        // the dead DMA units have been zero-filled before the workgroup leaves
 }
 
