@@ -178,3 +178,51 @@ def test_temporal_attention_runs_on_the_packed_bf16_dot(kernels):
     name = next(n for n in ks if "temporal_attn_b16_kernelILb0ELi8ELi96EE" in n)
     dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--disassemble-symbols=" + name, f], capture_output=True, text=True).stdout
     assert dis.count("v_dot2c_f32_bf16") + dis.count("v_dot2_f32_bf16") >= 48, "the bf16 dot product instruction is gone"
+
+
+def _mem_sequence(dis):
+    """memory-side skeleton of a disassembled kernel: L = global / buffer load, D = LDS-DMA, S = store, w<n> = s_waitcnt vmcnt(n), | = barrier"""
+    seq = []
+    for line in dis.split("\n"):
+        t = line.split("//")[0].strip()
+        m = re.search(r"s_waitcnt.*vmcnt\((\d+)\)", t)
+        if m:
+            seq.append("w" + m.group(1))
+        elif re.search(r"\b(global|buffer)_load\w* .*\blds\b", t):
+            seq.append("D")
+        elif re.search(r"\b(global|buffer)_load", t):
+            seq.append("L")
+        elif re.search(r"\b(global|buffer)_store", t):
+            seq.append("S")
+        elif "s_barrier" in t:
+            seq.append("|")
+    return seq
+
+
+def test_requests_of_a_block_go_out_together(kernels):
+    """Round 4's ISA audit, pinned: (i) a dQ block of the resident / paired / two-item attention backward asks for Q, dO, O and its
+    statistic in ONE batch (>= 13 plain loads between the image DMAs and the first wait; they were four round trips behind each
+    other while the row fragments were loaded inside `if (row < nrows)`); (ii) the 256x256 GEMM fetches no bias from global memory in
+    its epilogue (the slice arrives by LDS-DMA in the prologue: no 8-byte global loads at all in the forward instance); (iii) the
+    decoder's stream LayerNorm has no store pending at a barrier (no vmcnt(0) directly in front of a barrier behind a store)."""
+    ks, _ = kernels
+
+    def dis_of(frag):
+        name = next(n for n in ks if frag in n)
+        return subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--disassemble-symbols=" + name, ks[name]["file"]], capture_output=True, text=True).stdout
+
+    for frag, need in (("22attn_bwd_dq_res_kernelILi64ELi0ELi320ELi3EE", 13), ("25attn_bwd_dq_pair64_kernelILi192ELi3EE", 13), ("24attn_bwd_dq_duo96_kernelILi256EE", 19)):
+        seq = _mem_sequence(dis_of(frag))
+        first_dma = seq.index("D")
+        run = 0
+        for t in seq[first_dma:]:
+            if t == "L":
+                run += 1
+            elif t.startswith("w") and run:
+                break
+        assert run >= need, (frag, run, seq[:40])
+    assert "global_load_dwordx2" not in dis_of("14gemm256_kernelILb0ELb0ELb0ELi4EE")
+    seq = _mem_sequence(dis_of("23ln_stream_fwd_wg_kernelILb0EE"))
+    for i in range(1, len(seq) - 1):
+        if seq[i] == "w0" and seq[i + 1] == "|":
+            assert "S" not in seq[:i], seq
