@@ -453,4 +453,11 @@ def test_bench_contract_line_forced_distributed_path():
     roof = rec["roofline"]
     assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 2500.0
     assert 0.2 < roof["frac"] < 1.0 and roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], abs=1e-3)
+    # `frac` is the STEP-level fraction: executed FLOPs of the step / the contract's step time / peak; the GEMM family is gemm_frac
+    assert roof["achieved"] == pytest.approx(roof["step_algorithmic_tflop"] / (rec["ms_per_step"] * 1e-3), rel=2e-3)
+    assert roof["frac"] < roof["gemm_frac"] < 1.0 and roof["gemm_frac"] == pytest.approx(roof["gemm_achieved"] / roof["peak"], abs=1e-3)
+    for k in ("sclk_mhz", "power_w", "clock_power_samples", "clock_power_source"):
+        assert k in roof, k
+    if roof["clock_power_source"] is not None:      # a box whose SMI answers: plausible MI355X figures, sampled during the timed region
+        assert roof["clock_power_samples"] >= 1 and 500 < roof["sclk_mhz"] < 3000 and 100 < roof["power_w"] < 2000
     assert 30.0 < rec["ms_per_step"] < 400.0

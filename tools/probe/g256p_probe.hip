@@ -50,6 +50,15 @@ constexpr int HEAD_SUB = 17;                      // K-steps 0..16 of a tile are
 constexpr uint32_t OOB = 0x80000000u;
 
 #define SB() __builtin_amdgcn_sched_barrier(0)
+// Round-5 attribution switches (-DABL_NODMA / -DABL_NOREAD / -DABL_NOBAR / -DABL_M0X4): the steady-state K loop without its LDS-DMA
+// instructions, without its fragment reads, without its workgroup barrier (TIMING ONLY: the results are wrong by construction), and
+// with ONE m0 write per operand half (the four pieces of a half addressed through the instruction offset, which moves the LDS
+// address and the global address together; the scalar offset takes the difference back out) -- that one stays correct.
+#if defined(ABL_NODMA) || defined(ABL_NOREAD) || defined(ABL_NOBAR)
+#define ABL_WRONG 1
+#else
+#define ABL_WRONG 0
+#endif
 
 __device__ __forceinline__ void dma16(i32x4 rsrc, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
   // (readfirstlane: both are wave-uniform by construction; this only tells the register allocator)
@@ -139,8 +148,20 @@ __global__ __launch_bounds__(256) void g256p(const bf16* __restrict__ A, const b
   };
   auto issue_one = [&](auto I) __attribute__((always_inline)) {                                     // i = 0..3: A rows, 4..7: B rows
     constexpr int i = decltype(I)::value;
+#if defined(ABL_NODMA)
+    (void)i;
+#elif defined(ABL_M0X4)
+    constexpr int j = i & 3;
+    if constexpr (j == 0) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(__builtin_amdgcn_readfirstlane(is_lds + (uint32_t)(i < 4 ? 0 : UNIT))) : "memory");
+    const uint32_t so = (i < 4 ? is_sa : is_sb) + (uint32_t)j * jstride - (uint32_t)(j * 1024);
+    if constexpr (j == 0) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(is_vo), "s"(i < 4 ? ra : rb), "s"(__builtin_amdgcn_readfirstlane(so)) : "memory");
+    else if constexpr (j == 1) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:1024 lds" : : "v"(is_vo), "s"(i < 4 ? ra : rb), "s"(__builtin_amdgcn_readfirstlane(so)) : "memory");
+    else if constexpr (j == 2) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:2048 lds" : : "v"(is_vo), "s"(i < 4 ? ra : rb), "s"(__builtin_amdgcn_readfirstlane(so)) : "memory");
+    else asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:3072 lds" : : "v"(is_vo), "s"(i < 4 ? ra : rb), "s"(__builtin_amdgcn_readfirstlane(so)) : "memory");
+#else
     if constexpr (i < 4) dma16(ra, is_lds + (uint32_t)(i * 1024), is_vo, is_sa + (uint32_t)i * jstride);
     else dma16(rb, is_lds + (uint32_t)(UNIT + (i - 4) * 1024), is_vo, is_sb + (uint32_t)(i - 4) * jstride);
+#endif
   };
   auto issue_end = [&]() __attribute__((always_inline)) {
     islot = islot == NSLOT - 1 ? 0 : islot + 1;
@@ -241,7 +262,12 @@ __global__ __launch_bounds__(256) void g256p(const bf16* __restrict__ A, const b
       if constexpr (nb < 7) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nb], fa[buf][mb], acc[mb][nb], 0, 0, 0);
       else acc[mb][7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb7[buf], fa[buf][mb], acc[mb][7], 0, 0, 0);
     }
-    if constexpr (pf) {
+#if defined(ABL_NOREAD)
+    constexpr bool do_reads = false;
+#else
+    constexpr bool do_reads = true;
+#endif
+    if constexpr (pf && do_reads) {
       if constexpr (nb < 7) read_b(nb);
       if constexpr (nb == 0) {           // (nothing is read behind the LAST column: the step's closing lgkmcnt(0) would wait for it)
         read_a_one(IC<buf ^ 1>{}, 0);
@@ -265,7 +291,9 @@ __global__ __launch_bounds__(256) void g256p(const bf16* __restrict__ A, const b
                                              // two instructions too must have landed in a step that also trickled two stores: harmless,
                                              // they are ~900 clocks old); loads complete in order, so everything older has landed whatever
                                              // the stores do; lgkmcnt(0): this wave's reads of the slot the next K-step refills are done
+#if !defined(ABL_NOBAR)
     __builtin_amdgcn_s_barrier();
+#endif
     SB();
   };
   auto substep = [&](auto BUF, auto TRK) __attribute__((always_inline)) {
@@ -481,7 +509,7 @@ int main(int argc, char** argv) {
     hipEventElapsedTime(&ms, e0, e1);
     const double t = ms / it * 1e-3;
     printf("g256p<park=%d> (4 waves x 128x128, persistent ring%s; %d workgroups for %d tiles) M=%d N=%d K=%d: %.1f us  %.1f TFLOP/s  max rel err %.3g %s\n", park,
-           park ? ", parked epilogue" : ", exposed epilogue", grid, ntiles, M, N, K, t * 1e6, 2.0 * M * N * K / t / 1e12, maxerr, maxerr < 2e-2 ? "(ok)" : "(WRONG)");
+           park ? ", parked epilogue" : ", exposed epilogue", grid, ntiles, M, N, K, t * 1e6, 2.0 * M * N * K / t / 1e12, maxerr, ABL_WRONG ? "(ablation: timing only)" : maxerr < 2e-2 ? "(ok)" : "(WRONG)");
   }
   return 0;
 }
