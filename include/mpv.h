@@ -59,6 +59,8 @@ int mpv_version(void);
 const char* mpv_last_error(void);
 /* 0 if the current device is gfx950, MPV_E_ARCH otherwise */
 int mpv_check_device(void);
+/* the same test on a gcnArchName string (hipDeviceProp_t::gcnArchName, e.g. "gfx950:sramecc+:xnack-"): 0 / MPV_E_ARCH / MPV_E_ARG */
+int mpv_check_arch_name(const char* gcn_arch_name);
 
 /* ------------------------------------------------------------------------------------------
  * GEMM: C[M,N] = epilogue(sum_k A(m,k) B(n,k)), bf16 in, fp32 accumulate (MFMA 32x32x16).

@@ -32,6 +32,41 @@ CASES = {
 }
 
 
+# Round 5: the true-dims goldens also hold WHOLE-TENSOR gradients of these tensors (fp32 run, stored as bf16: 2.3e-3
+# of relative L2 noise) plus the L2 deviation of the reference's own bf16 run on each -- a 64-element sample of a near-zero gradient
+# cannot tell a rounding difference from a wrong row, an L2 distance over every row block can.  Tensors above FULL_GRAD_MAX elements
+# are stored as a row-strided slab (every k-th row of the [rows, last-dim] view, k recorded) so that a golden stays a few MB.
+FULL_GRAD_MAX = 600_000
+FULL_GRAD_KEYS = {
+    "gencls": ["cls_head.0.weight", "cls_head.0.bias", "cls_head.2.weight", "cls_head.2.bias", "visual_fc.weight", "learnable_queries",
+               "visual_encoder.blocks.0.attn.qkv.weight", "visual_encoder.blocks.6.temporal_fc.weight", "visual_encoder.blocks.11.temporal_attn.qkv.weight",
+               "visual_encoder.pos_embed", "visual_encoder.temporal_embed", "attn_pool.attn.bias_k", "attn_pool.attn.in_proj_weight",
+               "visual_encoder.blocks.3.norm1.weight", "visual_encoder.blocks.9.temporal_attn.q_bias"],
+    "eva": ["visual_fc.weight", "learnable_queries", "visual_encoder.blocks.0.attn.qkv.weight", "visual_encoder.blocks.39.mlp.fc2.weight",
+            "visual_encoder.blocks.20.attn.proj.weight", "visual_encoder.pos_embed", "visual_encoder.cls_token", "attn_pool.attn.bias_k",
+            "visual_encoder.blocks.20.attn.q_bias", "visual_encoder.blocks.39.norm2.weight"],
+}
+
+
+def grad_slab(g: torch.Tensor):
+    """(rows ::k of the [rows, last-dim] view, k) with k the smallest stride that brings the tensor under FULL_GRAD_MAX elements."""
+    g2 = g.detach().float().reshape(-1, g.shape[-1])
+    k = max(1, -(-g2.numel() // FULL_GRAD_MAX))
+    return g2[::k].clone(), k
+
+
+def record_full_grads(model, r, keys, keep, tag):
+    """fp32 pass: store the slabs (bf16) and keep them; bf16 pass: store ||g_bf16 - g_fp32|| / ||g_fp32|| per slab."""
+    params = dict(model.named_parameters())
+    if tag == "fp32":
+        r["grad_full"], r["grad_full_stride"] = {}, {}
+        for n in keys:
+            keep[n], r["grad_full_stride"][n] = grad_slab(params[n].grad)
+            r["grad_full"][n] = keep[n].to(torch.bfloat16)
+    else:
+        r["grad_full_dev"] = {n: float((grad_slab(params[n].grad)[0] - keep[n]).norm() / keep[n].norm()) for n in keys}
+
+
 def grad_sample(g: torch.Tensor, n: int = 64):
     f = g.detach().float().reshape(-1)
     step = max(1, f.numel() // n)
@@ -144,6 +179,7 @@ def run_gencls(kind: str, full: bool = False):
     name = f"{kind}_1p3b" if full else f"{kind}_tiny"
     wseed = 23 if full else 3
     rec = {"meta": dict(case=name, weight_seed=wseed, torch=str(torch.__version__), **shape)}
+    keep = {}
     for tag, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
         t0 = time.time()
         inp = gencls_inputs(cfg, kind, **shape)
@@ -161,6 +197,8 @@ def run_gencls(kind: str, full: bool = False):
             if p.grad is not None:
                 r["grad_norm"][n] = float(p.grad.float().norm())
                 r["grad_sample"][n] = grad_sample(p.grad)
+        if full:
+            record_full_grads(model, r, FULL_GRAD_KEYS["gencls"], keep, tag)
         etext = types.SimpleNamespace(input_ids=inp["e_ids"], attention_mask=inp["e_mask"], prompt_lengths=inp["e_plen"])
         eptext = types.SimpleNamespace(input_ids=inp["e_pids"], attention_mask=inp["e_pmask"])
         with torch.no_grad():
@@ -197,6 +235,7 @@ def run_eva(name: str = "eva_tiny"):
     cfg = full_eva_cfg() if full else CONFIG_EVA_TINY
     B, wseed = (2, 24) if full else (3, 4)
     rec = {"meta": dict(case=name, batch=B, text_len=9, weight_seed=wseed, input_seed=6, prompt_lengths=[1, 2, 1][:B], torch=str(torch.__version__))}
+    keep = {}
     for tag, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
         t0 = time.time()
         model, sd = build_reference_image(cfg, wseed, dtype=dtype)
@@ -223,6 +262,8 @@ def run_eva(name: str = "eva_tiny"):
             if p.grad is not None:
                 r["grad_norm"][n] = float(p.grad.float().norm())
                 r["grad_sample"][n] = grad_sample(p.grad)
+        if full:
+            record_full_grads(model, r, FULL_GRAD_KEYS["eva"], keep, tag)
         rec[tag] = r
         print(f"[{name}/{tag}] loss={float(loss):.6f}  {time.time() - t0:.0f}s", flush=True)
         del model, sd, out, captured

@@ -303,6 +303,32 @@ def test_gemm_gelu_derivative_parked_by_the_forward(dev, hint):
             assert torch.equal(d, z)
 
 
+def test_parked_gelu_derivative_does_not_depend_on_the_tile_kernel(dev):
+    """The 256x256 kernel evaluates tanh-GELU and its derivative from ONE polynomial (mpv_gelu_tanh_both_t), the 128x128 kernel from
+    the stand-alone derivative (gelu_tanh_grad_f): a product whose tiles are split between the two (row bands, fall-backs) must not
+    see two functions.  The pre-activations of the two kernels are the same bf16 values (same K order per tile is NOT promised, so
+    elements whose z differs are left out); on equal z the parked derivatives agree to one bf16 unit in the last place."""
+    from youku_mplug_amd import ops
+    M, N, K = 1024, 768, 256
+    a, w, bias = rn(M, K, dev=dev, seed=17), rn(N, K, dev=dev, seed=18, scale=0.1), rn(N, dev=dev, seed=19)
+    for act in (ops.ACT_GELU_ERF, ops.ACT_GELU_TANH):
+        zs, ds = [], []
+        for hint in (256, 128):
+            z = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            d = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            ops.gemm(a, w, M, N, K, bias=bias, act=act, preact_out=z, tile_hint=hint)
+            ops.gemm(a, w, M, N, K, bias=bias, act=act, preact_out=d, preact_deriv=True, tile_hint=hint)
+            zs.append(z)
+            ds.append(d.float())
+        same = zs[0] == zs[1]
+        assert same.float().mean().item() > 0.99
+        if not ops.GELU_DERIV_FWD:
+            continue
+        diff = (ds[0] - ds[1]).abs()[same]
+        ulp = torch.maximum(ds[0].abs(), ds[1].abs())[same] * 2.0 ** -7 + 2.0 ** -14      # one bf16 step at the value (8 bits of significand)
+        assert bool((diff <= ulp).all()), (diff.max().item(), (diff > ulp).float().mean().item())
+
+
 @pytest.mark.parametrize("M,N,K", [(2560, 2560, 10240), (1024, 2048, 8192), (512, 2560, 10240)])
 def test_gemm256_split_forward_with_bias_and_dropout_in_the_reduce(dev, M, N, K):
     """Few output tiles, long reduction (the decoder's 4h -> h product at 2.7B dims: 100 tiles on 256 CUs): the forward product is split

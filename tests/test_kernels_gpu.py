@@ -795,3 +795,84 @@ def test_video_randaugment_kernels_vs_oracle(dev):
         np.random.seed(5)
         outs.append(tf(clip))
     assert tuple(outs[0].shape) == (3, 4, 64, 64) and outs[0].dtype == torch.bfloat16 and torch.equal(outs[0], outs[1])
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# C-ABI error paths ON the device: every bad call returns its documented MPV_E_* with a message in
+# mpv_last_error(), launches nothing, and leaves the process (and the device) usable -- never an abort.
+def test_cabi_error_paths_on_the_device(dev):
+    import ctypes as C
+    from youku_mplug_amd import _lib, ops
+    L = _lib.lib()
+    E_SHAPE, E_ALIGN, E_ARCH, E_ARG = -1, -2, -3, -5
+    M, N, K = 512, 512, 256
+    a, w = rn(M, K + 64, dev=dev, seed=1), rn(N, K + 64, dev=dev, seed=2)
+    out = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=dev)
+    ws = torch.empty(L.mpv_gemm_workspace_size(M, N, K, 0, 0), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def gemm(A=None, B=None, Cp=None, m=M, n=N, k=K, lda=K + 64, ldb=K + 64, ldc=N, ta=0, tb=0, ep=None, wsp=None, wsn=None):
+        ep = ep or _lib.GemmEpilogue()
+        return L.mpv_gemm_bf16(A if A is not None else a.data_ptr(), B if B is not None else w.data_ptr(), Cp if Cp is not None else out.data_ptr(),
+                               m, n, k, lda, ldb, ldc, ta, tb, C.byref(ep), ws.data_ptr() if wsp is None else wsp, ws.numel() if wsn is None else wsn, stream)
+
+    def refused(rc, code, what):
+        msg = L.mpv_last_error().decode()
+        assert rc == code, (what, rc, msg)
+        assert msg and "mpv_" in msg, (what, msg)
+
+    refused(gemm(A=a.data_ptr() + 2), E_ALIGN, "A two bytes off a 16-byte boundary")
+    refused(gemm(Cp=out.data_ptr() + 8), E_ALIGN, "C eight bytes off")
+    refused(gemm(lda=K - 8), E_SHAPE, "lda shorter than K")
+    refused(gemm(ldb=K - 8), E_SHAPE, "ldb shorter than K")
+    refused(gemm(ldc=N - 8), E_SHAPE, "ldc shorter than N")
+    refused(gemm(lda=K + 4), E_ALIGN, "lda not a multiple of 8")
+    refused(gemm(k=K - 4), E_ALIGN, "K not a multiple of 8")
+    refused(gemm(n=N - 4), E_ALIGN, "N not a multiple of 8")
+    refused(gemm(m=0), E_SHAPE, "empty problem")
+    refused(gemm(A=0), E_ARG, "null operand")
+    refused(gemm(ta=1, tb=0), E_ARG, "transA without transB")
+    ep = _lib.GemmEpilogue()
+    ep.preact_deriv = 1
+    refused(gemm(ep=ep), E_ARG, "preact_deriv without preact_out")
+    ep = _lib.GemmEpilogue()
+    ep.dropout_p = 1.5
+    refused(gemm(ep=ep), E_ARG, "dropout_p >= 1")
+    cs = torch.empty(M, dtype=torch.bfloat16, device=dev)
+    ep = _lib.GemmEpilogue()
+    ep.colsum_out = cs.data_ptr()
+    refused(gemm(ep=ep), E_ARG, "colsum_out on a forward product")
+    # weight gradient with the fused column sums and a workspace of 16 bytes: refused (whichever tile kernel would have taken it)
+    dy, x = rn(1024, M, dev=dev, seed=3), rn(1024, N, dev=dev, seed=4)
+    for hint in (0, 128):
+        ep = _lib.GemmEpilogue()
+        ep.colsum_out, ep.tile_hint = cs.data_ptr(), hint
+        refused(gemm(A=dy.data_ptr(), B=x.data_ptr(), k=1024, lda=M, ldb=N, ta=1, tb=1, ep=ep, wsn=16), E_ARG, f"wgrad + colsum, 16-byte workspace, hint {hint}")
+    torch.cuda.synchronize()
+    assert bool((out == 7.0).all()), "a refused call must not have launched anything"
+    # K = 72: a multiple of 8 but not of the 256x256 kernel's K-tile -- not an error: the 128x128 kernel takes it, whatever the hint says
+    ep = _lib.GemmEpilogue()
+    ep.tile_hint = 256
+    assert gemm(k=72, ep=ep) == 0
+    close(out, a[:, :72].float() @ w[:, :72].float().t(), 1e-2, "K = 72 under tile_hint 256")
+    # LayerNorm backward with parameter gradients and a workspace that is too small; LayerNorm widths the kernels do not take
+    R, Cc = 1024, 768
+    xx, dyy, g = rn(R, Cc, dev=dev, seed=5), rn(R, Cc, dev=dev, seed=6), rn(Cc, dev=dev, seed=7)
+    mean, rstd = torch.zeros(R, device=dev), torch.ones(R, device=dev)
+    dx, dg, db = torch.empty_like(xx), torch.empty_like(g), torch.empty_like(g)
+    def ln_bwd(cols=Cc, wsn=64, dgp=dg.data_ptr(), dbp=db.data_ptr()):
+        return L.mpv_layernorm_bwd(dyy.data_ptr(), xx.data_ptr(), g.data_ptr(), mean.data_ptr(), rstd.data_ptr(), None, dx.data_ptr(), None, 0.0, 0, 0,
+                                   dgp, dbp, 0, R, cols, Cc, Cc, 0, 0, 0, 0, 0, 0, ws.data_ptr(), wsn, stream)
+    refused(ln_bwd(), E_ARG, "LayerNorm backward: workspace too small")
+    refused(ln_bwd(cols=Cc + 2), E_SHAPE, "LayerNorm backward: cols not a multiple of 4")
+    refused(ln_bwd(cols=8192), E_SHAPE, "LayerNorm backward: cols > 4096")
+    refused(ln_bwd(dbp=None), E_ARG, "LayerNorm backward: dgamma without dbeta")
+    # the device check on a mocked architecture string
+    refused(L.mpv_check_arch_name(b"gfx942:sramecc+:xnack-"), E_ARCH, "gfx942")
+    assert "gfx942" in L.mpv_last_error().decode()
+    refused(L.mpv_check_arch_name(b"gfx90a"), E_ARCH, "gfx90a")
+    refused(L.mpv_check_arch_name(None), E_ARG, "null name")
+    assert L.mpv_check_arch_name(b"gfx950:sramecc+:xnack-") == 0 and L.mpv_check_arch_name(b"gfx950") == 0 and L.mpv_check_device() == 0
+    # ... and the library still works
+    o2 = ops.gemm(a[:, :K].contiguous(), w[:, :K].contiguous(), M, N, K)
+    close(o2, a[:, :K].float() @ w[:, :K].float().t(), 1e-2, "a good call after the refused ones")

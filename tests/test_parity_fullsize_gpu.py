@@ -2,7 +2,7 @@
 configs[3] (2.7B decoder, 32 layers) and configs[4] (ITC retrieval, 16 frames) against the oracle restatement
 (oracle/restate.py, pinned to the reference's own modules at 1e-5 by tests/test_host_cpu.py) run live in fp32 on the host,
 at batch sizes the host finishes in seconds.  eval() mode.  Every case appends THREE deviations per quantity to a parity report
-(gpurun_out/r04_parity.txt, committed under profiles/), all as max-abs error / max-abs reference:
+(gpurun_out/r05_parity.txt, committed under profiles/), all as max-abs error / max-abs reference:
   (1) HIP (bf16) vs the fp32 oracle               -- the distance to the function the reference defines;
   (2) the oracle itself run in bf16 vs its fp32 run -- what the reference's OWN bf16 execution loses (the yardstick);
   (3) HIP (bf16) vs the oracle run in bf16          -- two bf16 executions with different rounding points.
@@ -24,7 +24,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REPORT = os.environ.get("MPV_PARITY_REPORT", os.path.join(ROOT, "gpurun_out", "r04_parity.txt"))
+REPORT = os.environ.get("MPV_PARITY_REPORT", os.path.join(ROOT, "gpurun_out", "r05_parity.txt"))
 
 
 def rel(a, b):
@@ -72,23 +72,25 @@ def _pretrain_case(name, cfg, dev, B, L, wseed, grad_keys, logits_gate, hidden_g
     ex = dict(logits=rel(out.logits, refb["logits"]), hidden=rel(out.last_hidden_state, refb["last_hidden_state"]),
               losses=rel(out.losses, refb["losses"]))
     params = dict(model.named_parameters())
-    worst, worst_norm = 0.0, 0.0
+    worst, worst_norm, worst_l2 = 0.0, 0.0, 0.0
     for k in grad_keys:
         g, r = params[k].grad.float().cpu(), sdr[k].grad
         worst = max(worst, rel(g, r))
         worst_norm = max(worst_norm, abs(g.norm().item() - r.norm().item()) / r.norm().item())
+        worst_l2 = max(worst_l2, ((g - r).norm() / r.norm()).item())
     report(f"{name}: B={B} L={L} S={cfg.num_queries + L} frames={cfg.num_frames} layers={cfg.layers} mask={'full' if full_mask else 'ragged'}\n"
-           f"    (1) HIP vs fp32 oracle        : logits {e['logits']:.3e} hidden {e['hidden']:.3e} losses {e['losses']:.3e} loss {e['loss']:.3e} worst-grad {worst:.3e} worst-grad-norm {worst_norm:.3e}\n"
+           f"    (1) HIP vs fp32 oracle        : logits {e['logits']:.3e} hidden {e['hidden']:.3e} losses {e['losses']:.3e} loss {e['loss']:.3e} worst-grad {worst:.3e} worst-grad-norm {worst_norm:.3e} worst-grad-L2 {worst_l2:.3e}\n"
            f"    (2) oracle bf16 vs fp32 oracle: logits {eb['logits']:.3e} hidden {eb['hidden']:.3e} losses {eb['losses']:.3e}\n"
            f"    (3) HIP vs oracle bf16        : logits {ex['logits']:.3e} hidden {ex['hidden']:.3e} losses {ex['losses']:.3e}\n"
-           f"    gates on (1): logits <= {logits_gate:.1e}, hidden <= {hidden_gate:.1e}, losses <= 1.0e-02, loss <= 5.0e-03, worst-grad <= 4.0e-02, worst-grad-norm <= 1.0e-02 | {time.time() - t0:.0f} s")
+           f"    gates on (1): logits <= {logits_gate:.1e}, hidden <= {hidden_gate:.1e}, losses <= 1.0e-02, loss <= 5.0e-03, worst-grad <= 4.0e-02, worst-grad-norm <= 1.0e-02, worst-grad-L2 <= {GRAD_L2_GATE:.1e} | {time.time() - t0:.0f} s")
     assert e["logits"] <= logits_gate, e
     assert e["hidden"] <= hidden_gate, e
     assert e["losses"] <= 1e-2, e
     assert e["loss"] <= 5e-3, e
-    assert worst <= 4e-2 and worst_norm <= 1e-2, (worst, worst_norm)
+    assert worst <= 4e-2 and worst_norm <= 1e-2 and worst_l2 <= GRAD_L2_GATE, (worst, worst_norm, worst_l2)
 
 
+GRAD_L2_GATE = 1.0e-1      # ||g - r||_2 / ||r||_2 over the WHOLE tensor, live fp32 oracle (round 5)
 # Gates on deviation (1), as numbers: north_star's 1e-2 for the logits, at every full-depth shape.  With the decoder's residual
 # stream in fp32 (gpt3.FP32_STREAM) the measured deviations are 6.6e-3 (config B), 7.7e-3 (S = 208) and 7.9e-3 (config D, 32
 # layers); the reference's own bf16 execution -- column (2) -- sits at 1.3-1.6e-2, and so does column (3), which is dominated by it.
@@ -104,6 +106,75 @@ def test_configB_full_depth_vs_oracle(dev):
     from oracle.weights import CONFIG_B
     _pretrain_case("config B (1.3B, T=8, full depth)", CONFIG_B, dev, B=2, L=32, wseed=11, grad_keys=GRAD_KEYS, logits_gate=LOGITS_GATE_B,
                    hidden_gate=HIDDEN_GATE_B)
+
+
+
+def test_configB_at_the_benchmarked_batch_vs_oracle(dev):
+    """configs[1] EXACTLY as bench.py runs it: B = 32 clips x 8 frames + 32-token titles, full depth -- the only shape where the
+    192 / 160-row GEMM bands, the 2.31-round launches and the > 256-item persistent attention walks all fire together (VERDICT r04
+    weak 1).  eval() mode (dropout off: samples are independent, so the fp32 oracle of the batch is the oracle of its sixteen
+    2-clip slices; each slice runs restate.pretrain_forward in fp32 on the host, forward AND backward, its loss weighted by the
+    batch's token count so that the summed gradients are the gradients of the B = 32 loss).  Compared: the logits of the loss
+    window (the text rows the benchmarked forward forms), the last hidden state, the per-token losses, the loss of the
+    benchmarked entry point (model(video, text): loss window on), and seven gradient tensors of the B = 32 backward."""
+    from oracle import restate
+    from oracle.weights import CONFIG_B, make_inputs, make_state_dict
+    from youku_mplug_amd.pretrain import synthetic_model
+    t0 = time.time()
+    cfg, B, L, SL = CONFIG_B, 32, 32, 2
+    Q = cfg.num_queries
+    model = synthetic_model(cfg, device=dev)
+    sd = make_state_dict(cfg, 11)
+    model.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+    model.eval()
+    video, ids, mask = make_inputs(cfg, B, L, seed=57, ragged=True)
+    text = types.SimpleNamespace(input_ids=ids.to(dev), attention_mask=mask.to(dev))
+    vid = video.to(dev).to(torch.bfloat16)
+    out = model.forward_outputs(vid, text)
+    logits_w = out.logits[:, Q:].float().cpu()
+    hidden = out.last_hidden_state.float().cpu()
+    losses = out.losses.float().cpu()
+    del out
+    loss, _ = model(vid, text)                      # the benchmarked entry point (loss window)
+    loss.backward()
+    torch.cuda.synchronize()
+    sdr = {k: v.bfloat16().float() for k, v in sd.items()}
+    del sd
+    for k in GRAD_KEYS:
+        sdr[k].requires_grad_(True)
+    ntok = float(mask[:, 1:].sum())                 # the batch's loss-mask count (Q query slots carry none)
+    err = dict(logits=0.0, hidden=0.0, losses=0.0)
+    ref_max = dict(logits=0.0, hidden=0.0, losses=0.0)
+    num = 0.0
+    for b0 in range(0, B, SL):
+        sl = slice(b0, b0 + SL)
+        ref = restate.pretrain_forward(video[sl].bfloat16().float(), ids[sl], mask[sl], sdr, cfg)
+        lm = torch.cat([torch.zeros(SL, Q), mask[sl, 1:].float()], dim=1)
+        part = (ref["losses"] * lm).sum() / ntok
+        part.backward()
+        num += part.item()
+        with torch.no_grad():
+            for name, mine, r in (("logits", logits_w[sl], ref["logits"][:, Q:]), ("hidden", hidden[sl], ref["last_hidden_state"]),
+                                  ("losses", losses[sl], ref["losses"])):
+                err[name] = max(err[name], (mine - r).abs().max().item())
+                ref_max[name] = max(ref_max[name], r.abs().max().item())
+        del ref, part
+    e = {k: err[k] / ref_max[k] for k in err}
+    e_loss = abs(loss.item() - num) / abs(num)
+    params = dict(model.named_parameters())
+    worst, worst_norm, worst_l2 = (0.0, ""), (0.0, ""), (0.0, "")
+    for k in GRAD_KEYS:
+        g, r = params[k].grad.float().cpu(), sdr[k].grad
+        worst = max(worst, (rel(g, r), k))
+        worst_norm = max(worst_norm, (abs(g.norm().item() - r.norm().item()) / r.norm().item(), k))
+        worst_l2 = max(worst_l2, (((g - r).norm() / r.norm()).item(), k))
+    report(f"config B at the BENCHMARKED batch: B={B} L={L} S={Q + L} frames={cfg.num_frames} layers={cfg.layers} (fp32 oracle in {B // SL} slices of {SL})\n"
+           f"    HIP vs fp32 oracle: window logits {e['logits']:.3e} hidden {e['hidden']:.3e} losses {e['losses']:.3e} loss {e_loss:.3e} "
+           f"worst-grad {worst[0]:.3e} ({worst[1]}) worst-grad-norm {worst_norm[0]:.3e} ({worst_norm[1]}) worst-grad-L2 {worst_l2[0]:.3e} ({worst_l2[1]})\n"
+           f"    gates: logits <= 1.0e-02, hidden <= 1.0e-02, losses <= 1.0e-02, loss <= 5.0e-03, worst-grad <= 4.0e-02, worst-grad-norm <= 1.0e-02, worst-grad-L2 <= {GRAD_L2_GATE:.1e} | {time.time() - t0:.0f} s")
+    assert e["logits"] <= 1e-2 and e["hidden"] <= 1e-2 and e["losses"] <= 1e-2, e
+    assert e_loss <= 5e-3, e_loss
+    assert worst[0] <= 4e-2 and worst_norm[0] <= 1e-2 and worst_l2[0] <= GRAD_L2_GATE, (worst, worst_norm, worst_l2)
 
 
 def test_configB_train_mode_full_depth_vs_oracle_through_the_kernels_own_masks(dev):
@@ -147,6 +218,43 @@ def test_configB_train_mode_full_depth_vs_oracle_through_the_kernels_own_masks(d
            f"    gates: loss <= 5.0e-03, worst-grad <= 4.0e-02, worst-grad-norm <= 1.0e-02 | {time.time() - t0:.0f} s")
     assert e_loss <= 5e-3 and worst[0] <= 4e-2 and worst_norm[0] <= 1e-2, (e_loss, worst, worst_norm)
 
+
+
+BF16_STREAM_VS_REF_BF16_GATE = 2.0e-2     # logits, bf16 residual-stream mode against the reference's OWN bf16 execution (two bf16 runs)
+
+
+def test_configB_bf16_stream_mode_full_depth_vs_the_oracles_bf16_run(dev, monkeypatch):
+    """MPV_DECODER_STREAM=bf16 (gpt3.FP32_STREAM off) is the mode that keeps the REFERENCE's rounding points in the decoder (every
+    sublayer output added into a bf16 stream, models/modeling_distributed_gpt3.py:1059-1078).  Round 4 pinned it to the goldens at tiny
+    dims only; here it runs configs[1] at full depth against the oracle's bf16 execution (column (3) of the report: two bf16 runs of
+    one function) and against the fp32 function (column (1): where the reference's own bf16 run sits at 1.3e-2)."""
+    from oracle import restate
+    from oracle.weights import CONFIG_B, make_inputs, make_state_dict
+    from youku_mplug_amd import gpt3
+    from youku_mplug_amd.pretrain import synthetic_model
+    t0 = time.time()
+    monkeypatch.setattr(gpt3, "FP32_STREAM", False)
+    cfg, B, L = CONFIG_B, 2, 32
+    model = synthetic_model(cfg, device=dev)
+    sd = make_state_dict(cfg, 11)
+    model.load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=True)
+    model.eval()
+    video, ids, mask = make_inputs(cfg, B, L, seed=31, ragged=True)
+    text = types.SimpleNamespace(input_ids=ids.to(dev), attention_mask=mask.to(dev))
+    out = model.forward_outputs(video.to(dev).to(torch.bfloat16), text)
+    with torch.no_grad():
+        ref = restate.pretrain_forward(video.bfloat16().float(), ids, mask, {k: v.bfloat16().float() for k, v in sd.items()}, cfg)
+        refb = restate.pretrain_forward(video.bfloat16(), ids, mask, {k: v.bfloat16() for k, v in sd.items()}, cfg)
+    e1 = dict(logits=rel(out.logits, ref["logits"]), hidden=rel(out.last_hidden_state, ref["last_hidden_state"]), losses=rel(out.losses, ref["losses"]))
+    e2 = dict(logits=rel(refb["logits"], ref["logits"]), hidden=rel(refb["last_hidden_state"], ref["last_hidden_state"]), losses=rel(refb["losses"], ref["losses"]))
+    e3 = dict(logits=rel(out.logits, refb["logits"]), hidden=rel(out.last_hidden_state, refb["last_hidden_state"]), losses=rel(out.losses, refb["losses"]))
+    report(f"config B, bf16 residual-stream mode (the reference's rounding points), full depth: B={B} L={L}\n"
+           f"    (1) HIP vs fp32 oracle        : logits {e1['logits']:.3e} hidden {e1['hidden']:.3e} losses {e1['losses']:.3e}\n"
+           f"    (2) oracle bf16 vs fp32 oracle: logits {e2['logits']:.3e} hidden {e2['hidden']:.3e} losses {e2['losses']:.3e}\n"
+           f"    (3) HIP vs oracle bf16        : logits {e3['logits']:.3e} hidden {e3['hidden']:.3e} losses {e3['losses']:.3e}\n"
+           f"    gates: (3) logits <= {BF16_STREAM_VS_REF_BF16_GATE:.1e}, (3) losses <= 1.0e-02, (1) logits <= 1.5 x column (2) | {time.time() - t0:.0f} s")
+    assert e3["logits"] <= BF16_STREAM_VS_REF_BF16_GATE and e3["losses"] <= 1e-2, e3
+    assert e1["logits"] <= 1.5 * e2["logits"], (e1, e2)        # no worse against the function than the reference's own bf16 run (x 1.5)
 
 def test_yaml_geometry_full_depth_vs_oracle(dev):
     """The geometry the shipped YAML runs (configs/pretrain/gpt3_1.3B/pretrain_gpt3_freezeGPT_youku_v0.yaml: 4 frames, titles of up
@@ -205,41 +313,58 @@ def test_retrieval_config5_shape_vs_oracle(dev):
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
-RELU_GATED = ("cls_head.0.weight", "cls_head.0.bias")      # the one ReLU of the path sits behind cls_head[0] (models/distributed_gpt3.py:523-527)
 
 
-def _grad_gates(model, f32, b16, norm_floor=5e-2, samp_floor=8e-2, k=3.0):
-    """Every trainable parameter: |grad| norm and a 64-element strided sample against the fp32 golden; the gate on each is
-    max(floor, k x the reference's own bf16 deviation on the same quantity).  Returns (failures, worst norm dev, worst sample dev).
+NORM_GATE, L2_GATE = 5e-2, 1.0e-1      # plain numbers (round 5): |grad| norm of EVERY trainable tensor; relative L2 distance of the whole-tensor goldens
 
-    The gradients behind the ReLU (RELU_GATED) are DISCONTINUOUS in the pre-activation: an element of z within a bf16 error of
-    zero falls on the other side of the gate in a bf16 execution than in the fp32 function, and a sampled element of the gradient
-    then gains or loses one row's whole contribution (with 9 decoder rows: ~10-30 % of the element).  P(|z| < 3e-3 sigma) x 576
-    sampled (row, column) pairs ~ 1-2 such flips per run -- the reference's own bf16 run has them too (2.65e-2 on the tiny golden;
-    none drawn at true dims: 4.9e-3) -- so for these two tensors the sample gate is on the 5th-largest of the 64 element errors
-    (up to four flipped elements tolerated), the max is reported, and the NORM gate (continuous in the flips' measure) stays as is."""
+
+def _grad_gates(model, f32, b16):
+    """Round 5: plain-number gates.
+      (1) every trainable parameter: | ||g|| - ||r|| | / ||r|| <= NORM_GATE against the fp32 golden;
+      (2) the tensors whose WHOLE gradient the golden holds (f32["grad_full"]: >= 10 tensors per case, the large ones as row-strided
+          slabs -- oracle/gen_golden.py): ||g - r||_2 / ||r||_2 <= L2_GATE over every stored element.  The reference's own bf16 run
+          sits at 6-9e-2 on this measure for the ITM / classification cases and 2-3e-2 for EVA (b16["grad_full_dev"], reported beside
+          ours) -- a wrong row, a dropped bias gradient or a mis-scaled branch shows up here as O(1);
+      (3) the 64-element strided samples of round 4 are REPORTED (worst max-abs deviation) and no longer gated: on a near-zero
+          gradient tensor a max-abs / max-abs over 64 elements cannot tell a rounding difference from a defect, and the `3 x the
+          reference's own bf16 deviation` clause that admitted 12-27 % there is gone.
+    Returns (failures, worst norm dev, worst sample dev, {name: (our L2 dev, reference-bf16 L2 dev)})."""
     bad, wn, ws = [], (0.0, ""), (0.0, "")
     seen = 0
-    for n, p in model.named_parameters():
+    params = dict(model.named_parameters())
+    for n, p in params.items():
         if n not in f32["grad_norm"]:
             continue
         seen += 1
         assert p.grad is not None, n
         gn = p.grad.float().norm().item()
         e = abs(gn - f32["grad_norm"][n]) / (f32["grad_norm"][n] + 1e-12)
-        e_ref = abs(b16["grad_norm"][n] - f32["grad_norm"][n]) / (f32["grad_norm"][n] + 1e-12)
         step = max(1, p.numel() // 64)
         samp = p.grad.float().reshape(-1)[::step][:64].cpu()
         den = f32["grad_sample"][n].abs().max().item() + 1e-12
-        errs = (samp - f32["grad_sample"][n]).abs() / den
-        es = errs.max().item()
-        es_ref = (b16["grad_sample"][n] - f32["grad_sample"][n]).abs().max().item() / den
-        es_gate = errs.sort(descending=True).values[min(4, errs.numel() - 1)].item() if n in RELU_GATED else es
+        es = ((samp - f32["grad_sample"][n]).abs() / den).max().item()
         wn, ws = max(wn, (e, n)), max(ws, (es, n))
-        if e > max(norm_floor, k * e_ref) or es_gate > max(samp_floor, k * es_ref):
-            bad.append((n, e, e_ref, es, es_ref))
+        if e > NORM_GATE:
+            bad.append((n, "norm", e))
     assert seen == len(f32["grad_norm"]), (seen, len(f32["grad_norm"]))
-    return bad, wn, ws
+    l2 = {}
+    for n, r in f32["grad_full"].items():
+        k = f32["grad_full_stride"][n]
+        g = params[n].grad.float().reshape(-1, params[n].shape[-1])[::k].cpu()
+        r = r.float()
+        assert g.shape == r.shape, (n, g.shape, r.shape)
+        e = ((g - r).norm() / r.norm()).item()
+        l2[n] = (e, b16["grad_full_dev"][n])
+        if e > L2_GATE:
+            bad.append((n, "L2", e))
+    assert len(l2) >= 8
+    return bad, wn, ws, l2
+
+
+def _l2_line(l2):
+    worst = max(l2.items(), key=lambda kv: kv[1][0])
+    return (f"whole-tensor L2 dev over {len(l2)} tensors: worst {worst[1][0]:.3e} ({worst[0]}; reference bf16 run {worst[1][1]:.3e}), "
+            f"median {sorted(v[0] for v in l2.values())[len(l2) // 2]:.3e} (reference bf16 run: median {sorted(v[1] for v in l2.values())[len(l2) // 2]:.3e})")
 
 
 @pytest.mark.parametrize("kind", ["itm", "cls"])
@@ -274,7 +399,7 @@ def test_itm_cls_true_dims_vs_reference_golden(dev, kind):
         el[name] = (abs(mine.item() - ref) / abs(ref), abs(refb - ref) / abs(ref))
     (lc + lk).backward()
     torch.cuda.synchronize()
-    bad, wn, ws = _grad_gates(model, f32, b16)
+    bad, wn, ws, l2 = _grad_gates(model, f32, b16)
     etext = types.SimpleNamespace(input_ids=d(inp["e_ids"]), attention_mask=d(inp["e_mask"]), prompt_lengths=inp["e_plen"])
     eptext = types.SimpleNamespace(input_ids=d(inp["e_pids"]), attention_mask=d(inp["e_pmask"]))
     gen, cl = model(video, etext, eptext, train=False)
@@ -288,9 +413,9 @@ def test_itm_cls_true_dims_vs_reference_golden(dev, kind):
            f"cls {el['loss_cls'][0]:.3e} | {el['loss_cls'][1]:.3e}\n"
            f"    scores  (train=False): generation {es['generation_logits'][0]:.3e} | {es['generation_logits'][1]:.3e}   "
            f"cls {es['cls_logits'][0]:.3e} | {es['cls_logits'][1]:.3e}\n"
-           f"    grads   ({len(f32['grad_norm'])} tensors): worst norm dev {wn[0]:.3e} ({wn[1]})  worst 64-sample dev {ws[0]:.3e} ({ws[1]})  "
-           f"outside max(floor, 3 x ref-bf16): {len(bad)}\n"
-           f"    gates: losses <= max(1e-2, 3 x ref-bf16), scores <= max(2e-2, 3 x ref-bf16), grad norm <= max(5e-2, 3 x), sample <= max(8e-2, 3 x) | {time.time() - t0:.0f} s")
+           f"    grads   ({len(f32['grad_norm'])} tensors): worst norm dev {wn[0]:.3e} ({wn[1]})  [worst 64-sample dev {ws[0]:.3e} ({ws[1]}), not gated]\n"
+           f"            {_l2_line(l2)}\n"
+           f"    gates: losses <= max(1e-2, 3 x ref-bf16), scores <= max(2e-2, 3 x ref-bf16), grad norm <= {NORM_GATE:.1e}, whole-tensor L2 <= {L2_GATE:.1e} | {time.time() - t0:.0f} s")
     for name, (e, e_ref) in el.items():
         assert e <= max(1e-2, 3 * e_ref), (name, e, e_ref)
     for name, (e, e_ref) in es.items():
@@ -329,12 +454,12 @@ def test_eva_g_true_dims_vs_reference_golden(dev):
     r_loss = abs(b16["loss"].item() - f32["loss"].item()) / abs(f32["loss"].item())
     loss.backward()
     torch.cuda.synchronize()
-    bad, wn, ws = _grad_gates(model, f32, b16)
+    bad, wn, ws, l2 = _grad_gates(model, f32, b16)
     report(f"EVA-ViT-g at true dims (1408 x 40 blocks, 257 tokens, heads of 88) + 1.3B decoder, B={m['batch']} (reference-module golden eva_g_full.pt)\n"
            f"    HIP vs fp32 ref | ref bf16 vs fp32: logits {e_log:.3e} | {r_log:.3e}   per-token losses {e_los:.3e} | {r_los:.3e}   loss {e_loss:.3e} | {r_loss:.3e}\n"
-           f"    grads ({len(f32['grad_norm'])} tensors): worst norm dev {wn[0]:.3e} ({wn[1]})  worst 64-sample dev {ws[0]:.3e} ({ws[1]})  "
-           f"outside max(floor, 3 x ref-bf16): {len(bad)}\n"
-           f"    gates: logits <= max(1e-2, 1.5 x ref-bf16), losses <= max(1e-2, 1.5 x), loss <= max(2e-3, 2 x), grads as above | {time.time() - t0:.0f} s")
+           f"    grads ({len(f32['grad_norm'])} tensors): worst norm dev {wn[0]:.3e} ({wn[1]})  [worst 64-sample dev {ws[0]:.3e} ({ws[1]}), not gated]\n"
+           f"          {_l2_line(l2)}\n"
+           f"    gates: logits <= max(1e-2, 1.5 x ref-bf16), losses <= max(1e-2, 1.5 x), loss <= max(2e-3, 2 x), grad norm <= {NORM_GATE:.1e}, whole-tensor L2 <= {L2_GATE:.1e} | {time.time() - t0:.0f} s")
     assert e_log <= max(1e-2, 1.5 * r_log) and e_los <= max(1e-2, 1.5 * r_los), (e_log, r_log, e_los, r_los)
     assert e_loss <= max(2e-3, 2 * r_loss), (e_loss, r_loss)
     assert not bad, bad[:8]

@@ -54,7 +54,12 @@ constexpr uint32_t OOB = 0x80000000u;
 // instructions, without its fragment reads, without its workgroup barrier (TIMING ONLY: the results are wrong by construction), and
 // with ONE m0 write per operand half (the four pieces of a half addressed through the instruction offset, which moves the LDS
 // address and the global address together; the scalar offset takes the difference back out) -- that one stays correct.
-#if defined(ABL_NODMA) || defined(ABL_NOREAD) || defined(ABL_NOBAR)
+// -DABL_OOBDMA: every DMA lane out of range (the instructions are issued, zero fill, NO memory traffic); -DABL_NOWAIT: no counted wait.
+// Result (profiles/r05_c2_*, r05_c3_*): 0.79 PF as is; no DMA 1.28-1.33; DMA issued but nothing fetched 1.21-1.23; no wait 0.80;
+// no fragment reads 0.75; no barrier 0.80; a FOUR-slot ring (two batches behind the wait; patch not kept) 0.78.  It is neither
+// the instructions nor the latency: it is the BYTES -- the walk below hands tile t to workgroup t % G, i.e. to XCD t % 8, so the
+// three / nine tiles that share an A panel run on different XCDs and every L2 fetches every panel (~3 TB/s of L2 misses).
+#if defined(ABL_NODMA) || defined(ABL_NOREAD) || defined(ABL_NOBAR) || defined(ABL_OOBDMA) || defined(ABL_NOWAIT) || defined(ABL_FULLLINE)
 #define ABL_WRONG 1
 #else
 #define ABL_WRONG 0
@@ -108,7 +113,7 @@ __device__ __forceinline__ Piece make_piece(f32x4 x, f32x4 y, f32x4 bx, f32x4 by
 // denominator of what parking buys.
 template <int PARK>
 __global__ __launch_bounds__(256) void g256p(const bf16* __restrict__ A, const bf16* __restrict__ B, const bf16* __restrict__ bias,
-                                             bf16* __restrict__ C, int M, int N, int K, int tiles_n, int ntiles) {
+                                             bf16* __restrict__ C, int M, int N, int K, int tiles_n, int ntiles, int GM) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -122,26 +127,69 @@ __global__ __launch_bounds__(256) void g256p(const bf16* __restrict__ A, const b
 
   // ---- issue stream: K-step `it_ks` of tile `it_tile` goes to ring slot `islot`; it runs three K-steps ahead of the consumer and
   // simply continues into the workgroup's next tile
-  int it_tile = blockIdx.x, it_ks = 0, islot = 0;
+  // XCD-aware walk (round 5; -DABL_FLATWALK restores tile = blockIdx.x + i * G): workgroup b runs on XCD b % 8; every XCD owns a
+  // contiguous eighth of the tile ids in GROUPED order (GM m-tiles x all n-tiles, as csrc/gemm256.hip walks them), and the nx
+  // workgroups of an XCD take ids j, j + nx, j + 2 nx, ... of that range -- at any moment they work on ~32 neighbouring tiles whose A and
+  // B panels their L2 fetches once.  (The flat walk gives the 3 / 9 tiles that share an A panel to 3 / 8 different XCDs.)
+  const int tiles_m = ntiles / tiles_n;
+#ifdef ABL_FLATWALK
+  const int x_start = 0, x_count = ntiles, nx = G, jx = blockIdx.x;
+#else
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7;
+  const int x_start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int x_count = q8 + (xcd < r8 ? 1 : 0);
+  const int nx = (G - xcd + 7) >> 3;
+#endif
+  auto decode = [&](int w, int& tm, int& tn) __attribute__((always_inline)) {
+#ifdef ABL_FLATWALK
+    tm = w / tiles_n;
+    tn = w - tm * tiles_n;
+#else
+    const int pid = x_start + w, gsz = GM * tiles_n;
+    const int grp = pid / gsz, rem = pid - grp * gsz;
+    const int gm = min(GM, tiles_m - grp * GM);
+    tn = rem / gm;
+    tm = grp * GM + (rem - tn * gm);
+#endif
+  };
+  int it_tile = jx, it_ks = 0, islot = 0;
   // per-lane part of the DMA source offsets (row inside the tile, swizzled 16-byte chunk): constant for the whole kernel; the tile's
   // origin and the K-step travel in the SCALAR offset of the DMA instruction, so moving on to the next tile is SALU work only
   // (one VGPR per operand: the four instructions of a wave cover rows 16 j apart -- a scalar)
+#ifdef ABL_FULLLINE
+  // (attribution, TIMING ONLY: the same bytes and the same number of DMA instructions per K-step, but every instruction reads 8 rows x
+  // one whole 128-byte line instead of 16 rows x half a line -- K-step s fetches rows [128 (s & 1), +128) of the K = 64 column pair
+  // s >> 1, so that two K-steps cover each line exactly once)
+  const uint32_t vo_lane = (uint32_t)((wave * 32 + (lane >> 3)) * K * 2 + (lane & 7) * 16);
+  const uint32_t jstride = (uint32_t)(8 * K * 2);
+#else
   const uint32_t vo_lane = (uint32_t)((wave * 64 + (lane >> 2)) * K * 2 + (((lane & 3) ^ f4((lane >> 4) & 3)) * 16));      // = slot ^ f4((r >> 2) & 3)
   const uint32_t jstride = (uint32_t)(16 * K * 2);
+#endif
   uint32_t baseA = 0, baseB = 0;
   auto set_tile = [&](int t) __attribute__((always_inline)) {
-    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+    int tm, tn;
+    decode(t, tm, tn);
     baseA = (uint32_t)((long long)tm * TM * lda * 2);
     baseB = (uint32_t)((long long)tn * TN * ldb * 2);
   };
-  set_tile(it_tile);
+  if (it_tile < x_count) set_tile(it_tile);
   // One K-step's eight DMA instructions are issued ONE PER COLUMN BLOCK, behind that block's eight MFMAs (a single wave feeds its SIMD:
   // issued in one batch in front of the step they would cost the matrix pipe ~100 idle clocks per K-step).
   uint32_t is_vo = 0, is_sa = 0, is_sb = 0, is_lds = 0;
   auto issue_begin = [&]() __attribute__((always_inline)) {
-    const bool live = it_tile < ntiles;                              // wave-uniform
+    const bool live = it_tile < x_count;                             // wave-uniform
+#ifdef ABL_FULLLINE
+    const uint32_t ko = (uint32_t)((it_ks >> 1) * 128 + (it_ks & 1) * 128 * K * 2);
+#else
     const uint32_t ko = (uint32_t)(it_ks * SUBK * 2);
-    is_vo = vo_lane | (live ? 0u : OOB);                             // past the last tile: zero fill, no traffic (the counted waits stay uniform)
+#endif
+#ifdef ABL_OOBDMA
+    is_vo = vo_lane | OOB;                                           // (attribution: the DMA instructions are issued, nothing is fetched)
+#else
+    is_vo = vo_lane | (live ? 0u : OOB);
+#endif                             // past the last tile: zero fill, no traffic (the counted waits stay uniform)
     is_sa = live ? baseA + ko : 0u;
     is_sb = live ? baseB + ko : 0u;
     is_lds = smem_base + (uint32_t)((islot * 2) * UNIT + wave * 4096);
@@ -165,11 +213,11 @@ __global__ __launch_bounds__(256) void g256p(const bf16* __restrict__ A, const b
   };
   auto issue_end = [&]() __attribute__((always_inline)) {
     islot = islot == NSLOT - 1 ? 0 : islot + 1;
-    if (it_tile < ntiles) {
+    if (it_tile < x_count) {
       if (++it_ks == nsub) {
         it_ks = 0;
-        it_tile += G;
-        if (it_tile < ntiles) set_tile(it_tile);
+        it_tile += nx;
+        if (it_tile < x_count) set_tile(it_tile);
       }
     }
   };
@@ -237,12 +285,11 @@ __global__ __launch_bounds__(256) void g256p(const bf16* __restrict__ A, const b
   // Inline asm on purpose: a load the compiler knows about is waited for with ITS count of younger requests -- it cannot see the
   // LDS-DMA instructions, so `s_waitcnt vmcnt(0)` in front of the first use drained the whole ring once per tile.  These are
   // requested in front of the second-to-last K-step's DMA batch; that step's own vmcnt(8) retires them, one K-step before they are used.
-  auto load_bias = [&](int t) __attribute__((always_inline)) {
-    const int tn = t % tiles_n;
+  auto load_bias = [&](int tn) __attribute__((always_inline)) {
     const uint32_t lo = (uint32_t)((wc * 128 + (fresh_lane() >> 4) * 4) * 2), so = (uint32_t)(tn * TN * 2);
     typedef __attribute__((ext_vector_type(2))) unsigned u2;
     u2 t0, t1, t2, t3, t4, t5, t6, t7;
-#define BIAS_LD(t, i) asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen offset:" #i : "=v"(t) : "v"(lo), "s"(bias_rs), "s"(so) : "memory")
+#define BIAS_LD(t, i) asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen offset:" #i : "=v"(t) : "v"(lo), "s"(bias_rs), "s"(__builtin_amdgcn_readfirstlane(so)) : "memory")
     BIAS_LD(t0, 0); BIAS_LD(t1, 32); BIAS_LD(t2, 64); BIAS_LD(t3, 96); BIAS_LD(t4, 128); BIAS_LD(t5, 160); BIAS_LD(t6, 192); BIAS_LD(t7, 224);
 #undef BIAS_LD
     braw[0] = __builtin_bit_cast(bf16x4, t0); braw[1] = __builtin_bit_cast(bf16x4, t1); braw[2] = __builtin_bit_cast(bf16x4, t2);
@@ -287,7 +334,12 @@ __global__ __launch_bounds__(256) void g256p(const bf16* __restrict__ A, const b
   };
   auto end_step = [&]() __attribute__((always_inline)) {
     SB();
-    __builtin_amdgcn_s_waitcnt(0x0078);      // vmcnt(8): at most the eight youngest requests are still out -- this step's DMA batch (its first
+#ifdef ABL_NOWAIT
+    __builtin_amdgcn_s_waitcnt(0xC07F);      // (attribution: lgkmcnt(0) only -- the fragments are read whether their batch has landed or not)
+#else
+    __builtin_amdgcn_s_waitcnt(0x0078);      // vmcnt(8): at most
+#endif
+    // ... at most the eight youngest requests are still out -- this step's DMA batch (its first
                                              // two instructions too must have landed in a step that also trickled two stores: harmless,
                                              // they are ~900 clocks old); loads complete in order, so everything older has landed whatever
                                              // the stores do; lgkmcnt(0): this wave's reads of the slot the next K-step refills are done
@@ -396,7 +448,9 @@ __global__ __launch_bounds__(256) void g256p(const bf16* __restrict__ A, const b
   __builtin_amdgcn_s_waitcnt(0x0F70);        // (vmcnt(0): simple, once)
   __builtin_amdgcn_s_barrier();
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += G) {
+  for (int tile = jx; tile < x_count; tile += nx) {
+    int tm, tn;
+    decode(tile, tm, tn);
     first_step();                            // K-step 0
     substep(IC<1>{}, IC<0>{});               // K-step 1: pieces 0, 1
     // K-steps 2 .. 16: pieces 2 (s - 1), 2 (s - 1) + 1
@@ -421,11 +475,10 @@ __global__ __launch_bounds__(256) void g256p(const bf16* __restrict__ A, const b
       substep(IC<0>{}, IC<-1>{});
       substep(IC<1>{}, IC<-1>{});
     }
-    load_bias(tile);                                     // this tile's bias, in front of the second-to-last K-step's DMA batch (that step's vmcnt(8) retires it)
+    load_bias(tn);                                       // this tile's bias, in front of the second-to-last K-step's DMA batch (that step's vmcnt(8) retires it)
     substep(IC<0>{}, IC<-1>{});
     last_substep();                                      // ... and converts the finished tile
     // this tile becomes the one on its way out
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     c_prev = make_rsrc(C + ((long long)tm * TM * ldc + tn * TN), tile_bytes);
     prev_valid = true;
     if constexpr (!PARK) flush_all();        // reference point: the tile is stored here, exposed
@@ -475,11 +528,12 @@ int main(int argc, char** argv) {
   const int tiles_m = M / TM, tiles_n = N / TN, ntiles = tiles_m * tiles_n;
   const int grid = ntiles < ncu ? ntiles : ncu;
   const int only = argc > 4 ? atoi(argv[4]) : -1;            // 0 / 1: run one variant only
+  const int gm_arg = argc > 5 ? atoi(argv[5]) : 4;           // m-tiles per group of the XCD-aware walk
   for (int park = 0; park < 2; ++park) {
     if (only >= 0 && only != park) continue;
     auto launch = [&]() {
-      if (park) hipLaunchKernelGGL(g256p<1>, dim3(grid), dim3(256), SMEM, 0, dA, dB, dBias, dC, M, N, K, tiles_n, ntiles);
-      else hipLaunchKernelGGL(g256p<0>, dim3(grid), dim3(256), SMEM, 0, dA, dB, dBias, dC, M, N, K, tiles_n, ntiles);
+      if (park) hipLaunchKernelGGL(g256p<1>, dim3(grid), dim3(256), SMEM, 0, dA, dB, dBias, dC, M, N, K, tiles_n, ntiles, gm_arg);
+      else hipLaunchKernelGGL(g256p<0>, dim3(grid), dim3(256), SMEM, 0, dA, dB, dBias, dC, M, N, K, tiles_n, ntiles, gm_arg);
     };
     hipMemset(dC, 0xff, hc.size() * 2);
     launch();

@@ -46,6 +46,7 @@ _SIGS = {
     "mpv_version": (c_int, []),
     "mpv_last_error": (C.c_char_p, []),
     "mpv_check_device": (c_int, []),
+    "mpv_check_arch_name": (c_int, [C.c_char_p]),
     "mpv_gemm_workspace_size": (c_size_t, [c_int64, c_int64, c_int64, c_int, c_int]),
     "mpv_gemm_plan_bands": (c_int, [c_int64, c_int64, c_int64, c_int, c_int, c_int, C.POINTER(c_int)]),
     "mpv_gemm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64,

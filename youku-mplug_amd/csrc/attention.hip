@@ -23,7 +23,7 @@
 #include <type_traits>
 
 #include "mpv_common.h"
-#include "mpv_kernels.h"
+#include "../../include/mpv.h"
 
 namespace {
 

@@ -9,7 +9,7 @@
 // opencv pieces (warpAffine's fixed-point bilinear remap, filter2D's float accumulation) follow the restatement there -- see its
 // header for what is pinned against the reference and what is not.
 #include "mpv_common.h"
-#include "mpv_kernels.h"
+#include "../../include/mpv.h"
 
 namespace {
 

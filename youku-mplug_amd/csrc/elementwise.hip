@@ -3,7 +3,7 @@
 // (bias / broadcast-parameter gradients), GPT embedding front and masked cross-entropy.
 // All of them move 8-16 bytes per lane per access, rows contiguous across a wave.
 #include "mpv_common.h"
-#include "mpv_kernels.h"
+#include "../../include/mpv.h"
 
 namespace {
 

@@ -27,7 +27,7 @@
 #include <stdlib.h>
 
 #include "mpv_common.h"
-#include "mpv_kernels.h"
+#include "../../include/mpv.h"
 #include "gemm_args.h"
 
 namespace {
@@ -709,6 +709,11 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
   if (!transA) MPV_REQUIRE(K % 8 == 0, MPV_E_ALIGN, "mpv_gemm_bf16: K (%lld) must be a multiple of 8", (long long)K);
   if (transA) MPV_REQUIRE(M % 8 == 0, MPV_E_ALIGN, "mpv_gemm_bf16: M (%lld) must be a multiple of 8 when transA", (long long)M);
   MPV_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0, MPV_E_ALIGN, "mpv_gemm_bf16: operands must be 16-byte aligned");
+  // a leading dimension shorter than the row it strides over would make rows overlap (the kernels' buffer descriptors are sized from
+  // rows x ld): refused, not clipped
+  MPV_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? N : K) && ldc >= N, MPV_E_SHAPE,
+              "mpv_gemm_bf16: leading dimension shorter than its row (lda=%lld ldb=%lld ldc=%lld for M=%lld N=%lld K=%lld, transA=%d transB=%d)",
+              (long long)lda, (long long)ldb, (long long)ldc, (long long)M, (long long)N, (long long)K, transA, transB);
 
   GemmArgs g = {};
   g.A = (const bf16*)A;
@@ -810,7 +815,7 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
           (size_t)M * N * sizeof(float) * ep->split_hint + (size_t)ep->split_hint * M * sizeof(float) <= (workspace ? workspace_bytes : 0))
         s256 = ep->split_hint;
     } else if (!g.out_f32 && t256 * 2 <= 256 && K >= 4096 && !g.act && !g.residual && !g.act_bwd && !g.tap_out &&
-             !g.preact && g.cmap.group == 0 && ldc == N && N % 4 == 0) {
+             !g.preact && g.cmap.group == 0 && ldc == N && N % 4 == 0 && ((uintptr_t)g.bias & 7) == 0) {      // (the reduce reads the bias as bf16x4)
       // few tiles, long reduction, plain / bias / bias + dropout epilogue (applied by the reduce): split-K over the idle CUs (at most
       // the 16 splits the workspace size allows for)
       s256 = choose_splitk256(t256, K, M, N, workspace ? workspace_bytes : 0);
@@ -838,7 +843,8 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
       ReduceEpi repi = {};
       if (h.splits > 1) {
         const bool wgrad = transA && transB;
-        ok = ok && (wgrad ? (!g.bias && !g.drop_thr) : N % 4 == 0) && !g.act && !g.residual && !g.act_bwd && g.cmap.group == 0 && ldc == N;
+        ok = ok && (wgrad ? (!g.bias && !g.drop_thr) : (N % 4 == 0 && ((uintptr_t)g.bias & 7) == 0)) && !g.act && !g.residual && !g.act_bwd &&
+             g.cmap.group == 0 && ldc == N;
         if (!wgrad) {       // forward / dgrad product split along K: bias and dropout move into the reduce
           repi = ReduceEpi{g.bias, (int)N, g.drop_thr, g.drop_scale, g.seed, g.drop_offset};
           h.bias = nullptr;

@@ -35,7 +35,7 @@
 #include <type_traits>
 
 #include "mpv_common.h"
-#include "mpv_kernels.h"
+#include "../../include/mpv.h"
 #include "gemm_args.h"
 
 namespace {

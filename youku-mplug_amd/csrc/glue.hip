@@ -2,7 +2,7 @@
 // float round trips) off the hot path of the step: each replaces a chain of 4-12 generic element-wise launches of the
 // host framework by ONE launch.  All of them move a few KB; what they save is launches (1.2-1.9 us per kernel boundary).
 #include "mpv_common.h"
-#include "mpv_kernels.h"
+#include "../../include/mpv.h"
 
 namespace {
 

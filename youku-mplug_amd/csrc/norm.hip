@@ -6,7 +6,7 @@
 // layer) and per-block partial dgamma/dbeta sums (finalised by a second tiny kernel).
 #include <cstdlib>
 #include "mpv_common.h"
-#include "mpv_kernels.h"
+#include "../../include/mpv.h"
 
 namespace {
 
@@ -889,7 +889,9 @@ extern "C" int mpv_layernorm_bwd(const void* dy, const void* x, const void* gamm
   MPV_REQUIRE(drop_p >= 0.f && drop_p < 1.f, MPV_E_ARG, "mpv_layernorm_bwd: bad dropout_p");
   if (rows == 0) return MPV_OK;
   const bool dparam = dgamma != nullptr;
-  int grid = ln_bwd_blocks(rows);
+  // the 768-workgroup cap belongs to the prefetching parameter-gradient kernel (and to the partial rows mpv_layernorm_bwd_partial_rows
+  // promises a deferred finish); a launch without parameter gradients keeps the 1024 that was measured best for it
+  int grid = dparam ? ln_bwd_blocks(rows) : (int)((rows + 3) / 4 < LN_BWD_MAX_BLOCKS ? (rows + 3) / 4 : LN_BWD_MAX_BLOCKS);
   if (dparam)
     MPV_REQUIRE(workspace && workspace_bytes >= (size_t)(grid + LN_L1_ROWS) * 2 * cols * sizeof(float), MPV_E_ARG,
                 "mpv_layernorm_bwd: workspace too small (need %zu bytes)", (size_t)(grid + LN_L1_ROWS) * 2 * cols * sizeof(float));

@@ -2,7 +2,7 @@
 // Replaces DeepSpeed FusedAdam + bf16 master-weight handling + global-norm clipping
 // (run_pretrain_distributed_gpt3.py:137; utils.py:490-529); math of optim/adamw.py:66-115.
 #include "mpv_common.h"
-#include "mpv_kernels.h"
+#include "../../include/mpv.h"
 
 namespace {
 

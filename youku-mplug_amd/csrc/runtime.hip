@@ -5,7 +5,7 @@
 #include <string.h>
 
 #include "mpv_common.h"
-#include "mpv_kernels.h"
+#include "../../include/mpv.h"
 
 static thread_local char g_err[512] = "";
 
@@ -39,8 +39,18 @@ extern "C" int mpv_check_device(void) {
     mpv_set_error("mpv_check_device: hipGetDeviceProperties failed");
     return MPV_E_HIP;
   }
-  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-    mpv_set_error("mpv_check_device: kernels are built for gfx950 only, device is %s", prop.gcnArchName);
+  return mpv_check_arch_name(prop.gcnArchName);
+}
+
+// the comparison mpv_check_device makes, on a caller-supplied gcnArchName ("gfx950:sramecc+:xnack-"): lets a host decide before it
+// touches a device, and lets the error path be exercised on a gfx950 box
+extern "C" int mpv_check_arch_name(const char* gcn_arch_name) {
+  if (!gcn_arch_name) {
+    mpv_set_error("mpv_check_arch_name: null name");
+    return MPV_E_ARG;
+  }
+  if (strncmp(gcn_arch_name, "gfx950", 6) != 0 || (gcn_arch_name[6] != '\0' && gcn_arch_name[6] != ':')) {
+    mpv_set_error("mpv_check_device: kernels are built for gfx950 only, device is %s", gcn_arch_name);
     return MPV_E_ARCH;
   }
   return MPV_OK;

@@ -565,6 +565,9 @@ class MplugEngine(nn.Module):
         self.last_load_missing_keys = list(missing)
         op = os.path.join(d, self._zero_file() if self.zero_shards is not None else "mp_rank_00_optim_states.pt")
         osd = torch.load(op, map_location=self.flat.device) if os.path.isfile(op) else None
+        # the dropout stream's position is read BEFORE an unusable shard is discarded (a resume at another world size restarts the
+        # moments, not the mask sequence)
+        seen_osd = osd.get("micro_batches_seen") if osd is not None else None
         usable = osd is not None and osd["master"].numel() == self.optimizer.master.numel() and \
             tuple(osd.get("shard", (0, self.flat.numel))) == (self.optimizer.lo, self.optimizer.hi)
         if self.zero_shards is not None:
@@ -592,8 +595,8 @@ class MplugEngine(nn.Module):
         self.micro_steps = 0
         self.reducer.pending.clear()
         self.reducer.launched.clear()
-        if osd is not None:
-            self.micro_batches_seen = int(osd.get("micro_batches_seen", self.micro_batches_seen))
+        if seen_osd is not None:
+            self.micro_batches_seen = int(seen_osd)
         self._set_dropout_seed()
         return d, state
 

@@ -95,6 +95,8 @@ class DecodeState:
         from . import _lib
         B, H = self.batch, self.H
         qf = None if query_embeds is None else query_embeds.reshape(-1, H).to(torch.bfloat16).contiguous()
+        if query_embeds is not None and self.twin is not None:
+            self._twin_shared = 0                    # a new visual prefix: the twin's copy of the shared positions is stale (reorder re-gathers from 0)
         Q = 0 if qf is None else qf.shape[0] // B
         L = 0 if tokens is None else tokens.shape[1]
         ids = tokens.contiguous() if L else None
