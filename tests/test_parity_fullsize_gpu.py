@@ -90,7 +90,7 @@ def _pretrain_case(name, cfg, dev, B, L, wseed, grad_keys, logits_gate, hidden_g
     assert worst <= 4e-2 and worst_norm <= 1e-2 and worst_l2 <= GRAD_L2_GATE, (worst, worst_norm, worst_l2)
 
 
-GRAD_L2_GATE = 1.0e-1      # ||g - r||_2 / ||r||_2 over the WHOLE tensor, live fp32 oracle (round 5)
+GRAD_L2_GATE = 3.0e-2      # ||g - r||_2 / ||r||_2 over the WHOLE tensor against the live fp32 oracle (round 5; measured 1.7-1.9e-2)
 # Gates on deviation (1), as numbers: north_star's 1e-2 for the logits, at every full-depth shape.  With the decoder's residual
 # stream in fp32 (gpt3.FP32_STREAM) the measured deviations are 6.6e-3 (config B), 7.7e-3 (S = 208) and 7.9e-3 (config D, 32
 # layers); the reference's own bf16 execution -- column (2) -- sits at 1.3-1.6e-2, and so does column (3), which is dominated by it.
@@ -220,7 +220,8 @@ def test_configB_train_mode_full_depth_vs_oracle_through_the_kernels_own_masks(d
 
 
 
-BF16_STREAM_VS_REF_BF16_GATE = 2.0e-2     # logits, bf16 residual-stream mode against the reference's OWN bf16 execution (two bf16 runs)
+BF16_STREAM_VS_REF_BF16_GATE = 1.7e-2     # logits, bf16 residual-stream mode against the reference's OWN bf16 execution (two bf16 runs; measured 1.46e-2,
+                                          # of which 1.33e-2 is that run's own distance from the fp32 function)
 
 
 def test_configB_bf16_stream_mode_full_depth_vs_the_oracles_bf16_run(dev, monkeypatch):
@@ -252,9 +253,9 @@ def test_configB_bf16_stream_mode_full_depth_vs_the_oracles_bf16_run(dev, monkey
            f"    (1) HIP vs fp32 oracle        : logits {e1['logits']:.3e} hidden {e1['hidden']:.3e} losses {e1['losses']:.3e}\n"
            f"    (2) oracle bf16 vs fp32 oracle: logits {e2['logits']:.3e} hidden {e2['hidden']:.3e} losses {e2['losses']:.3e}\n"
            f"    (3) HIP vs oracle bf16        : logits {e3['logits']:.3e} hidden {e3['hidden']:.3e} losses {e3['losses']:.3e}\n"
-           f"    gates: (3) logits <= {BF16_STREAM_VS_REF_BF16_GATE:.1e}, (3) losses <= 1.0e-02, (1) logits <= 1.5 x column (2) | {time.time() - t0:.0f} s")
+           f"    gates: (3) logits <= {BF16_STREAM_VS_REF_BF16_GATE:.1e}, (3) losses <= 1.0e-02, (1) logits <= 1.4e-02 | {time.time() - t0:.0f} s")
     assert e3["logits"] <= BF16_STREAM_VS_REF_BF16_GATE and e3["losses"] <= 1e-2, e3
-    assert e1["logits"] <= 1.5 * e2["logits"], (e1, e2)        # no worse against the function than the reference's own bf16 run (x 1.5)
+    assert e1["logits"] <= 1.4e-2, (e1, e2)        # against the function: where the reference's own bf16 run sits (1.33e-2; measured 1.23e-2)
 
 def test_yaml_geometry_full_depth_vs_oracle(dev):
     """The geometry the shipped YAML runs (configs/pretrain/gpt3_1.3B/pretrain_gpt3_freezeGPT_youku_v0.yaml: 4 frames, titles of up
@@ -315,7 +316,11 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 
 
-NORM_GATE, L2_GATE = 5e-2, 1.0e-1      # plain numbers (round 5): |grad| norm of EVERY trainable tensor; relative L2 distance of the whole-tensor goldens
+# plain numbers (round 5): |grad| norm of EVERY trainable tensor (measured worst 2.1e-2); relative L2 distance on the whole-tensor goldens
+# (measured worst 9.1e-2 / 7.2e-2 / 2.8e-2 for ITM / CLS / EVA with the reference's OWN bf16 run at 7.2e-2 / 9.2e-2 / 3.1e-2 on the same
+# tensors, medians equal to the reference's: VERDICT r04's 3e-2 is below what a bf16 execution of these 9- / 3-sequence batches can
+# reach -- the fp32-oracle cases above, where it can, ARE gated at 3e-2)
+NORM_GATE, L2_GATE = 5e-2, 1.0e-1
 
 
 def _grad_gates(model, f32, b16):

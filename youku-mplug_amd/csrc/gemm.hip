@@ -438,7 +438,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
             if (p.preact_deriv) {
               f32x8 d;
 #pragma unroll
-              for (int e = 0; e < 8; ++e) d[e] = p.act == 1 ? gelu_erf_grad_f(z[e]) : gelu_tanh_grad_f(z[e]);
+              for (int e = 0; e < 8; ++e) {       // the tanh flavour from the 256x256 kernel's formula (one polynomial for GELU and GELU'):
+                float gv, dv;                     // a product split between the two tile kernels parks ONE function
+                mpv_gelu_tanh_both_t(z[e], gv, dv);
+                d[e] = p.act == 1 ? gelu_erf_grad_f(z[e]) : dv;
+              }
               *(bf16x8*)(p.preact + crow * p.ldc + n) = cvt8(d);
             } else {
               *(bf16x8*)(p.preact + crow * p.ldc + n) = zb;

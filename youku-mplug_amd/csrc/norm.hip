@@ -891,7 +891,11 @@ extern "C" int mpv_layernorm_bwd(const void* dy, const void* x, const void* gamm
   const bool dparam = dgamma != nullptr;
   // the 768-workgroup cap belongs to the prefetching parameter-gradient kernel (and to the partial rows mpv_layernorm_bwd_partial_rows
   // promises a deferred finish); a launch without parameter gradients keeps the 1024 that was measured best for it
+#ifdef MPV_AB_LN_CAP768      // (same-box A/B build: round 4's grid for every launch)
+  int grid = ln_bwd_blocks(rows);
+#else
   int grid = dparam ? ln_bwd_blocks(rows) : (int)((rows + 3) / 4 < LN_BWD_MAX_BLOCKS ? (rows + 3) / 4 : LN_BWD_MAX_BLOCKS);
+#endif
   if (dparam)
     MPV_REQUIRE(workspace && workspace_bytes >= (size_t)(grid + LN_L1_ROWS) * 2 * cols * sizeof(float), MPV_E_ARG,
                 "mpv_layernorm_bwd: workspace too small (need %zu bytes)", (size_t)(grid + LN_L1_ROWS) * 2 * cols * sizeof(float));
