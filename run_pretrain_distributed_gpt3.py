@@ -76,8 +76,10 @@ def train_one_epoch(model, tokenizer, data_loader, optimizer, device, epoch, num
     model.micro_steps = 0
     sums, count = {}, 0
     world = dist.get_world_size()
+    # (data parallel: graph_step replays a chain of segments with the bucket all-reduces issued between them; ZeRO-1 shares its shards
+    # with one more collective after the optimizer step and keeps the eager step)
     use_graph = os.environ.get("MPV_GRAPH", "0") == "1" and update_freq == 1 and device.type == "cuda" and \
-        (world == 1 or os.environ.get("MPV_GRAPH_DP") == "1")
+        (world == 1 or getattr(model, "zero_shards", None) is None)
     for data_iter_step, (video, text) in enumerate(data_loader):
         t0 = time.time()
         step = data_iter_step // update_freq

@@ -130,14 +130,29 @@ class DPReducer:
         self.comm_dtype = comm_dtype or os.environ.get("MPV_DP_COMM_DTYPE", "bf16")
         assert self.comm_dtype in ("bf16", "fp32"), self.comm_dtype
         self._stage32: Dict[str, torch.Tensor] = {}
+        # MplugEngine.graph_step, while it CAPTURES a data-parallel step: a callable(action).  A bucket that becomes ready (and the
+        # final wait) then does not touch the communicator: it ends the graph segment being captured, and the replay loop issues
+        # the collective eagerly between two segment launches -- RCCL never runs inside a stream capture (round 5).
+        self.capture_cut = None
+
+    @property
+    def active(self):
+        return self.world > 1 or self.always
 
     def stage_ready(self, name: str):
         if getattr(self, "hold", False):
             return      # gradient accumulation: buckets go out from step(), once the window's sum is in place
-        if (self.world == 1 and not self.always) or name in self.launched or name not in self.flat.stage_slices:
+        if not self.active or name in self.launched or name not in self.flat.stage_slices:
             return
-        a, b = self.flat.stage_slices[name]
         self.launched.add(name)
+        if self.capture_cut is not None:
+            self.capture_cut(("bucket", name))
+            return
+        self.issue(name)
+
+    def issue(self, name: str):
+        """the all-reduce of one stage's slice of the flat gradient buffer, asynchronous, behind the current stream's work"""
+        a, b = self.flat.stage_slices[name]
         if self.comm_dtype == "fp32":
             from . import ops
             st = self._stage32.get(name)
@@ -150,17 +165,26 @@ class DPReducer:
 
     def finish(self):
         """Launch whatever was not announced, then make the current stream wait for every bucket."""
-        if self.world > 1 or self.always:
+        if self.active:
             for name in self.flat.stage_slices:
                 self.stage_ready(name)
-            for w, name in self.pending:
-                w.wait()
-                if self.comm_dtype == "fp32":
-                    from . import ops
-                    a, b = self.flat.stage_slices[name]
-                    ops.f32_to_bf16(self._stage32[name], self.flat.grads[a:b])     # one rounding of the fp32 sum
+            if self.capture_cut is not None:
+                self.capture_cut(("finish",))
+                self.launched.clear()
+                return
+            self.drain()
         self.pending.clear()
         self.launched.clear()
+
+    def drain(self):
+        """the current stream waits for every bucket in flight (fp32 wire: the sums are rounded into the bf16 gradients once)"""
+        for w, name in self.pending:
+            w.wait()
+            if self.comm_dtype == "fp32":
+                from . import ops
+                a, b = self.flat.stage_slices[name]
+                ops.f32_to_bf16(self._stage32[name], self.flat.grads[a:b])     # one rounding of the fp32 sum
+        self.pending.clear()
 
 
 class FlatAdamW:
@@ -435,9 +459,16 @@ class MplugEngine(nn.Module):
         Call 1 runs eagerly (every lazily created buffer and kernel attribute exists afterwards), call 2 captures the step and
         replays it, later calls copy the inputs into the captured buffers, write the step's scalars and replay.  Shapes must
         not change between calls (pre-training: they do not).  Returns the loss tensor of the step (a static buffer from call
-        2 on).  No gradient accumulation; world size 1 unless MPV_GRAPH_DP=1 says the collectives may be captured too."""
+        2 on).  No gradient accumulation.
+
+        Data parallel (world > 1, or the reducer's `always` switch): the step is captured as a CHAIN of graph segments cut where a
+        gradient bucket becomes ready and where the step waits for the buckets; a replay launches the segments in order and issues the
+        collectives EAGERLY between them (same order, same streams and events as the eager step: ProcessGroupNCCL orders each
+        all-reduce behind the segment just launched, `wait()` orders the next segment behind the reduction).  RCCL inside a stream
+        capture (round 4's MPV_GRAPH_DP=1) took the process down in hipStreamEndCapture once in nine suite runs; it is gone.  Host
+        cost of a replay: ~16 graph launches + 14 all-reduce calls instead of one launch."""
         assert self.gas == 1, "graph_step: no gradient accumulation"
-        assert self.reducer.world == 1 or os.environ.get("MPV_GRAPH_DP") == "1", "graph_step: data-parallel capture is opt-in (MPV_GRAPH_DP=1)"
+        assert self.zero_shards is None or not self.reducer.active, "graph_step: ZeRO-1 shares its shards with a collective after the optimizer step; use the eager step"
         self.enable_device_step_state()
         self._graph_calls += 1
 
@@ -486,17 +517,47 @@ class MplugEngine(nn.Module):
             static_in = tuple(clone_in(x) for x in inputs)
             counters = (self.optimizer.step_count,)
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
             self._upload_seeds = False
+            segs = []                                        # [(graph, action after it)]: action None | ("bucket", stage) | ("finish",)
             try:
-                # thread_local: a DataLoader's pin-memory thread (hipHostMalloc / event calls) must not invalidate the capture
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    static_loss = run(static_in)
+                if not self.reducer.active:
+                    g = torch.cuda.CUDAGraph()
+                    # thread_local: a DataLoader's pin-memory thread (hipHostMalloc / event calls) must not invalidate the capture
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        static_loss = run(static_in)
+                    segs.append((g, None))
+                else:
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    state = {"g": None, "pool": None}
+
+                    def begin():
+                        state["g"] = torch.cuda.CUDAGraph()
+                        if state["pool"] is None:
+                            state["g"].capture_begin(capture_error_mode="thread_local")
+                            state["pool"] = state["g"].pool()      # every segment allocates from the first one's pool (replayed in capture order)
+                        else:
+                            state["g"].capture_begin(pool=state["pool"], capture_error_mode="thread_local")
+
+                    def cut(action):
+                        state["g"].capture_end()
+                        segs.append((state["g"], action))
+                        begin()
+                    with torch.cuda.stream(side):
+                        self.reducer.capture_cut = cut
+                        try:
+                            begin()
+                            static_loss = run(static_in)
+                            state["g"].capture_end()
+                            segs.append((state["g"], None))
+                        finally:
+                            self.reducer.capture_cut = None
+                    torch.cuda.current_stream().wait_stream(side)
             finally:
                 self._upload_seeds = True
             (self.optimizer.step_count,) = counters          # the capture executed nothing
-            self._graph = (g, static_in, static_loss)
-        g, static_in, static_loss = self._graph
+            self._graph = (segs, static_in, static_loss)
+        segs, static_in, static_loss = self._graph
         # Bounded host run-ahead.  hipGraphLaunch on a FULL launch queue busy-waits (measured r03: 72 ms of CPU per 77 ms step,
         # where the eager path sleeps in the driver) -- on a host shared by eight ranks that spin is what starves the others.  So
         # the host launches step k + 1 only once step k + 1 - depth has FINISHED, and waits for that ASLEEP: a query / sleep poll
@@ -514,7 +575,13 @@ class MplugEngine(nn.Module):
             copy_in(d, s_)
         self.optimizer.step_count += 1
         self.optimizer.upload_hyper()                        # this step's lr / bias corrections -> device
-        g.replay()
+        for g, action in segs:
+            g.replay()
+            if action is not None:
+                if action[0] == "bucket":
+                    self.reducer.issue(action[1])
+                else:
+                    self.reducer.drain()
         if depth > 0:
             ev = torch.cuda.Event()
             ev.record()
