@@ -479,6 +479,7 @@ def main():
     dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
     if sampler is not None:
         sampler.__exit__()
+    final_loss = loss.item()                    # of the LAST TIMED step (under graph replay `loss` is a static buffer the extra launches below overwrite)
     log(f"host enqueue time {t_enq / args.steps * 1e3:.1f} ms/step wall, {t_cpu / args.steps * 1e3:.1f} ms/step CPU (launch-bound if the CPU figure approaches the step time)" +
         (" [MPV_GRAPH=1: graph replay]" if use_graph else ""))
     # the same on an IDLE queue (nothing to wait for): what the host really spends to launch one step
@@ -494,7 +495,6 @@ def main():
     if dist_on:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = dt.item()
-    final_loss = loss.item()
     log(f"timed region done: {dt / args.steps * 1e3:.1f} ms/step")
     ms_ = {} if _ON_CPU else torch.cuda.memory_stats(dev)
     log(f"device memory: peak allocated {ms_.get('allocated_bytes.all.peak', 0) / 2**30:.1f} GiB, peak reserved {ms_.get('reserved_bytes.all.peak', 0) / 2**30:.1f} GiB, "
@@ -572,7 +572,7 @@ def main():
                "dtype": "bf16", "data": "synthetic",
                "config": {"workload": f"{names[args.config]}, per-GPU bs={B} x {T} frames x 224^2 + {L}-token titles",
                           "global_batch": world * B, "frames": T, "text_len": L, "queries": Shapes.num_queries, "parallelism": f"dp{world}",
-                          "trainable_params_m": round(engine.flat.numel / 1e6, 1), "final_loss": round(final_loss, 4)},
+                          "trainable_params_m": round(engine.flat.numel / 1e6, 1), "final_loss": round(final_loss, 6)},
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(rec), flush=True)
     if dist_on:

@@ -7,7 +7,7 @@ timeout 900 python -m pytest -q -x -m gpu -p no:cacheprovider "tests/test_model_
   "tests/test_model_gpu.py::test_graph_step_bit_identical_to_eager" "tests/test_gemm256_gpu.py::test_parked_gelu_derivative_does_not_depend_on_the_tile_kernel" \
   "tests/test_gemm256_gpu.py::test_gemm_gelu_derivative_parked_by_the_forward" "tests/test_entrypoint_gpu.py" > gpurun_out/r05_c7_tests.log 2>&1
 tail -8 gpurun_out/r05_c7_tests.log
-bash tools/ab_same_box.sh lib gpurun_ab/libmpv_hip_ln768.so 2>&1 | tee gpurun_out/r05_c7_ab_ln_grid.log
+for gm in 2 8 16; do echo -n "MPV_GEMM_GM=$gm "; MPV_GEMM_GM=$gm python bench.py --no-cpu-baseline --no-roofline --steps 30 2>&1 | grep -E "timed region" | sed "s/.*timed region done: //"; done | tee gpurun_out/r05_c7_gm.log; echo -n "default "; python bench.py --no-cpu-baseline --no-roofline --steps 30 2>&1 | grep -E "timed region" | sed "s/.*timed region done: //"
 for mode in eager graph; do
   if [ $mode = graph ]; then export MPV_GRAPH=1; else unset MPV_GRAPH; fi
   MPV_BENCH_FORCE_DIST=1 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > gpurun_out/r05_c7_bench_dist_$mode.json 2> gpurun_out/r05_c7_bench_dist_$mode.err

@@ -529,18 +529,17 @@ class MplugEngine(nn.Module):
                 else:
                     side = torch.cuda.Stream()
                     side.wait_stream(torch.cuda.current_stream())
-                    state = {"g": None, "pool": None}
+                    # every segment allocates from ONE private pool (the segments are replayed in capture order, never concurrently)
+                    state = {"g": None, "open": False, "pool": torch.cuda.graph_pool_handle()}
 
                     def begin():
                         state["g"] = torch.cuda.CUDAGraph()
-                        if state["pool"] is None:
-                            state["g"].capture_begin(capture_error_mode="thread_local")
-                            state["pool"] = state["g"].pool()      # every segment allocates from the first one's pool (replayed in capture order)
-                        else:
-                            state["g"].capture_begin(pool=state["pool"], capture_error_mode="thread_local")
+                        state["g"].capture_begin(pool=state["pool"], capture_error_mode="thread_local")
+                        state["open"] = True
 
                     def cut(action):
                         state["g"].capture_end()
+                        state["open"] = False
                         segs.append((state["g"], action))
                         begin()
                     with torch.cuda.stream(side):
@@ -549,9 +548,15 @@ class MplugEngine(nn.Module):
                             begin()
                             static_loss = run(static_in)
                             state["g"].capture_end()
+                            state["open"] = False
                             segs.append((state["g"], None))
                         finally:
                             self.reducer.capture_cut = None
+                            if state["open"]:            # an exception inside the step: close the capture before the graph object dies
+                                try:                     # (destroying a graph whose stream still captures terminates the process)
+                                    state["g"].capture_end()
+                                except Exception:
+                                    pass
                     torch.cuda.current_stream().wait_stream(side)
             finally:
                 self._upload_seeds = True
