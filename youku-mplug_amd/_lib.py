@@ -154,6 +154,11 @@ def lib():
     return _lib
 
 
+n_calls = 0      # C-ABI calls checked so far (engine.graph_step: "has this graph segment captured anything yet?")
+
+
 def check(rc: int, what: str = ""):
+    global n_calls
+    n_calls += 1
     if rc != 0:
         raise MpvError(f"{what} failed ({rc}): {lib().mpv_last_error().decode()}")

@@ -518,29 +518,33 @@ class MplugEngine(nn.Module):
             counters = (self.optimizer.step_count,)
             torch.cuda.synchronize()
             self._upload_seeds = False
-            segs = []                                        # [(graph, action after it)]: action None | ("bucket", stage) | ("finish",)
+            segs = []                                        # [(graph, actions after it)]: ("bucket", stage) | ("finish",)
             try:
                 if not self.reducer.active:
                     g = torch.cuda.CUDAGraph()
                     # thread_local: a DataLoader's pin-memory thread (hipHostMalloc / event calls) must not invalidate the capture
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):
                         static_loss = run(static_in)
-                    segs.append((g, None))
+                    segs.append((g, []))
                 else:
                     side = torch.cuda.Stream()
                     side.wait_stream(torch.cuda.current_stream())
                     # every segment allocates from ONE private pool (the segments are replayed in capture order, never concurrently)
-                    state = {"g": None, "open": False, "pool": torch.cuda.graph_pool_handle()}
+                    from . import _lib
+                    state = {"g": None, "open": False, "pool": torch.cuda.graph_pool_handle(), "calls": 0}
 
                     def begin():
                         state["g"] = torch.cuda.CUDAGraph()
                         state["g"].capture_begin(pool=state["pool"], capture_error_mode="thread_local")
-                        state["open"] = True
+                        state["open"], state["calls"] = True, _lib.n_calls
 
                     def cut(action):
+                        if segs and _lib.n_calls == state["calls"]:
+                            segs[-1][1].append(action)      # nothing launched since the last cut (the last bucket, then the wait): no empty segment
+                            return
                         state["g"].capture_end()
                         state["open"] = False
-                        segs.append((state["g"], action))
+                        segs.append((state["g"], [action]))
                         begin()
                     with torch.cuda.stream(side):
                         self.reducer.capture_cut = cut
@@ -549,7 +553,7 @@ class MplugEngine(nn.Module):
                             static_loss = run(static_in)
                             state["g"].capture_end()
                             state["open"] = False
-                            segs.append((state["g"], None))
+                            segs.append((state["g"], []))
                         finally:
                             self.reducer.capture_cut = None
                             if state["open"]:            # an exception inside the step: close the capture before the graph object dies
@@ -580,9 +584,9 @@ class MplugEngine(nn.Module):
             copy_in(d, s_)
         self.optimizer.step_count += 1
         self.optimizer.upload_hyper()                        # this step's lr / bias corrections -> device
-        for g, action in segs:
+        for g, actions in segs:
             g.replay()
-            if action is not None:
+            for action in actions:
                 if action[0] == "bucket":
                     self.reducer.issue(action[1])
                 else:
