@@ -54,6 +54,20 @@ template <int V>
 using IC = std::integral_constant<int, V>;
 
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// 16-byte output stores of the finish pass.  NON-TEMPORAL (round 5): an output tile is written once and not read again by this launch;
+// as plain stores its 128 KiB per tile pushed the A / B panels the resident workgroups share out of the XCD's 4 MiB L2 (same-box
+// alternation of whole libraries: GEMM family 60.5 -> 58.8 ms per step, step 76.0 -> 75.1 ms, identical results;
+// profiles/r05_c14_gemm_store_flavours_ab.log).  -DMPV_AB_PLAIN_C / _2ND / _EXT, -DMPV_AB_NT_F32, -DMPV_AB_NT_DMA_A / _B: A/B builds (profiles/r05_c15_*, r05_c16_*).
+#ifdef MPV_AB_PLAIN_C
+#define MPV_ST_C(ptr, val) (*(bf16x8*)(ptr) = (val))
+#else
+#define MPV_ST_C(ptr, val) __builtin_nontemporal_store((val), (bf16x8*)(ptr))
+#endif
+#ifdef MPV_AB_PLAIN_2ND
+#define MPV_ST_2ND(ptr, val) (*(bf16x8*)(ptr) = (val))
+#else
+#define MPV_ST_2ND(ptr, val) __builtin_nontemporal_store((val), (bf16x8*)(ptr))
+#endif
 
 __device__ __forceinline__ bf16x8 lds_read_tr8(const char* p) {
   // two transposing reads: k rows +0..3 and +4..7 (1 KiB apart in the [k][256 B] image)
@@ -134,8 +148,13 @@ __device__ __forceinline__ void prefetch_rows(const GemmArgs& p, EpExt<KIND, NIT
       const int m = m0 + (c >> 5), n = n0 + (c & 31) * 8;
       x.v[it] = bf16x8{};
       if (m < p.M && n < p.N) {
+#ifndef MPV_AB_PLAIN_EXT      // read once, by this thread only: non-temporal (step 74.3 -> 74.0 ms on top of the non-temporal stores)
+        if constexpr (KIND == EP_BWD_ERF || KIND == EP_BWD_TANH || KIND == EP_MUL) x.v[it] = __builtin_nontemporal_load((const bf16x8*)(p.actz + (long long)m * p.ldz + n));
+        else x.v[it] = __builtin_nontemporal_load((const bf16x8*)(p.residual + map_row(p.cmap, m) * p.ldr + n));
+#else
         if constexpr (KIND == EP_BWD_ERF || KIND == EP_BWD_TANH || KIND == EP_MUL) x.v[it] = *(const bf16x8*)(p.actz + (long long)m * p.ldz + n);
         else x.v[it] = *(const bf16x8*)(p.residual + map_row(p.cmap, m) * p.ldr + n);
+#endif
       }
     }
   }
@@ -166,7 +185,7 @@ __device__ __forceinline__ void finish_rows(const GemmArgs& p, const EpExt<KIND,
       const long long crow = map_row(p.cmap, m);
       bf16* cp = (bf16*)p.C + crow * p.ldc + n;
       if constexpr (KIND == EP_PLAIN) {
-        *(bf16x8*)cp = zb;
+        MPV_ST_C(cp, zb);
       } else if constexpr (KIND == EP_ERF_PRE || KIND == EP_TANH_PRE) {
         constexpr int A = KIND == EP_ERF_PRE ? MPV_ACT_GELU_ERF : MPV_ACT_GELU_TANH;
         // preact_deriv: the second output is act'(z) for the dgrad to multiply by (one wave-uniform branch per 8-element chunk);
@@ -182,37 +201,37 @@ __device__ __forceinline__ void finish_rows(const GemmArgs& p, const EpExt<KIND,
               gv[e] = g2[0]; gv[e + 1] = g2[1];
               dv[e] = d2[0]; dv[e + 1] = d2[1];
             }
-            *(bf16x8*)(p.preact + crow * p.ldc + n) = cvt8(dv);
-            *(bf16x8*)cp = cvt8(gv);
+            MPV_ST_2ND((p.preact + crow * p.ldc + n), cvt8(dv));
+            MPV_ST_C(cp, cvt8(gv));
           } else {
-            *(bf16x8*)(p.preact + crow * p.ldc + n) = cvt8(act_deriv<A>(cvt8(zb)));
-            *(bf16x8*)cp = cvt8(apply_act<A>(cvt8(zb)));
+            MPV_ST_2ND((p.preact + crow * p.ldc + n), cvt8(act_deriv<A>(cvt8(zb))));
+            MPV_ST_C(cp, cvt8(apply_act<A>(cvt8(zb))));
           }
         } else {
-          *(bf16x8*)(p.preact + crow * p.ldc + n) = zb;
-          *(bf16x8*)cp = cvt8(apply_act<A>(cvt8(zb)));
+          MPV_ST_2ND((p.preact + crow * p.ldc + n), zb);
+          MPV_ST_C(cp, cvt8(apply_act<A>(cvt8(zb))));
         }
       } else if constexpr (KIND == EP_BWD_ERF || KIND == EP_BWD_TANH) {
-        *(bf16x8*)cp = cvt8(apply_act_grad<KIND == EP_BWD_ERF ? MPV_ACT_GELU_ERF : MPV_ACT_GELU_TANH>(cvt8(zb), cvt8(ex)));
+        MPV_ST_C(cp, cvt8(apply_act_grad<KIND == EP_BWD_ERF ? MPV_ACT_GELU_ERF : MPV_ACT_GELU_TANH>(cvt8(zb), cvt8(ex))));
       } else if constexpr (KIND == EP_MUL) {          // act_bwd == MPV_ACT_DERIV: ex holds act'(z)
-        *(bf16x8*)cp = cvt8(cvt8(zb) * cvt8(ex));
+        MPV_ST_C(cp, cvt8(cvt8(zb) * cvt8(ex)));
       } else if constexpr (KIND == EP_RES) {
-        if (p.tap_out && m % p.tap_group == 0) *(bf16x8*)(p.tap_out + (long long)(m / p.tap_group) * p.N + n) = zb;
-        *(bf16x8*)cp = cvt8(cvt8(zb) + cvt8(ex));
+        if (p.tap_out && m % p.tap_group == 0) MPV_ST_2ND((p.tap_out + (long long)(m / p.tap_group) * p.N + n), zb);
+        MPV_ST_C(cp, cvt8(cvt8(zb) + cvt8(ex)));
       } else if constexpr (KIND == EP_DROP_RES) {
         const uint64_t base = p.drop_offset + (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
         const f32x8 v = mpv_dropout_vec<f32x8, 8>(cvt8(zb), seed_r, base, p.drop_thr, p.drop_scale);
-        *(bf16x8*)cp = cvt8(v + cvt8(ex));
+        MPV_ST_C(cp, cvt8(v + cvt8(ex)));
       } else if constexpr (KIND == EP_DROP) {       // dropout(acc + bias): the decoder's sublayer outputs (the residual add is the next LayerNorm's, in fp32)
         const uint64_t base = p.drop_offset + (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
-        *(bf16x8*)cp = cvt8(mpv_dropout_vec<f32x8, 8>(cvt8(zb), seed_r, base, p.drop_thr, p.drop_scale));
+        MPV_ST_C(cp, cvt8(mpv_dropout_vec<f32x8, 8>(cvt8(zb), seed_r, base, p.drop_thr, p.drop_scale)));
       } else {
         f32x8 v = cvt8(zb);
-        if (p.tap_out && m % p.tap_group == 0) *(bf16x8*)(p.tap_out + (long long)(m / p.tap_group) * p.N + n) = zb;
+        if (p.tap_out && m % p.tap_group == 0) MPV_ST_2ND((p.tap_out + (long long)(m / p.tap_group) * p.N + n), zb);
         if (p.act) {
           if (p.preact) {
-            if (p.preact_deriv) *(bf16x8*)(p.preact + crow * p.ldc + n) = cvt8(p.act == MPV_ACT_GELU_ERF ? act_deriv<MPV_ACT_GELU_ERF>(v) : act_deriv<MPV_ACT_GELU_TANH>(v));
-            else *(bf16x8*)(p.preact + crow * p.ldc + n) = zb;
+            if (p.preact_deriv) MPV_ST_2ND((p.preact + crow * p.ldc + n), cvt8(p.act == MPV_ACT_GELU_ERF ? act_deriv<MPV_ACT_GELU_ERF>(v) : act_deriv<MPV_ACT_GELU_TANH>(v)));
+            else MPV_ST_2ND((p.preact + crow * p.ldc + n), zb);
           }
           v = p.act == MPV_ACT_GELU_ERF ? apply_act<MPV_ACT_GELU_ERF>(v) : p.act == MPV_ACT_GELU_TANH ? apply_act<MPV_ACT_GELU_TANH>(v) : apply_act<MPV_ACT_RELU>(v);
         }
@@ -228,7 +247,7 @@ __device__ __forceinline__ void finish_rows(const GemmArgs& p, const EpExt<KIND,
         }
         if (p.residual) v += cvt8(*(const bf16x8*)(p.residual + crow * p.ldr + n));
         if (p.accumulate) v += cvt8(*(const bf16x8*)cp);
-        *(bf16x8*)cp = cvt8(v);
+        MPV_ST_C(cp, cvt8(v));
       }
     }
   }
@@ -240,6 +259,12 @@ __device__ __forceinline__ void finish_rows(const GemmArgs& p, const EpExt<KIND,
 // drain the ring every phase; the waits for these DMAs are the counted s_waitcnt vmcnt(N) of the schedule below.
 __device__ __forceinline__ void dma16(i32x4 rsrc, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+               : "memory");
+}
+__device__ __forceinline__ void dma16_nt(i32x4 rsrc, uint32_t lds_addr, uint32_t voff, uint32_t soff) {      // (A/B builds: -DMPV_AB_NT_DMA_A / _B)
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds"
                :
                : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
                : "memory");
@@ -345,12 +370,27 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const uint32_t dst = smem_base + (uint32_t)(slot * UNIT + (wave * 2 + j) * 1024);
+#if defined(MPV_AB_NT_DMA_A) && defined(MPV_AB_NT_DMA_B)
+      constexpr bool NT = true;
+#elif defined(MPV_AB_NT_DMA_A)
+      constexpr bool NT = isA;
+#elif defined(MPV_AB_NT_DMA_B)
+      constexpr bool NT = !isA;
+#elif defined(MPV_AB_NT_DMA_ACT)      // the ACTIVATION operand(s): A always; B too unless it is a weight (forward / dgrad forms: B = W)
+      constexpr bool NT = isA || (TA && TB);
+#else
+      constexpr bool NT = false;
+#endif
+      auto dma = [&](i32x4 rr, uint32_t d, uint32_t vv, uint32_t ss) {
+        if constexpr (NT) dma16_nt(rr, d, vv, ss);
+        else dma16(rr, d, vv, ss);
+      };
       if constexpr (!T) {
-        dma16(r, dst, vo[x][j] | dead, live ? (uint32_t)((kbeg + kt * TK) * 2) : 0u);
+        dma(r, dst, vo[x][j] | dead, live ? (uint32_t)((kbeg + kt * TK) * 2) : 0u);
       } else if constexpr (!kmapped) {
-        dma16(r, dst, vo[x][j] | dead, live ? (uint32_t)((long long)(kbeg + kt * TK) * ld * 2) : 0u);
+        dma(r, dst, vo[x][j] | dead, live ? (uint32_t)((long long)(kbeg + kt * TK) * ld * 2) : 0u);
       } else {
-        dma16(r, dst, (vo[x][j] == OOB ? OOB : vo[x][j] + (uint32_t)(prow[j] * ld * 2)) | dead, 0u);
+        dma(r, dst, (vo[x][j] == OOB ? OOB : vo[x][j] + (uint32_t)(prow[j] * ld * 2)) | dead, 0u);
       }
     }
   };
@@ -612,7 +652,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
           f32x4 v = *(const f32x4*)(cs + row * FPITCH + col);
           float* cp = (float*)p.C + (long long)split * p.M * p.N + map_row(p.cmap, m) * p.ldc + n;
           if (p.accumulate) v += *(const f32x4*)cp;
-          *(f32x4*)cp = v;
+#ifdef MPV_AB_NT_F32
+          __builtin_nontemporal_store(v, (f32x4*)cp);
+#else
+          *(f32x4*)cp = v;      // (split-K partials are read back by the reduce kernel right behind this launch: they stay cacheable)
+#endif
         }
       }
       __syncthreads();
