@@ -103,6 +103,10 @@ typedef struct mpv_gemm_epilogue {
   int gm_hint;            /* measurements: > 0 pins the m-tiles per n-tile of an XCD's tile walk in the 256x256 kernel       */
   int preact_deriv;       /* with act (GELU kinds) and preact_out: preact_out receives bf16(act'(bf16(acc + bias))) instead of the
                              pre-activation itself -- what the matching dgrad multiplies by (act_bwd = MPV_ACT_DERIV)               */
+  int keep_output;        /* cache hint.  0 (default): bf16 output tiles leave as NON-TEMPORAL stores -- a tile is written once, and as
+                             plain stores it pushes the operand panels its neighbours share out of the XCD's L2 (round 5: -1.2 ms per
+                             step).  1: plain stores -- for a SMALL output that a latency-bound kernel reads right behind this launch
+                             (the decoder's qkv product in front of its attention: 26 vs 34 us per layer)                             */
 } mpv_gemm_epilogue;
 
 size_t mpv_gemm_workspace_size(int64_t M, int64_t N, int64_t K, int transA, int transB);

@@ -68,7 +68,7 @@ gemm_calls = 0
 def gemm(a, b, M, N, K, *, out=None, trans_a=False, trans_b=False, lda=None, ldb=None, ldc=None, bias=None, act=0, preact_out=None,
          residual=None, ldr=0, act_bwd_z=None, act_bwd=0, ldz=0, dropout_p=0.0, seed=0, offset=0, alpha_dev=None, alpha=0.0,
          amap=IDENT, cmap=IDENT, kmap=IDENT, out_rows=None, accumulate=False, out_f32=False, colsum_out=None, tile_hint=0,
-         row_tap_out=None, row_tap_group=0, split_hint=0, gm_hint=0, preact_deriv=False, z_is_deriv=False):
+         row_tap_out=None, row_tap_group=0, split_hint=0, gm_hint=0, preact_deriv=False, z_is_deriv=False, keep_output=False):
     """include/mpv.h mpv_gemm_bf16: C[M,N] = epilogue(sum_k A(m,k) B(n,k)).  preact_deriv / z_is_deriv: the product's own pair of
     switches (ops.gemm): preact_out receives bf16(act'(zb)) and the dgrad multiplies by that tensor (MPV_ACT_DERIV)."""
     from youku_mplug_amd import ops as _ops

@@ -24,7 +24,7 @@ class GemmEpilogue(C.Structure):
         ("act_bwd_z", c_void_p), ("ldz", c_int64), ("act_bwd", c_int),
         ("dropout_p", c_float), ("seed", c_uint64), ("offset", c_uint64),
         ("alpha_dev", c_void_p), ("alpha", c_float), ("out_f32", c_int), ("accumulate", c_int),
-        ("colsum_out", c_void_p), ("tile_hint", c_int), ("row_tap_out", c_void_p), ("row_tap_group", c_int), ("split_hint", c_int), ("gm_hint", c_int), ("preact_deriv", c_int),
+        ("colsum_out", c_void_p), ("tile_hint", c_int), ("row_tap_out", c_void_p), ("row_tap_group", c_int), ("split_hint", c_int), ("gm_hint", c_int), ("preact_deriv", c_int), ("keep_output", c_int),
     ]
 
 

@@ -747,6 +747,7 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
     MPV_REQUIRE(!ep->preact_deriv || (ep->preact_out && (ep->act == MPV_ACT_GELU_ERF || ep->act == MPV_ACT_GELU_TANH)), MPV_E_ARG,
                 "mpv_gemm_bf16: preact_deriv needs preact_out and a GELU activation");
     g.preact_deriv = ep->preact_deriv ? 1 : 0;
+    g.keep_c = ep->keep_output ? 1 : 0;
     if (ep->dropout_p > 0.f) {
       MPV_REQUIRE(ep->dropout_p < 1.f, MPV_E_ARG, "mpv_gemm_bf16: dropout_p must be < 1");
       g.drop_thr = mpv_drop_threshold(ep->dropout_p);

@@ -185,7 +185,8 @@ __device__ __forceinline__ void finish_rows(const GemmArgs& p, const EpExt<KIND,
       const long long crow = map_row(p.cmap, m);
       bf16* cp = (bf16*)p.C + crow * p.ldc + n;
       if constexpr (KIND == EP_PLAIN) {
-        MPV_ST_C(cp, zb);
+        if (p.keep_c) *(bf16x8*)cp = zb;      // (mpv.h keep_output: a small tile a latency-bound consumer reads next stays cacheable)
+        else MPV_ST_C(cp, zb);
       } else if constexpr (KIND == EP_ERF_PRE || KIND == EP_TANH_PRE) {
         constexpr int A = KIND == EP_ERF_PRE ? MPV_ACT_GELU_ERF : MPV_ACT_GELU_TANH;
         // preact_deriv: the second output is act'(z) for the dgrad to multiply by (one wave-uniform branch per 8-element chunk);

@@ -251,7 +251,7 @@ class DistributedGPT3(nn.Module):
                                                     add_dropout_p=p_l, seed=seed, offset=pend_off)
                 stream = nxt if nxt is not None else stream
                 h_in = stream                                                   # x of LayerNorm 1 (for its backward)
-                qkv = ops.gemm(x1, att.query_key_value.weight, R, 3 * H, H, bias=att.query_key_value.bias)
+                qkv = ops.gemm(x1, att.query_key_value.weight, R, 3 * H, H, bias=att.query_key_value.bias, keep_output=True)
                 ctx = torch.empty((R, H), dtype=torch.bfloat16, device=h.device)
                 lse = ops.attn_fwd(qkv, qkv[:, hn:], qkv[:, 2 * hn:], ctx, lay, B, np_, S, S, hn, causal=True, scale=scale,
                                    dropout_p=p_a, seed=seed, offset=_offset(ln, _SITE_ATTN))
@@ -332,7 +332,7 @@ class DistributedGPT3(nn.Module):
             ln = li + 1
             att, mlp = layer.self_attention, layer.mlp
             x1, m1, r1 = ops.layernorm_fwd(h, layer.input_layernorm.weight, layer.input_layernorm.bias, layer.input_layernorm.eps, R, H)
-            qkv = ops.gemm(x1, att.query_key_value.weight, R, 3 * H, H, bias=att.query_key_value.bias)
+            qkv = ops.gemm(x1, att.query_key_value.weight, R, 3 * H, H, bias=att.query_key_value.bias, keep_output=True)
             ctx = torch.empty((R, H), dtype=torch.bfloat16, device=h.device)
             lse = ops.attn_fwd(qkv, qkv[:, hn:], qkv[:, 2 * hn:], ctx, lay, B, np_, S, S, hn, causal=True, scale=scale,
                                dropout_p=p_a, seed=seed, offset=_offset(ln, _SITE_ATTN))
