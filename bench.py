@@ -20,7 +20,11 @@ import sys
 import time
 import types
 
-import torch
+# the host driver of this pool only supports dmabuf IPC: without it RCCL across processes fails in hipIpcGetMemHandle.  The launch environment
+# exports it already; set here too (before the HIP runtime comes up) so that a bare `torchrun bench.py --gpus N` is enough
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
