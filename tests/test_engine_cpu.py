@@ -482,3 +482,74 @@ def test_bf16_bucket_sum_error_world8_gloo(comm):
     worst = ((got - exact).abs().max() / exact.abs().max()).item()
     print(f"world-8 gradient sum, wire {comm}: norm-relative error {err:.2e}, max-abs / max-abs {worst:.2e}")
     assert err < (6e-3 if comm == "bf16" else 2.5e-3) and worst < 1e-2
+
+
+# ------------------------------------------------------------------ graph segments: the reducer's cut / issue / drain protocol, world 2
+def _cut_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from youku_mplug_amd import engine as eng
+    _stub_optimizer_kernels(_MP())
+    n = 1024
+    ps = [nn.Parameter(torch.zeros(n, dtype=torch.bfloat16)) for _ in range(3)]
+    flat = eng.FlatParams([("head", [ps[0]]), ("block0", [ps[1]]), ("stem", [ps[2]])])
+    red = eng.DPReducer(flat)
+
+    def fill(step):
+        g = torch.Generator().manual_seed(1000 * step + rank)
+        flat.grads.copy_(torch.randn(flat.grads.numel(), generator=g).to(torch.bfloat16))
+
+    # "capture": what engine.graph_step does while it records a data-parallel step -- every ready bucket and the final wait become
+    # actions of the schedule; nothing touches the communicator
+    actions = []
+    red.capture_cut = actions.append
+    red.stage_ready("head")
+    red.stage_ready("head")            # announced twice: one action
+    red.stage_ready("block0")
+    red.finish()                       # announces what is left ("stem"), then the wait
+    red.capture_cut = None
+    assert actions == [("bucket", "head"), ("bucket", "block0"), ("bucket", "stem"), ("finish",)], actions
+    assert not red.pending and not red.launched
+    # "replays": the recorded schedule issued eagerly, twice with different gradients; against the eager protocol on the same data
+    out = []
+    for step in (1, 2):
+        fill(step)
+        for a in actions:
+            if a[0] == "bucket":
+                red.issue(a[1])
+            else:
+                red.drain()
+        assert not red.pending
+        replayed = flat.grads.float().clone()
+        fill(step)
+        for name in ("head", "block0"):
+            red.stage_ready(name)
+        red.finish()
+        assert not red.pending and not red.launched
+        out.append((replayed, flat.grads.float().clone()))
+    if rank == 0:
+        q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reducer_cut_issue_drain_protocol_world2_gloo():
+    """engine.graph_step of a data-parallel step replays a chain of graph segments and issues the collectives between them from a schedule
+    the reducer recorded during capture (DPReducer.capture_cut -> issue / drain).  Two gloo ranks: the recorded schedule holds every
+    bucket once, in announcement order, then the wait; replaying it sums the ranks' gradients exactly as the eager protocol does."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 26500 + os.getpid() % 1500
+    procs = [ctx.Process(target=_cut_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for step, (replayed, eager) in zip((1, 2), out):
+        assert torch.equal(replayed, eager)
+        exact = sum(torch.randn(3 * 1024, generator=torch.Generator().manual_seed(1000 * step + r)).to(torch.bfloat16).float() for r in range(2))
+        assert torch.allclose(replayed[:exact.numel()], exact, atol=2e-2, rtol=2e-2)

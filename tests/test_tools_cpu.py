@@ -103,3 +103,28 @@ def test_g256p_probe_layout_model():
     for tiles in (1, 2, 4):                  # the ring protocol: no refill without a barrier behind the last read, no read before a counted wait + barrier
         for nk in (10, 12, 37):
             assert r.run(tiles, nk) > 0
+
+
+def test_bench_clock_power_sampler_without_and_with_a_source():
+    """bench.py's ClockPowerSampler (shader clock / package power of the timed region in the JSON line): on a host without an SMI
+    source it reports nulls and starts no thread; with a reader it samples at its period from a host thread and reports medians,
+    the clock minimum and the power maximum."""
+    import importlib.util
+    import time
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    s = bench.ClockPowerSampler(0)
+    if s.source is None:                       # (this container: no GPU, no SMI)
+        with s:
+            time.sleep(0.05)
+        r = s.summary()
+        assert r["sclk_mhz"] is None and r["power_w"] is None and r["clock_power_samples"] == 0 and r["clock_power_source"] is None
+    seq = iter([(2100.0, 1300.0), (2050.0, 1350.0), (None, 1200.0), (2080.0, None)] + [(2070.0, 1310.0)] * 1000)
+    s = bench.ClockPowerSampler(0, hz=200.0)
+    s._read, s.source = (lambda: next(seq)), "fake"
+    with s:
+        time.sleep(0.1)
+    r = s.summary()
+    assert r["clock_power_source"] == "fake" and r["clock_power_samples"] >= 5
+    assert r["sclk_mhz_min"] == 2050.0 and r["power_w_max"] == 1350.0 and r["sclk_mhz"] == 2070.0 and r["power_w"] == 1310.0
