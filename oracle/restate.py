@@ -6,6 +6,10 @@ each function cites the reference file:line it follows (paths relative to /root/
 It is validated against the reference's own modules (oracle/ref_loader.py) by
 tests/test_oracle_vs_reference.py and by the committed goldens in tests/golden/.
 
+Device rule: every function computes on the device of the tensors it is given (tensors it creates follow its inputs).  The CPU run is the
+oracle; one test (config B at the benchmarked batch: sixteen fp32 slices) runs most slices of this same code on the GPU in fp32 -- torch's
+fp32 ops, nothing of the product -- after checking on its first slice that the two placements agree.
+
 Dtype rule: every function computes in the dtype of the tensors it is given, with the
 same explicit fp32 up-casts the reference performs (LayerNormWithForceFP32, fp32 QK^T and
 softmax in the ViT, fp32 cross-entropy), so running it in bf16 reproduces the
@@ -153,7 +157,7 @@ def gpt_layer(h, sd, p, layer_number, cfg: PathConfig, causal_mask, drop=None):
     k = k.reshape(s, b * np_, hn).transpose(0, 1)
     v = v.reshape(s, b * np_, hn).transpose(0, 1)
     norm = math.sqrt(hn) * layer_number                                                          # :719-722
-    scores = torch.baddbmm(torch.zeros(b * np_, s, s, dtype=q.dtype), q, k.transpose(1, 2),
+    scores = torch.baddbmm(torch.zeros(b * np_, s, s, dtype=q.dtype, device=q.device), q, k.transpose(1, 2),
                            beta=0.0, alpha=1.0 / norm).view(b, np_, s, s)                        # :757-765
     scores = scores * layer_number                                                               # coeff, :727
     scores = scores.masked_fill(causal_mask, -10000.0)                                           # :684-686
@@ -187,7 +191,7 @@ def gpt_forward(input_embeds, labels, loss_mask, sd, cfg: PathConfig,
     if drop is not None:
         e = e * drop["embed"].to(e.dtype)
     h = e.transpose(0, 1).contiguous()                                                           # :650-653
-    causal = torch.tril(torch.ones(1, 1, S, S)) < 0.5                                            # :1288-1292
+    causal = torch.tril(torch.ones(1, 1, S, S, device=input_embeds.device)) < 0.5                # :1288-1292
     for i in range(cfg.layers):
         h = gpt_layer(h, sd, f"{p}encoder.layers.{i}.", i + 1, cfg, causal, None if drop is None else drop["layers"][i])
     h = ln_fp32(h, sd[p + "encoder.final_layernorm.weight"], sd[p + "encoder.final_layernorm.bias"],
@@ -224,10 +228,10 @@ def pretrain_forward(video, ids, attn_mask, sd, cfg: PathConfig, drop=None):
     query_features = visual_connect(image_query, sd)                                             # :136
     Q = query_features.shape[1]
     targets = torch.cat([ids[:, 1:], ids[:, 1:2]], dim=1)                                        # :142-143
-    targets = torch.cat([torch.full((B, Q), 100, dtype=torch.long), targets], dim=1)             # :150-153
+    targets = torch.cat([torch.full((B, Q), 100, dtype=torch.long, device=ids.device), targets], dim=1)      # :150-153
     emb = F.embedding(ids, sd["text_decoder.dist_model.language_model.embedding.word_embeddings.weight"])
     input_embeds = torch.cat([query_features, emb], dim=1)                                       # :155-156
-    loss_mask = torch.cat([torch.zeros(B, Q, dtype=torch.long), attn_mask[:, 1:]], dim=1)        # :145,159
+    loss_mask = torch.cat([torch.zeros(B, Q, dtype=torch.long, device=attn_mask.device), attn_mask[:, 1:]], dim=1)        # :145,159
     out = gpt_forward(input_embeds, targets, loss_mask, sd, cfg, drop=drop)
     out.update(image_embeds=image_embeds, image_query=image_query, query_features=query_features,
                input_embeds=input_embeds)
