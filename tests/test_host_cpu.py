@@ -552,3 +552,46 @@ def test_gemm_row_band_plans():
             assert sum(rounds(r, t) for r, t in bands) <= rounds(256, -(-M // 256)) + 1e-6, (M, N, K, bands)
     n = f(50432, 768, 3072, ncu, 0, 0, out)
     assert n == 3 and [out[0], out[2], out[4]] == [256, 192, 160]
+
+
+def test_ctypes_struct_layouts_match_the_header(tmp_path):
+    """The ctypes mirrors of the C-ABI structs (youku-mplug_amd/_lib.py) against include/mpv.h itself: a C program compiled with gcc prints
+    sizeof and the offset of every field of mpv_gemm_epilogue / mpv_attn_desc / mpv_gpt_layer_weights / mpv_gpt_weights; size, field
+    order and every offset must equal the ctypes layout.  (A field added to the header and forgotten in _lib.py -- or inserted in the
+    middle -- would otherwise only show up on a GPU box, as wrong numbers.)"""
+    import re
+    import shutil
+    import subprocess
+    from youku_mplug_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    hdr = open(os.path.join(ROOT, "include", "mpv.h")).read()
+    pairs = [("mpv_gemm_epilogue", _lib.GemmEpilogue), ("mpv_attn_desc", _lib.AttnDesc), ("mpv_gpt_layer_weights", _lib.GptLayerWeights),
+             ("mpv_gpt_weights", _lib.GptWeights)]
+    prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "mpv.h"', 'int main(void) {']
+    for cname, ct in pairs:
+        body = re.search(r"typedef struct " + cname + r" \{(.*?)\} " + cname + ";", hdr, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):
+                names.append(re.findall(r"[A-Za-z_][A-Za-z_0-9]*", part)[-1])
+        assert names == [f[0] for f in ct._fields_], (cname, names, [f[0] for f in ct._fields_])
+        prog.append(f'  printf("{cname} %zu", sizeof({cname}));')
+        for n in names:
+            prog.append(f'  printf(" %zu", offsetof({cname}, {n}));')
+        prog.append('  printf("\\n");')
+    prog += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(prog))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    for line, (cname, ct) in zip(out, pairs):
+        tok = line.split()
+        assert tok[0] == cname
+        assert int(tok[1]) == ctypes.sizeof(ct), (cname, tok[1], ctypes.sizeof(ct))
+        assert [int(x) for x in tok[2:]] == [getattr(ct, f[0]).offset for f in ct._fields_], cname
