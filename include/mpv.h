@@ -63,7 +63,7 @@ int mpv_check_device(void);
 int mpv_check_arch_name(const char* gcn_arch_name);
 
 /* ------------------------------------------------------------------------------------------
- * GEMM: C[M,N] = epilogue(sum_k A(m,k) B(n,k)), bf16 in, fp32 accumulate (MFMA 32x32x16).
+ * GEMM: C[M,N] = epilogue(sum_k A(m,k) B(n,k)), bf16 in, fp32 accumulate (v_mfma_f32_16x16x32_bf16 in the 256x256 kernel, 32x32x16 in the 128x128 fallback).
  * transA=0: A is [M][K] (lda); transA=1: A is [K][M].  transB=0: B is [N][K] (nn.Linear
  * weight); transB=1: B is [K][N].  (0,0)=forward, (0,1)=dgrad, (1,1)=wgrad (split-K inside).
  * Replaces: F.linear / nn.Linear (models/vision_transformer.py:104,108,175,205,250),
