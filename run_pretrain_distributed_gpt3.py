@@ -76,8 +76,9 @@ def train_one_epoch(model, tokenizer, data_loader, optimizer, device, epoch, num
     model.micro_steps = 0
     sums, count = {}, 0
     world = dist.get_world_size()
-    # (data parallel: graph_step replays a chain of segments with the bucket all-reduces issued between them; ZeRO-1 shares its shards
-    # with one more collective after the optimizer step and keeps the eager step)
+    # (data parallel: graph_step replays a chain of segments with the bucket all-reduces issued between them -- used only after the
+    # start-up self-check below has passed on this job's ranks; ZeRO-1 shares its shards with one more collective after the optimizer
+    # step and keeps the eager step)
     use_graph = os.environ.get("MPV_GRAPH", "0") == "1" and update_freq == 1 and device.type == "cuda" and \
         (world == 1 or getattr(model, "zero_shards", None) is None)
     for data_iter_step, (video, text) in enumerate(data_loader):
@@ -97,6 +98,18 @@ def train_one_epoch(model, tokenizer, data_loader, optimizer, device, epoch, num
             text = tokenizer(text, padding="max_length", truncation=True, max_length=args.max_length, return_tensors="pt",
                              add_special_tokens=True)
         text = types.SimpleNamespace(input_ids=text.input_ids.to(device), attention_mask=text.attention_mask.to(device))
+        if use_graph and world > 1 and not getattr(model, "_graph_dp_checked", False):
+            # Data-parallel graph replay (a chain of graph segments with the bucket all-reduces issued between them) is only used
+            # after it has PROVED itself on this job's own ranks: three eager steps against three graph_step calls from one state,
+            # losses and parameters bit-identical on every rank (engine.graph_self_check; the state is rewound afterwards).  The
+            # test suite can only run that path on a 1-rank communicator, so the proof is taken here -- or the eager step stays.
+            ok, why = model.graph_self_check(video, text)
+            model._graph_dp_checked = True
+            model._graph_dp_ok = ok
+            log(f"MPV_GRAPH=1 on {world} ranks: start-up self-check of the segmented replay against the eager step: "
+                f"{'passed (' + why + ')' if ok else 'FAILED (' + why + '): keeping the eager step'}")
+        if use_graph and world > 1 and not getattr(model, "_graph_dp_ok", False):
+            use_graph = False
         if use_graph:
             # MPV_GRAPH=1: forward + backward + optimizer step as ONE replayed HIP graph (engine.graph_step).  The loss is known
             # only after the step it belongs to has been applied; a non-finite one is handled as below (reload the last checkpoint

@@ -335,7 +335,9 @@ def test_checkpoint_round_trip_deepspeed_layout(monkeypatch):
         e1.save_checkpoint(d, tag="checkpoint-3", client_state={"epoch": 3})
         assert open(os.path.join(d, "latest")).read().strip() == "checkpoint-3"
         raw = torch.load(os.path.join(d, "checkpoint-3", "mp_rank_00_model_states.pt"))
-        assert set(raw) == {"module", "epoch"} and set(raw["module"]) == set(m1.state_dict())
+        # 'micro_batches_seen': the dropout stream's position travels with the model file (every rank of a ZeRO resume reads it there)
+        assert set(raw) == {"module", "epoch", "micro_batches_seen"} and set(raw["module"]) == set(m1.state_dict())
+        assert raw["micro_batches_seen"] == 3
         m2 = _StubModel(seed=10)
         e2, _, _, _ = eng.initialize(model=m2, model_parameters=eng.get_parameter_groups(m2, 0.05), config=dict(lr=1e-2))
         path, client = e2.load_checkpoint(d)

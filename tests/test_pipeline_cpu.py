@@ -533,7 +533,7 @@ _init = gpt3.GPT3Config.__init__
 def _no_dropout(self, *a, **k):                     # the stand-ins do not model the hash dropout
     _init(self, *a, **k); self.hidden_dropout = self.attention_dropout = 0.0
 gpt3.GPT3Config.__init__ = _no_dropout
-sys.argv = ["bench.py", "--gpus", os.environ["WORLD_SIZE"], "--steps", "2", "--warmup", "1", "--batch", "2", "--frames", "4", "--text-len", "8"]
+sys.argv = ["bench.py", "--gpus", os.environ["WORLD_SIZE"], "--steps", "2", "--warmup", "1", "--batch", "2", "--frames", "4", "--text-len", "8", "--_test-cpu"]
 bench.main()
 '''
 
@@ -543,8 +543,8 @@ def test_bench_control_flow_world8_gloo(tmp_path):
     process-group bring-up, parameter broadcast, the bucketed all-reduce in every backward, barrier + sync fences on both sides of
     the timed region, MAX over ranks of the region's time, the post-run roofline steps on EVERY rank (each holds collectives), ONE
     JSON line from rank 0 and nothing on any other rank's stdout -- runs here as EIGHT gloo ranks launched the way the driver
-    launches them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), on the stand-ins (MPV_BENCH_DEVICE=cpu: a test
-    hook, tiny dims).  value must be global batch x steps / the slowest rank's time."""
+    launches them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), on the stand-ins (`--_test-cpu`: a test hook that
+    stamps the line as a TEST, tiny dims).  value must be global batch x steps / the slowest rank's time."""
     import json
     import subprocess
     import sys
@@ -556,8 +556,9 @@ def test_bench_control_flow_world8_gloo(tmp_path):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   MPV_BENCH_DEVICE="cpu", OMP_NUM_THREADS="1")
+                   OMP_NUM_THREADS="1")
         env.pop("MPV_BENCH_FORCE_DIST", None)
+        env.pop("MPV_BENCH_DEVICE", None)
         procs.append(subprocess.Popen([sys.executable, str(script), root], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                                       stdin=subprocess.DEVNULL))
     outs = []
@@ -580,4 +581,6 @@ def test_bench_control_flow_world8_gloo(tmp_path):
     assert rec["config"]["global_batch"] == world * 2 and rec["config"]["parallelism"] == "dp8"
     assert rec["value"] == pytest.approx(world * 2 * 2 / (rec["ms_per_step"] * 2e-3), rel=1e-3)
     assert rec["cpu_baseline"] is None                                      # rank 0 at N = 1 only
+    assert rec["data"].startswith("TEST"), rec["data"]                      # a stand-in run can never pass for a measurement
+    assert rec["step_mode"] == "eager" and rec["host"]["cpu_ms_per_step"] > 0
     assert rec["roofline"] is not None and rec["roofline"]["launches_per_step"] > 0

@@ -539,8 +539,12 @@ class MplugEngine(nn.Module):
                         state["open"], state["calls"] = True, _lib.n_calls
 
                     def cut(action):
-                        if segs and _lib.n_calls == state["calls"]:
-                            segs[-1][1].append(action)      # nothing launched since the last cut (the last bucket, then the wait): no empty segment
+                        # Only the final wait may ride on the previous segment (it follows the last bucket with nothing in between).  A
+                        # BUCKET always ends the segment being captured: "nothing launched since the last cut" can only be told from
+                        # the C ABI's call counter, which does not see a torch-native kernel a stage may have captured (a .copy_ into a
+                        # gradient view) -- merging such a bucket would issue its all-reduce before those writes at replay.
+                        if segs and action[0] == "finish" and _lib.n_calls == state["calls"]:
+                            segs[-1][1].append(action)
                             return
                         state["g"].capture_end()
                         state["open"] = False
@@ -598,6 +602,79 @@ class MplugEngine(nn.Module):
         after()
         return static_loss
 
+    # ---- start-up self-check of graph replay against the eager step (bench.py, the entry points) ------------------------------
+    def snapshot_state(self):
+        """Everything a step changes: the flat bf16 parameters, the optimizer's fp32 state and the counters (the dropout stream's
+        position among them).  Gradients and activations are overwritten by the next step and are not part of it."""
+        o = self.optimizer
+        return {"params": self.flat.params.clone(), "master": o.master.clone(), "exp_avg": o.exp_avg.clone(),
+                "exp_avg_sq": o.exp_avg_sq.clone(), "step_count": o.step_count,
+                "counters": (self._micro_steps, self._window_fill, self.micro_batches_seen, self.global_steps)}
+
+    def restore_state(self, snap):
+        o = self.optimizer
+        self.flat.params.copy_(snap["params"])
+        o.master.copy_(snap["master"])
+        o.exp_avg.copy_(snap["exp_avg"])
+        o.exp_avg_sq.copy_(snap["exp_avg_sq"])
+        o.step_count = snap["step_count"]
+        self._micro_steps, self._window_fill, self.micro_batches_seen, self.global_steps = snap["counters"]
+        self._set_dropout_seed()
+
+    def graph_self_check(self, *inputs, steps: int = 3, before_step=None):
+        """Is a replayed step the eager step?  From ONE state: `steps` eager steps (device-resident step scalars, as the replay reads
+        them), rewind, the same steps through graph_step (call 1 eager, call 2 capture + replay, later calls replay), rewind again.
+        Returns (ok, report): ok only if every loss and the final flat parameters are BIT-identical on every rank (the verdict is
+        the AND over the process group -- all ranks must take the same mode or none may).  On a data-parallel group this is the
+        chain-of-segments replay with the bucket all-reduces between the segments, run on the real communicator: the check a
+        2+ rank box never got in the test suite runs here, at start-up, on the ranks that are about to train.  An exception while
+        capturing (a stack that cannot capture) counts as a failed check; the eager step keeps working after it.
+        `before_step(i)`: the loop's per-step host work (learning-rate mutation), applied identically in both arms."""
+        assert steps >= 3, "the third graph_step call is the first pure replay"
+        snap = self.snapshot_state()
+        self.enable_device_step_state()
+
+        def fingerprint(losses):
+            return [float(l) for l in losses], self.flat.params.clone()
+
+        losses = []
+        for i in range(steps):
+            if before_step is not None:
+                before_step(i)
+            out = self.module(*inputs)
+            loss = out[0] if isinstance(out, (tuple, list)) else out
+            self.backward(loss)
+            self.step()
+            losses.append(loss.detach().float().item())
+        ref_losses, ref_params = fingerprint(losses)
+        self.restore_state(snap)
+        ok, why = True, "bit-identical"
+        try:
+            losses = []
+            for i in range(steps):
+                if before_step is not None:
+                    before_step(i)
+                losses.append(self.graph_step(*inputs).detach().float().item())
+            got_losses, got_params = fingerprint(losses)
+            if got_losses != ref_losses:
+                ok, why = False, f"losses differ: eager {ref_losses} vs replay {got_losses}"
+            elif not torch.equal(got_params, ref_params):
+                n = int((got_params != ref_params).sum().item())
+                ok, why = False, f"{n} of {ref_params.numel()} parameters differ after {steps} steps"
+        except Exception as e:                                  # capture refused by the stack: eager mode is what is left
+            ok, why = False, f"graph capture failed: {type(e).__name__}: {e}"
+            self._graph = None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
+            flag = torch.tensor([1 if ok else 0], device=self.flat.device, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.process_group)
+            if ok and flag.item() == 0:
+                ok, why = False, "another rank's self-check failed"
+        if torch.device(self.flat.device).type == "cuda":
+            torch.cuda.synchronize()
+        self._graph_inflight.clear()
+        self.restore_state(snap)
+        return ok, why
+
     # ---- DeepSpeed-layout checkpoints: <dir>/<tag>/mp_rank_00_model_states.pt with key 'module' (utils.py:476-480)
     def save_checkpoint(self, save_dir, tag=None, client_state=None):
         tag = tag or f"global_step{self.global_steps}"
@@ -605,7 +682,10 @@ class MplugEngine(nn.Module):
         rank0 = not dist.is_initialized() or dist.get_rank() == 0
         if rank0:
             os.makedirs(d, exist_ok=True)
-            state = {"module": {k: v.detach().cpu() for k, v in self.module.state_dict().items()}}
+            state = {"module": {k: v.detach().cpu() for k, v in self.module.state_dict().items()},
+                     # the dropout stream's position travels with the MODEL file: on a ZeRO-1 resume at a larger world size the new
+                     # ranks have no optimizer shard to read it from, and every rank must continue the same mask sequence
+                     "micro_batches_seen": self.micro_batches_seen}
             state.update(client_state or {})
             torch.save(state, os.path.join(d, "mp_rank_00_model_states.pt"))
             if self.zero_shards is None:
@@ -643,7 +723,9 @@ class MplugEngine(nn.Module):
         osd = torch.load(op, map_location=self.flat.device) if os.path.isfile(op) else None
         # the dropout stream's position is read BEFORE an unusable shard is discarded (a resume at another world size restarts the
         # moments, not the mask sequence)
-        seen_osd = osd.get("micro_batches_seen") if osd is not None else None
+        seen_osd = state.pop("micro_batches_seen", None)          # (the model file: the same for every rank)
+        if seen_osd is None and osd is not None:                  # checkpoints written before round 6 kept it per optimizer file
+            seen_osd = osd.get("micro_batches_seen")
         usable = osd is not None and osd["master"].numel() == self.optimizer.master.numel() and \
             tuple(osd.get("shard", (0, self.flat.numel))) == (self.optimizer.lo, self.optimizer.hi)
         if self.zero_shards is not None:
