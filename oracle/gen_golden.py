@@ -55,16 +55,41 @@ def grad_slab(g: torch.Tensor):
     return g2[::k].clone(), k
 
 
+# Round 6: EVERY trainable tensor of a true-dims golden also carries a WIDE element-strided sample of its gradient (about
+# WIDE_SAMPLE elements, fp32 run, stored as bf16; odd stride, so the sample walks through every column and across the rows of a tensor
+# with an even last dimension) and the relative L2 deviation of the reference's own bf16 run on the same elements: an L2 check on every
+# tensor (a permuted row, a sign, a dropped term are O(1) there), which the 64-element samples were too short for.
+WIDE_SAMPLE = 4096
+
+
+def wide_stride(numel: int) -> int:
+    step = max(1, numel // WIDE_SAMPLE)
+    return step + 1 if (step % 2 == 0 and step > 1) else step
+
+
+def grad_wide(g: torch.Tensor):
+    f = g.detach().float().reshape(-1)
+    return f[::wide_stride(f.numel())][:WIDE_SAMPLE].clone()
+
+
 def record_full_grads(model, r, keys, keep, tag):
-    """fp32 pass: store the slabs (bf16) and keep them; bf16 pass: store ||g_bf16 - g_fp32|| / ||g_fp32|| per slab."""
+    """fp32 pass: store the slabs (bf16) and keep them; bf16 pass: store ||g_bf16 - g_fp32|| / ||g_fp32|| per slab.  The same for the
+    wide sample of every trainable tensor (grad_wide / grad_wide_dev)."""
     params = dict(model.named_parameters())
     if tag == "fp32":
         r["grad_full"], r["grad_full_stride"] = {}, {}
         for n in keys:
             keep[n], r["grad_full_stride"][n] = grad_slab(params[n].grad)
             r["grad_full"][n] = keep[n].to(torch.bfloat16)
+        r["grad_wide"] = {}
+        for n, p in params.items():
+            if p.grad is not None:
+                keep["wide:" + n] = grad_wide(p.grad)
+                r["grad_wide"][n] = keep["wide:" + n].to(torch.bfloat16)
     else:
         r["grad_full_dev"] = {n: float((grad_slab(params[n].grad)[0] - keep[n]).norm() / keep[n].norm()) for n in keys}
+        r["grad_wide_dev"] = {n: float((grad_wide(p.grad) - keep["wide:" + n]).norm() / (keep["wide:" + n].norm() + 1e-30))
+                              for n, p in params.items() if p.grad is not None}
 
 
 def grad_sample(g: torch.Tensor, n: int = 64):

@@ -57,7 +57,8 @@ def _pretrain_case(name, cfg, dev, B, L, wseed, grad_keys, logits_gate, hidden_g
     torch.cuda.synchronize()
     # fp32 restatement on the same bf16-rounded weights and inputs
     sdr = {k: v.bfloat16().float() for k, v in sd.items()}
-    for k in grad_keys:
+    all_keys = _trainable_keys(model)
+    for k in all_keys:                                   # round 6: the oracle differentiates EVERY trainable tensor, not a hand-picked few
         sdr[k].requires_grad_(True)
     ref = restate.pretrain_forward(video.bfloat16().float(), ids, mask, sdr, cfg)
     ref["loss"].backward()
@@ -78,19 +79,46 @@ def _pretrain_case(name, cfg, dev, B, L, wseed, grad_keys, logits_gate, hidden_g
         worst = max(worst, rel(g, r))
         worst_norm = max(worst_norm, abs(g.norm().item() - r.norm().item()) / r.norm().item())
         worst_l2 = max(worst_l2, ((g - r).norm() / r.norm()).item())
+    all_l2, all_line = _all_tensor_l2(params, {k: sdr[k].grad for k in all_keys})
     report(f"{name}: B={B} L={L} S={cfg.num_queries + L} frames={cfg.num_frames} layers={cfg.layers} mask={'full' if full_mask else 'ragged'}\n"
            f"    (1) HIP vs fp32 oracle        : logits {e['logits']:.3e} hidden {e['hidden']:.3e} losses {e['losses']:.3e} loss {e['loss']:.3e} worst-grad {worst:.3e} worst-grad-norm {worst_norm:.3e} worst-grad-L2 {worst_l2:.3e}\n"
            f"    (2) oracle bf16 vs fp32 oracle: logits {eb['logits']:.3e} hidden {eb['hidden']:.3e} losses {eb['losses']:.3e}\n"
            f"    (3) HIP vs oracle bf16        : logits {ex['logits']:.3e} hidden {ex['hidden']:.3e} losses {ex['losses']:.3e}\n"
-           f"    gates on (1): logits <= {logits_gate:.1e}, hidden <= {hidden_gate:.1e}, losses <= 1.0e-02, loss <= 5.0e-03, worst-grad <= 4.0e-02, worst-grad-norm <= 1.0e-02, worst-grad-L2 <= {GRAD_L2_GATE:.1e} | {time.time() - t0:.0f} s")
+           f"    gates on (1): logits <= {logits_gate:.1e}, hidden <= {hidden_gate:.1e}, losses <= 1.0e-02, loss <= 5.0e-03, worst-grad <= 4.0e-02, worst-grad-norm <= 1.0e-02, worst-grad-L2 <= {GRAD_L2_GATE:.1e} | {time.time() - t0:.0f} s\n"
+           f"    {all_line}")
     assert e["logits"] <= logits_gate, e
     assert e["hidden"] <= hidden_gate, e
     assert e["losses"] <= 1e-2, e
     assert e["loss"] <= 5e-3, e
     assert worst <= 4e-2 and worst_norm <= 1e-2 and worst_l2 <= GRAD_L2_GATE, (worst, worst_norm, worst_l2)
+    assert all_l2[0] <= ALL_TENSOR_L2_GATE, all_l2
 
 
 GRAD_L2_GATE = 3.0e-2      # ||g - r||_2 / ||r||_2 over the WHOLE tensor against the live fp32 oracle (round 5; measured 1.7-1.9e-2)
+# Round 6: the same whole-tensor distance on EVERY trainable tensor of the model (the live oracle differentiates all of them):
+# a plain number.  Small tensors (a 768-element bias or LayerNorm gain summed over 50 k rows of bf16 products) sit higher than the big
+# weight matrices; measured worst per case in profiles/r06_parity.txt.
+ALL_TENSOR_L2_GATE = 6.0e-2
+
+
+def _trainable_keys(model):
+    return [n for n, p in model.named_parameters() if p.requires_grad]
+
+
+def _all_tensor_l2(params, ref_grads):
+    """relative L2 distance of every trainable tensor's gradient from the oracle's: (worst, its name), report line"""
+    devs = []
+    for k, r in ref_grads.items():
+        if r is None:                                    # a parameter the loss does not depend on: no gradient on either side
+            assert params[k].grad is None or params[k].grad.abs().max().item() == 0, k
+            continue
+        assert params[k].grad is not None, k
+        g, r = params[k].grad.float().cpu(), r.float().cpu()
+        devs.append((((g - r).norm() / (r.norm() + 1e-30)).item(), k))
+    devs.sort()
+    worst = devs[-1]
+    return worst, (f"EVERY trainable tensor ({len(devs)}): whole-tensor L2 dev worst {worst[0]:.3e} ({worst[1]}), median {devs[len(devs) // 2][0]:.3e}, "
+                   f"gate {ALL_TENSOR_L2_GATE:.1e}")
 # Gates on deviation (1), as numbers: north_star's 1e-2 for the logits, at every full-depth shape.  With the decoder's residual
 # stream in fp32 (gpt3.FP32_STREAM) the measured deviations are 6.6e-3 (config B), 7.7e-3 (S = 208) and 7.9e-3 (config D, 32
 # layers); the reference's own bf16 execution -- column (2) -- sits at 1.3-1.6e-2, and so does column (3), which is dominated by it.
@@ -141,14 +169,15 @@ def test_configB_at_the_benchmarked_batch_vs_oracle(dev):
     torch.cuda.synchronize()
     sdr = {k: v.bfloat16().float() for k, v in sd.items()}
     del sd
-    for k in GRAD_KEYS:
+    all_keys = _trainable_keys(model)
+    for k in all_keys:
         sdr[k].requires_grad_(True)
     ntok = float(mask[:, 1:].sum())                 # the batch's loss-mask count (Q query slots carry none)
     # The oracle of a slice is oracle/restate.py in fp32.  Slice 0 runs on the HOST (the oracle proper) AND on the device (the same code on
     # torch's fp32 ops; it computes on the device of its inputs) and the two placements must agree to 2e-5; the other fifteen slices run on
     # the device only -- 16 host slices were 210 s of the suite, this is ~25 s.  Nothing of the product is involved in either placement.
     sdg = {k: v.detach().to(dev) for k, v in sdr.items()}
-    for k in GRAD_KEYS:
+    for k in all_keys:
         sdg[k].requires_grad_(True)
     err = dict(logits=0.0, hidden=0.0, losses=0.0)
     ref_max = dict(logits=0.0, hidden=0.0, losses=0.0)
@@ -167,7 +196,7 @@ def test_configB_at_the_benchmarked_batch_vs_oracle(dev):
             partc.backward()
             placement = max(rel(ref["logits"].detach(), refc["logits"].detach()), rel(ref["losses"].detach(), refc["losses"].detach()),
                             abs(part.item() - partc.item()) / abs(partc.item()),
-                            max(rel(sdg[k].grad, sdr[k].grad) for k in GRAD_KEYS))
+                            max(rel(sdg[k].grad, sdr[k].grad) for k in all_keys))
             assert placement <= 2e-5, f"the fp32 restatement run on the device differs from its host run by {placement:.2e}"
             del refc, partc
         with torch.no_grad():
@@ -177,7 +206,7 @@ def test_configB_at_the_benchmarked_batch_vs_oracle(dev):
                 err[name] = max(err[name], (mine - r).abs().max().item())
                 ref_max[name] = max(ref_max[name], r.abs().max().item())
         del ref, part
-    for k in GRAD_KEYS:
+    for k in all_keys:
         sdr[k].grad = sdg[k].grad.cpu()             # (the gradients of the whole batch; the host's slice-0 gradients are replaced)
     e = {k: err[k] / ref_max[k] for k in err}
     e_loss = abs(loss.item() - num) / abs(num)
@@ -188,13 +217,16 @@ def test_configB_at_the_benchmarked_batch_vs_oracle(dev):
         worst = max(worst, (rel(g, r), k))
         worst_norm = max(worst_norm, (abs(g.norm().item() - r.norm().item()) / r.norm().item(), k))
         worst_l2 = max(worst_l2, (((g - r).norm() / r.norm()).item(), k))
+    all_l2, all_line = _all_tensor_l2(params, {k: sdr[k].grad for k in all_keys})
     report(f"config B at the BENCHMARKED batch: B={B} L={L} S={Q + L} frames={cfg.num_frames} layers={cfg.layers} (fp32 oracle in {B // SL} slices of {SL}; slice 0 on the host and on the device: {placement:.1e} apart, the rest on the device)\n"
            f"    HIP vs fp32 oracle: window logits {e['logits']:.3e} hidden {e['hidden']:.3e} losses {e['losses']:.3e} loss {e_loss:.3e} "
            f"worst-grad {worst[0]:.3e} ({worst[1]}) worst-grad-norm {worst_norm[0]:.3e} ({worst_norm[1]}) worst-grad-L2 {worst_l2[0]:.3e} ({worst_l2[1]})\n"
-           f"    gates: logits <= 1.0e-02, hidden <= 1.0e-02, losses <= 1.0e-02, loss <= 5.0e-03, worst-grad <= 4.0e-02, worst-grad-norm <= 1.0e-02, worst-grad-L2 <= {GRAD_L2_GATE:.1e} | {time.time() - t0:.0f} s")
+           f"    gates: logits <= 1.0e-02, hidden <= 1.0e-02, losses <= 1.0e-02, loss <= 5.0e-03, worst-grad <= 4.0e-02, worst-grad-norm <= 1.0e-02, worst-grad-L2 <= {GRAD_L2_GATE:.1e} | {time.time() - t0:.0f} s\n"
+           f"    {all_line}")
     assert e["logits"] <= 1e-2 and e["hidden"] <= 1e-2 and e["losses"] <= 1e-2, e
     assert e_loss <= 5e-3, e_loss
     assert worst[0] <= 4e-2 and worst_norm[0] <= 1e-2 and worst_l2[0] <= GRAD_L2_GATE, (worst, worst_norm, worst_l2)
+    assert all_l2[0] <= ALL_TENSOR_L2_GATE, all_l2
 
 
 def test_configB_train_mode_full_depth_vs_oracle_through_the_kernels_own_masks(dev):
@@ -336,24 +368,35 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 
 
-# plain numbers (round 5): |grad| norm of EVERY trainable tensor (measured worst 2.1e-2); relative L2 distance on the whole-tensor goldens
-# (measured worst 9.1e-2 / 7.2e-2 / 2.8e-2 for ITM / CLS / EVA with the reference's OWN bf16 run at 7.2e-2 / 9.2e-2 / 3.1e-2 on the same
-# tensors, medians equal to the reference's: VERDICT r04's 3e-2 is below what a bf16 execution of these 9- / 3-sequence batches can
-# reach -- the fp32-oracle cases above, where it can, ARE gated at 3e-2)
-NORM_GATE, L2_GATE = 5e-2, 1.0e-1
+# Round 6: every gate of the section-8(f) rows is a PLAIN NUMBER per case -- at most ~2x the value measured
+# on the round's tree for forward quantities, 1.2x the worst measured for the L2 distances (profiles/r06_parity.txt); the reference's own bf16
+# deviation is printed beside each figure for context and widens nothing.  Measured (round 5 / round 6):
+#   ITM: losses 1.5e-4 / 5.2e-3, scores 2.3e-4 / 1.9e-2, worst norm 1.7e-2, whole-tensor L2 9.1e-2 (the reference's own bf16 run: 7.2e-2)
+#   CLS: losses 1.8e-4 / 4.0e-3, scores 9.5e-7 / 1.2e-2, worst norm 2.1e-2, whole-tensor L2 7.2e-2 (9.2e-2)
+#   EVA: logits 8.1e-3, per-token losses 1.5e-3, loss 1.1e-4, worst norm 5.9e-3, whole-tensor L2 2.9e-2 (3.1e-2)
+# (the L2 figures of ITM / CLS are what a bf16 execution of a 9- / 3-sequence batch yields -- medians equal to the reference's own bf16
+# run on the same tensors; the fp32-oracle cases above, where 3e-2 can be reached, ARE gated at 3e-2)
+FGATES = {
+    "itm": dict(loss_caption=1e-3, loss_cls=1e-2, generation_logits=2e-3, cls_logits=4e-2, norm=4e-2, l2=1.1e-1, wide=1.6e-1),
+    "cls": dict(loss_caption=1e-3, loss_cls=1e-2, generation_logits=2e-3, cls_logits=2.5e-2, norm=4e-2, l2=9e-2, wide=1.6e-1),
+    "eva": dict(logits=1e-2, losses=3e-3, loss=5e-4, norm=1.5e-2, l2=3.5e-2, wide=8e-2),
+    "caption": dict(score=3.5e-3),
+}
 
 
-def _grad_gates(model, f32, b16):
-    """Round 5: plain-number gates.
-      (1) every trainable parameter: | ||g|| - ||r|| | / ||r|| <= NORM_GATE against the fp32 golden;
+def _grad_gates(model, f32, b16, case):
+    """Plain-number gates on the gradients of a true-dims golden (FGATES[case]):
+      (1) every trainable parameter: | ||g|| - ||r|| | / ||r|| <= norm against the fp32 golden;
       (2) the tensors whose WHOLE gradient the golden holds (f32["grad_full"]: >= 10 tensors per case, the large ones as row-strided
-          slabs -- oracle/gen_golden.py): ||g - r||_2 / ||r||_2 <= L2_GATE over every stored element.  The reference's own bf16 run
-          sits at 6-9e-2 on this measure for the ITM / classification cases and 2-3e-2 for EVA (b16["grad_full_dev"], reported beside
-          ours) -- a wrong row, a dropped bias gradient or a mis-scaled branch shows up here as O(1);
-      (3) the 64-element strided samples of round 4 are REPORTED (worst max-abs deviation) and no longer gated: on a near-zero
-          gradient tensor a max-abs / max-abs over 64 elements cannot tell a rounding difference from a defect, and the `3 x the
-          reference's own bf16 deviation` clause that admitted 12-27 % there is gone.
-    Returns (failures, worst norm dev, worst sample dev, {name: (our L2 dev, reference-bf16 L2 dev)})."""
+          slabs -- oracle/gen_golden.py): ||g - r||_2 / ||r||_2 <= l2 over every stored element;
+      (3) round 6: EVERY trainable tensor: the same relative L2 distance over the golden's WIDE sample (~4096 elements on
+          an odd stride through the flattened gradient, f32["grad_wide"]) <= wide -- an element-wise check on every tensor: a permuted
+          row, a sign, a dropped term are O(1) on it.  The reference's own bf16 run on the same elements is reported beside it;
+      (4) the 64-element strided samples of round 4 are REPORTED (worst max-abs deviation), not gated: max-abs / max-abs over 64
+          elements of a near-zero gradient cannot tell a rounding difference from a defect -- (3) replaces them.
+    Returns (failures, worst norm dev, worst sample dev, {name: (our L2 dev, reference-bf16 L2 dev)}, wide-sample summary line)."""
+    NORM_GATE, L2_GATE, WIDE_GATE = FGATES[case]["norm"], FGATES[case]["l2"], FGATES[case]["wide"]
+    from oracle.gen_golden import WIDE_SAMPLE, wide_stride
     bad, wn, ws = [], (0.0, ""), (0.0, "")
     seen = 0
     params = dict(model.named_parameters())
@@ -383,7 +426,22 @@ def _grad_gates(model, f32, b16):
         if e > L2_GATE:
             bad.append((n, "L2", e))
     assert len(l2) >= 8
-    return bad, wn, ws, l2
+    wide, ww = [], (0.0, "", 0.0)
+    assert set(f32["grad_wide"]) == set(f32["grad_norm"]), "the golden's wide samples must cover every trainable tensor"
+    for n, r in f32["grad_wide"].items():
+        f = params[n].grad.detach().float().reshape(-1)
+        g = f[::wide_stride(f.numel())][:WIDE_SAMPLE].cpu()
+        r = r.float()
+        assert g.shape == r.shape, (n, g.shape, r.shape)
+        e = ((g - r).norm() / (r.norm() + 1e-30)).item()
+        wide.append(e)
+        ww = max(ww, (e, n, b16["grad_wide_dev"][n]))
+        if not e <= WIDE_GATE:
+            bad.append((n, "wide-L2", e))
+    refs = sorted(b16["grad_wide_dev"].values())
+    wline = (f"wide-sample L2 dev over ALL {len(wide)} tensors: worst {ww[0]:.3e} ({ww[1]}; reference bf16 run {ww[2]:.3e}), median "
+             f"{sorted(wide)[len(wide) // 2]:.3e} (reference bf16 run: worst {refs[-1]:.3e}, median {refs[len(refs) // 2]:.3e})")
+    return bad, wn, ws, l2, wline
 
 
 def _l2_line(l2):
@@ -424,7 +482,7 @@ def test_itm_cls_true_dims_vs_reference_golden(dev, kind):
         el[name] = (abs(mine.item() - ref) / abs(ref), abs(refb - ref) / abs(ref))
     (lc + lk).backward()
     torch.cuda.synchronize()
-    bad, wn, ws, l2 = _grad_gates(model, f32, b16)
+    bad, wn, ws, l2, wline = _grad_gates(model, f32, b16, kind)
     etext = types.SimpleNamespace(input_ids=d(inp["e_ids"]), attention_mask=d(inp["e_mask"]), prompt_lengths=inp["e_plen"])
     eptext = types.SimpleNamespace(input_ids=d(inp["e_pids"]), attention_mask=d(inp["e_pmask"]))
     gen, cl = model(video, etext, eptext, train=False)
@@ -440,11 +498,10 @@ def test_itm_cls_true_dims_vs_reference_golden(dev, kind):
            f"cls {es['cls_logits'][0]:.3e} | {es['cls_logits'][1]:.3e}\n"
            f"    grads   ({len(f32['grad_norm'])} tensors): worst norm dev {wn[0]:.3e} ({wn[1]})  [worst 64-sample dev {ws[0]:.3e} ({ws[1]}), not gated]\n"
            f"            {_l2_line(l2)}\n"
-           f"    gates: losses <= max(1e-2, 3 x ref-bf16), scores <= max(2e-2, 3 x ref-bf16), grad norm <= {NORM_GATE:.1e}, whole-tensor L2 <= {L2_GATE:.1e} | {time.time() - t0:.0f} s")
-    for name, (e, e_ref) in el.items():
-        assert e <= max(1e-2, 3 * e_ref), (name, e, e_ref)
-    for name, (e, e_ref) in es.items():
-        assert e <= max(2e-2, 3 * e_ref), (name, e, e_ref)
+           f"            {wline}\n"
+           f"    gates (plain numbers): {FGATES[kind]} | {time.time() - t0:.0f} s")
+    for name, (e, e_ref) in list(el.items()) + list(es.items()):
+        assert e <= FGATES[kind][name], (name, e, FGATES[kind][name], "reference bf16, for context:", e_ref)
     assert not bad, bad[:8]
 
 
@@ -479,14 +536,15 @@ def test_eva_g_true_dims_vs_reference_golden(dev):
     r_loss = abs(b16["loss"].item() - f32["loss"].item()) / abs(f32["loss"].item())
     loss.backward()
     torch.cuda.synchronize()
-    bad, wn, ws, l2 = _grad_gates(model, f32, b16)
+    bad, wn, ws, l2, wline = _grad_gates(model, f32, b16, "eva")
     report(f"EVA-ViT-g at true dims (1408 x 40 blocks, 257 tokens, heads of 88) + 1.3B decoder, B={m['batch']} (reference-module golden eva_g_full.pt)\n"
            f"    HIP vs fp32 ref | ref bf16 vs fp32: logits {e_log:.3e} | {r_log:.3e}   per-token losses {e_los:.3e} | {r_los:.3e}   loss {e_loss:.3e} | {r_loss:.3e}\n"
            f"    grads ({len(f32['grad_norm'])} tensors): worst norm dev {wn[0]:.3e} ({wn[1]})  [worst 64-sample dev {ws[0]:.3e} ({ws[1]}), not gated]\n"
            f"          {_l2_line(l2)}\n"
-           f"    gates: logits <= max(1e-2, 1.5 x ref-bf16), losses <= max(1e-2, 1.5 x), loss <= max(2e-3, 2 x), grad norm <= {NORM_GATE:.1e}, whole-tensor L2 <= {L2_GATE:.1e} | {time.time() - t0:.0f} s")
-    assert e_log <= max(1e-2, 1.5 * r_log) and e_los <= max(1e-2, 1.5 * r_los), (e_log, r_log, e_los, r_los)
-    assert e_loss <= max(2e-3, 2 * r_loss), (e_loss, r_loss)
+           f"          {wline}\n"
+           f"    gates (plain numbers): {FGATES['eva']} | {time.time() - t0:.0f} s")
+    G = FGATES["eva"]
+    assert e_log <= G["logits"] and e_los <= G["losses"] and e_loss <= G["loss"], (e_log, e_los, e_loss, G, "reference bf16, for context:", r_log, r_los, r_loss)
     assert not bad, bad[:8]
 
 
@@ -551,7 +609,7 @@ def test_caption_generate_true_dims_vs_reference_golden(dev):
                      f"best score {scores[i]:.5f} vs {ref_sc:.5f} ({e_sc:.2e}; ref bf16 {r_sc:.2e}) | teacher-forced score of the ref sequence {tf_score:.5f} ({e_tf:.2e})")
         assert r.shape == f32["sequences"][i].shape
         assert torch.equal(r[0, :n_prompt].cpu(), ids[i, :n_prompt])                      # the prompt is kept
-        ok &= e_sc <= max(2e-2, 3 * r_sc) and e_tf <= max(2e-2, 3 * r_sc) and (same_ref or not ref_stable)
+        ok &= e_sc <= FGATES["caption"]["score"] and e_tf <= FGATES["caption"]["score"] and (same_ref or not ref_stable)
     report("caption generate at true dims (24-layer 1.3B decoder, beam 5, 12 tokens; reference-module golden caption_1p3b.pt)\n" + "\n".join(lines) +
-           f"\n    gates: scores (best, teacher-forced) <= max(2e-2, 3 x ref-bf16); tokens exact where the reference's bf16 run is | {time.time() - t0:.0f} s")
+           f"\n    gates: scores (best, teacher-forced) <= {FGATES['caption']['score']:.1e} (plain; measured <= 1.7e-3); tokens exact where the reference's bf16 run is | {time.time() - t0:.0f} s")
     assert ok, lines
