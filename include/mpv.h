@@ -257,6 +257,21 @@ int mpv_copy_segments(const void* const* src, void* const* dst, const int64_t* c
  * Wc = Wf Wp): dWf = bf16(float(dWc Wp^T) + d(bc) bp^T) and d(bp) = Wf^T d(bc), all operands bf16 [D,D] / [D]. */
 int mpv_vit_compose_bwd_finish(const void* dwc_wpT, const void* dbc, const void* bp, const void* wf, void* dwf, void* dbp, int D,
                                mpv_stream_t stream);
+/* The composed temporal projection of EVERY block of the tower in one launch each (round 6; the [D, D] products of a block depend on
+ * parameters and on per-block reduced gradients only, so the 12 blocks' worth goes out together: Wc and bc at the head of the step,
+ * dWf / dWp / d(bp) at the end of the tower's backward -- 5 launches per step instead of 60).  Pointer tables are HOST arrays of
+ * `batch` device pointers (copied by value into the launches; any batch, 16 problems per launch).
+ *   mpv_vit_compose_bias_batched:       bc[b] = bf16(Wf[b] bp[b] + bf[b])             (models/vision_transformer.py:199-200, 250)
+ *   mpv_vit_compose_bwd_finish_batched: mpv_vit_compose_bwd_finish for every b
+ *   mpv_gemm_bf16_batched:              C[b] = A[b] op B[b], mpv_gemm_bf16's operand forms (transA / transB), ONE shape, plain epilogue
+ *                                       (bf16 out, no bias); replaces torch.bmm-shaped loops over blocks, which the reference does not
+ *                                       have (it runs proj and temporal_fc as two token-row products, :199-200, 250). */
+int mpv_vit_compose_bias_batched(const void* const* wf, const void* const* bp, const void* const* bf, void* const* bc, int batch, int D,
+                                 mpv_stream_t stream);
+int mpv_vit_compose_bwd_finish_batched(const void* const* dwc_wpT, const void* const* dbc, const void* const* bp, const void* const* wf,
+                                       void* const* dwf, void* const* dbp, int batch, int D, mpv_stream_t stream);
+int mpv_gemm_bf16_batched(const void* const* A, const void* const* B, void* const* C, int batch, int64_t M, int64_t N, int64_t K,
+                          int64_t lda, int64_t ldb, int64_t ldc, int transA, int transB, mpv_stream_t stream);
 /* Labels and loss weights of the L text positions behind the Q query slots (models/distributed_gpt3.py:142-159,
  * 348-351; the masked mean of models/modeling_distributed_gpt3.py:1615-1617 as per-position weights):
  * labels[b][l] = ids[b][l+1] (ids[b][1] at l = L-1), weights[b][l] = attention_mask[b][l+1] / sum(attention_mask[:,1:])

@@ -72,6 +72,20 @@ def grad_wide(g: torch.Tensor):
     return f[::wide_stride(f.numel())][:WIDE_SAMPLE].clone()
 
 
+def record_wide_grads(model, r, keep, tag):
+    """every trainable tensor's wide sample: fp32 pass stores it (bf16) and keeps it; bf16 pass stores its relative L2 deviation"""
+    params = dict(model.named_parameters())
+    if tag == "fp32":
+        r["grad_wide"] = {}
+        for n, p in params.items():
+            if p.grad is not None:
+                keep["wide:" + n] = grad_wide(p.grad)
+                r["grad_wide"][n] = keep["wide:" + n].to(torch.bfloat16)
+    else:
+        r["grad_wide_dev"] = {n: float((grad_wide(p.grad) - keep["wide:" + n]).norm() / (keep["wide:" + n].norm() + 1e-30))
+                              for n, p in params.items() if p.grad is not None}
+
+
 def record_full_grads(model, r, keys, keep, tag):
     """fp32 pass: store the slabs (bf16) and keep them; bf16 pass: store ||g_bf16 - g_fp32|| / ||g_fp32|| per slab.  The same for the
     wide sample of every trainable tensor (grad_wide / grad_wide_dev)."""
@@ -81,15 +95,9 @@ def record_full_grads(model, r, keys, keep, tag):
         for n in keys:
             keep[n], r["grad_full_stride"][n] = grad_slab(params[n].grad)
             r["grad_full"][n] = keep[n].to(torch.bfloat16)
-        r["grad_wide"] = {}
-        for n, p in params.items():
-            if p.grad is not None:
-                keep["wide:" + n] = grad_wide(p.grad)
-                r["grad_wide"][n] = keep["wide:" + n].to(torch.bfloat16)
     else:
         r["grad_full_dev"] = {n: float((grad_slab(params[n].grad)[0] - keep[n]).norm() / keep[n].norm()) for n in keys}
-        r["grad_wide_dev"] = {n: float((grad_wide(p.grad) - keep["wide:" + n]).norm() / (keep["wide:" + n].norm() + 1e-30))
-                              for n, p in params.items() if p.grad is not None}
+    record_wide_grads(model, r, keep, tag)
 
 
 def grad_sample(g: torch.Tensor, n: int = 64):
@@ -103,6 +111,7 @@ def run_case(name: str):
     rec = {"meta": dict(case=name, batch=B, text_len=L, weight_seed=wseed, input_seed=iseed,
                         ragged=ragged, logits_seq_from=sfrom, logits_vocab_step=vstep,
                         torch=str(torch.__version__))}
+    keep = {}
     for tag, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
         t0 = time.time()
         model, sd = build_reference_model(cfg, wseed, dtype=dtype)
@@ -121,6 +130,7 @@ def run_case(name: str):
             if p.grad is not None:
                 r["grad_norm"][n] = float(p.grad.float().norm())
                 r["grad_sample"][n] = grad_sample(p.grad)
+        record_wide_grads(model, r, keep, tag)
         rec[tag] = r
         print(f"[{name}/{tag}] loss={float(loss):.6f}  {time.time() - t0:.1f}s", flush=True)
         del model, sd
@@ -137,6 +147,7 @@ def run_retrieval(name: str = "retrieval_tiny"):
     cfg = CONFIG_TINY
     rec = {"meta": dict(case=name, batch=8, text_len=10, weight_seed=2, input_seed=5, ragged=True, idx=[3, 1, 4, 1, 5, 9, 2, 6],
                         torch=str(torch.__version__))}
+    keep = {}
     for tag, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
         model, sd = build_reference_retrieval(cfg, 2, dtype=dtype)
         video, ids, mask = make_inputs(cfg, 8, 10, seed=5, ragged=True)
@@ -150,6 +161,7 @@ def run_retrieval(name: str = "retrieval_tiny"):
             if p.grad is not None:
                 r["grad_norm"][n] = float(p.grad.float().norm())
                 r["grad_sample"][n] = grad_sample(p.grad)
+        record_wide_grads(model, r, keep, tag)
         rec[tag] = r
         print(f"[{name}/{tag}] loss={float(loss):.6f}", flush=True)
     path = os.path.join(GOLDEN_DIR, f"{name}.pt")
@@ -224,6 +236,8 @@ def run_gencls(kind: str, full: bool = False):
                 r["grad_sample"][n] = grad_sample(p.grad)
         if full:
             record_full_grads(model, r, FULL_GRAD_KEYS["gencls"], keep, tag)
+        else:
+            record_wide_grads(model, r, keep, tag)
         etext = types.SimpleNamespace(input_ids=inp["e_ids"], attention_mask=inp["e_mask"], prompt_lengths=inp["e_plen"])
         eptext = types.SimpleNamespace(input_ids=inp["e_pids"], attention_mask=inp["e_pmask"])
         with torch.no_grad():
@@ -289,6 +303,8 @@ def run_eva(name: str = "eva_tiny"):
                 r["grad_sample"][n] = grad_sample(p.grad)
         if full:
             record_full_grads(model, r, FULL_GRAD_KEYS["eva"], keep, tag)
+        else:
+            record_wide_grads(model, r, keep, tag)
         rec[tag] = r
         print(f"[{name}/{tag}] loss={float(loss):.6f}  {time.time() - t0:.0f}s", flush=True)
         del model, sd, out, captured

@@ -401,6 +401,22 @@ def vit_compose_bwd_finish(dwc_wpT, dbc, bp, wf, dwf, dbp, D):
     dbp.view(-1).copy_((wf.float().view(D, D) * dbc.float().view(D, 1)).sum(0).to(BF))
 
 
+def gemm_batched(a_list, b_list, c_list, M, N, K, trans_a=False, trans_b=False):
+    for a, b, c in zip(a_list, b_list, c_list):
+        gemm(a, b, M, N, K, out=c, trans_a=trans_a, trans_b=trans_b)
+    return c_list
+
+
+def vit_compose_bias_batched(wf_list, bp_list, bf_list, bc_list, D):
+    for wf, bp, bf, bc in zip(wf_list, bp_list, bf_list, bc_list):
+        bc.view(-1).copy_((wf.float().view(D, D) @ bp.float().view(D) + bf.float().view(D)).to(BF))
+
+
+def vit_compose_bwd_finish_batched(dwc_wpT, dbc, bp, wf, dwf, dbp, D):
+    for args in zip(dwc_wpT, dbc, bp, wf, dwf, dbp):
+        vit_compose_bwd_finish(*args, D)
+
+
 def caption_targets(ids, attention_mask, prompt_len=None):
     B, L = ids.shape
     m = attention_mask[:, 1:].clone().float()
@@ -496,7 +512,7 @@ def decode_step(self, tokens, query_embeds=None):
     return gemm(xf, lm.embedding.word_embeddings.weight, B, V, H)
 
 
-NAMES = ["ln_stream_fwd", "ln_stream_bwd", "LnDparamBatch", "accum_f32", "f32_to_bf16", "copy_segments", "vit_compose_bwd_finish", "caption_targets", "gather_rows_ld", "logprob_topk", "add", "gather_rows", "scatter_rows", "l2norm_fwd", "l2norm_bwd", "soft_target_ce", "gemm", "layernorm_fwd", "layernorm_bwd", "AttnLayout", "attn_fwd", "attn_bwd", "temporal_attn_fwd", "temporal_attn_bwd",
+NAMES = ["ln_stream_fwd", "ln_stream_bwd", "LnDparamBatch", "accum_f32", "f32_to_bf16", "copy_segments", "vit_compose_bwd_finish", "gemm_batched", "vit_compose_bias_batched", "vit_compose_bwd_finish_batched", "caption_targets", "gather_rows_ld", "logprob_topk", "add", "gather_rows", "scatter_rows", "l2norm_fwd", "l2norm_bwd", "soft_target_ce", "gemm", "layernorm_fwd", "layernorm_bwd", "AttnLayout", "attn_fwd", "attn_bwd", "temporal_attn_fwd", "temporal_attn_bwd",
          "im2col_patches", "vit_embed_assemble_fwd", "vit_embed_assemble_bwd", "vit_cls_fix_fwd", "vit_cls_merge_bwd_inplace",
          "copy_rows", "colsum", "gpt_embed_fwd", "gpt_embed_bwd", "gpt_embed_bwd_full", "cross_entropy"]
 

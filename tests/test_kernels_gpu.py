@@ -667,6 +667,39 @@ def test_compose_finish_and_caption_targets(dev):
         assert torch.allclose(w.view(B, L), ref_w, atol=0, rtol=1e-6)
 
 
+@pytest.mark.parametrize("D,nb", [(768, 12), (192, 3), (200, 18)])
+def test_composed_projection_batched_launches_match_per_block(dev, D, nb):
+    """Round 6: the composed temporal projection's small products of EVERY block in one launch each (mpv_gemm_bf16_batched,
+    mpv_vit_compose_bias_batched, mpv_vit_compose_bwd_finish_batched) against the per-block launches of rounds 3-5: the three operand
+    forms of the batched GEMM are BIT-identical to mpv_gemm_bf16 on the 128x128 kernel (same tile, same K order), the finish is
+    bit-identical, the bias product matches an fp32 reference.  18 problems: more than one launch's pointer table (16)."""
+    from youku_mplug_amd import ops
+    a = [rn(D, D, dev=dev, seed=10 + i) for i in range(nb)]
+    b = [rn(D, D, dev=dev, seed=40 + i) for i in range(nb)]
+    for ta, tb in ((False, False), (False, True), (True, True)):
+        out = torch.empty((nb, D, D), dtype=torch.bfloat16, device=dev)
+        ops.gemm_batched(a, b, list(out.unbind(0)), D, D, D, trans_a=ta, trans_b=tb)
+        for i in range(nb):
+            one = ops.gemm(a[i], b[i], D, D, D, trans_a=ta, trans_b=tb, tile_hint=128)
+            assert torch.equal(out[i], one), (ta, tb, i, (out[i].float() - one.float()).abs().max().item())
+        A = a[0].float().t() if ta else a[0].float()
+        Bm = b[0].float() if tb else b[0].float().t()
+        close(out[0], A @ Bm, 1e-2, f"batched gemm<{int(ta)},{int(tb)}>")
+    bp = [rn(D, dev=dev, seed=70 + i) for i in range(nb)]
+    bf = [rn(D, dev=dev, seed=100 + i) for i in range(nb)]
+    bc = torch.empty((nb, D), dtype=torch.bfloat16, device=dev)
+    ops.vit_compose_bias_batched(a, bp, bf, list(bc.unbind(0)), D)
+    for i in range(nb):
+        close(bc[i], a[i].float() @ bp[i].float() + bf[i].float(), 4e-3, "bc = Wf bp + bf")
+    dbc = [rn(D, dev=dev, seed=130 + i) for i in range(nb)]
+    dwf, dbp = torch.empty((nb, D, D), dtype=torch.bfloat16, device=dev), torch.empty((nb, D), dtype=torch.bfloat16, device=dev)
+    ops.vit_compose_bwd_finish_batched(a, dbc, bp, b, list(dwf.unbind(0)), list(dbp.unbind(0)), D)
+    for i in range(nb):
+        w1, p1 = torch.empty_like(a[i]), torch.empty_like(bp[i])
+        ops.vit_compose_bwd_finish(a[i], dbc[i], bp[i], b[i], w1, p1, D)
+        assert torch.equal(dwf[i], w1) and torch.equal(dbp[i], p1), i
+
+
 @pytest.mark.parametrize("rows,cols", [(50432, 768), (300, 768), (1024, 2048)])
 def test_layernorm_deferred_dparams_match_immediate(dev, rows, cols):
     """MPV_LN_DPARAM_DEFER + mpv_layernorm_dparam_finish (three LayerNorms in one launch, one of them accumulating) against the

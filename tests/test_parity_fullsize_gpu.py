@@ -24,7 +24,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REPORT = os.environ.get("MPV_PARITY_REPORT", os.path.join(ROOT, "gpurun_out", "r05_parity.txt"))
+REPORT = os.environ.get("MPV_PARITY_REPORT", os.path.join(ROOT, "gpurun_out", "r06_parity.txt"))
 
 
 def rel(a, b):

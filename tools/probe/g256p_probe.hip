@@ -1,10 +1,10 @@
-// g256p_probe.hip -- a GEMM tile whose epilogue does not own the matrix pipe (lead 1).  NOT a product path,
+// g256p_probe.hip -- a GEMM tile whose epilogue does not own the matrix pipe (NOTEBOOK.md section 10, lead 1).  NOT a product path,
 // NOT yet run on a GPU: written and compiled in round 4 (ISA checked on the host: tools/probe/README.md), to be validated and measured
 // against csrc/gemm256.hip at the start of the next round (./g256p_probe M N K prints its error against a host reference and its time).
 //
 // What the production kernel cannot do: at K = 768 a 256 x 256 tile is 2.2 us of prologue + 15.7 us of main loop + >= 4.9 us of a
 // store-issue-bound epilogue, and nothing overlaps the first and the last -- 160 KiB of LDS and all 256 registers of both waves of a
-// SIMD belong to the one tile (three rounds of attempts: DESIGN section 9).  This kernel changes the register economy instead:
+// SIMD belong to the one tile (three rounds of attempts: NOTEBOOK section 9).  This kernel changes the register economy instead:
 //
 //  * FOUR waves (one per SIMD, 512 registers each): a wave owns a 128 x 128 quarter of the tile, its 64 accumulator blocks
 //    (v_mfma_f32_16x16x32_bf16) fill the 256 AGPRs, the 256 arch VGPRs hold the operand fragments (A double-buffered, B rolling: 96) and ...

@@ -82,6 +82,9 @@ _SIGS = {
     "mpv_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "mpv_copy_segments": (c_int, [C.POINTER(c_void_p), C.POINTER(c_void_p), C.POINTER(c_int64), c_int, c_void_p]),
     "mpv_vit_compose_bwd_finish": (c_int, [c_void_p] * 6 + [c_int, c_void_p]),
+    "mpv_vit_compose_bias_batched": (c_int, [C.POINTER(c_void_p)] * 4 + [c_int, c_int, c_void_p]),
+    "mpv_vit_compose_bwd_finish_batched": (c_int, [C.POINTER(c_void_p)] * 6 + [c_int, c_int, c_void_p]),
+    "mpv_gemm_bf16_batched": (c_int, [C.POINTER(c_void_p)] * 3 + [c_int] + [c_int64] * 6 + [c_int, c_int, c_void_p]),
     "mpv_caption_targets": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "mpv_layernorm_bwd_partial_rows": (c_int, [c_int64]),
     "mpv_layernorm_dparam_finish": (c_int, [C.POINTER(c_void_p), C.POINTER(c_int), C.POINTER(c_void_p), C.POINTER(c_void_p),

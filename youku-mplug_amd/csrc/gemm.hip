@@ -98,7 +98,7 @@ struct Loader {
 };
 
 template <bool TA, bool TB>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
+__device__ __forceinline__ void gemm_bf16_body(const GemmArgs& p) {
   const uint64_t seed_r = p.drop_thr ? mpv_resolve_seed(p.seed) : 0;      // (bit 63 set: the seed lives in device memory, mpv_common.h)
   __shared__ __attribute__((aligned(1024))) char smem[4 * TILE_BYTES];
   const int tid = threadIdx.x;
@@ -437,11 +437,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
           if (p.preact) {
             if (p.preact_deriv) {
               f32x8 d;
+              if (p.act == 1) {
 #pragma unroll
-              for (int e = 0; e < 8; ++e) {       // the tanh flavour from the 256x256 kernel's formula (one polynomial for GELU and GELU'):
-                float gv, dv;                     // a product split between the two tile kernels parks ONE function
-                mpv_gelu_tanh_both_t(z[e], gv, dv);
-                d[e] = p.act == 1 ? gelu_erf_grad_f(z[e]) : dv;
+                for (int e = 0; e < 8; ++e) d[e] = gelu_erf_grad_f(z[e]);
+              } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {     // the tanh flavour from the 256x256 kernel's formula (one polynomial for GELU and GELU'):
+                  float gv, dv;                   // a product split between the two tile kernels parks ONE function
+                  mpv_gelu_tanh_both_t(z[e], gv, dv);
+                  d[e] = dv;
+                }
               }
               *(bf16x8*)(p.preact + crow * p.ldc + n) = cvt8(d);
             } else {
@@ -468,6 +473,30 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
     }
     if (!tail_src) __syncthreads();
   }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
+  gemm_bf16_body<TA, TB>(p);
+}
+
+// `batch` independent products of ONE shape in one launch (blockIdx.y = problem): the [D, D] chain-rule products of the composed
+// temporal projection -- Wc = Wf Wp of every ViT block at the head of the step, dWf' = dWc Wp^T and dWp = Wf^T dWc of every block at the
+// end of the tower's backward -- were 36 launches of 36 workgroups each (768^3: 42-50 TFLOP/s, 0.7 ms per step); as three launches of
+// 12 x 36 workgroups they fill the chip once.  The operand pointers of the problems travel by value in the launch.
+constexpr int GEMM_BATCH_MAX = 16;
+struct GemmBatchPtrs {
+  const bf16* a[GEMM_BATCH_MAX];
+  const bf16* b[GEMM_BATCH_MAX];
+  bf16* c[GEMM_BATCH_MAX];
+};
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_batched_kernel(const GemmArgs p, const GemmBatchPtrs bp) {
+  GemmArgs q = p;
+  q.A = bp.a[blockIdx.y];
+  q.B = bp.b[blockIdx.y];
+  q.C = bp.c[blockIdx.y];
+  gemm_bf16_body<TA, TB>(q);
 }
 
 // sum split-K fp32 partials -> bf16 (optionally accumulating into the existing bf16 value); the trailing workgroups of
@@ -934,4 +963,51 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
                        (bf16*)colsum_out, (int)M, splitk);
   }
   return mpv_check_launch("mpv_gemm_bf16");
+}
+
+// mpv_gemm_bf16_batched (include/mpv.h): `batch` products of one shape, plain epilogue (bf16 out), on the 128x128 kernel with
+// blockIdx.y = problem; more than GEMM_BATCH_MAX problems go out as several launches.
+extern "C" int mpv_gemm_bf16_batched(const void* const* A, const void* const* B, void* const* C, int batch, int64_t M, int64_t N, int64_t K,
+                                     int64_t lda, int64_t ldb, int64_t ldc, int transA, int transB, hipStream_t stream) {
+  MPV_REQUIRE(A && B && C && batch > 0, MPV_E_ARG, "mpv_gemm_bf16_batched: null pointer table or empty batch");
+  MPV_REQUIRE(M > 0 && N > 0 && K > 0, MPV_E_SHAPE, "mpv_gemm_bf16_batched: empty problem %lld x %lld x %lld", (long long)M, (long long)N, (long long)K);
+  MPV_REQUIRE(!(transA && !transB), MPV_E_ARG, "mpv_gemm_bf16_batched: transA=1,transB=0 is not a Linear pass");
+  MPV_REQUIRE(N % 8 == 0 && ldc % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && (transA ? M % 8 == 0 : K % 8 == 0), MPV_E_ALIGN,
+              "mpv_gemm_bf16_batched: N, K (M when transA) and the leading dimensions must be multiples of 8");
+  MPV_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? N : K) && ldc >= N, MPV_E_SHAPE, "mpv_gemm_bf16_batched: leading dimension shorter than its row");
+  const long long a_bytes = (((transA ? K : M) - 1) * lda + (transA ? M : K)) * 2, b_bytes = (((transB ? K : N) - 1) * ldb + (transB ? N : K)) * 2;
+  MPV_REQUIRE(a_bytes < 0x7FFFFFF0ll && b_bytes < 0x7FFFFFF0ll, MPV_E_SHAPE, "mpv_gemm_bf16_batched: operand larger than 2 GiB");
+  for (int i = 0; i < batch; ++i) {
+    MPV_REQUIRE(A[i] && B[i] && C[i], MPV_E_ARG, "mpv_gemm_bf16_batched: null operand in problem %d", i);
+    MPV_REQUIRE((((uintptr_t)A[i] | (uintptr_t)B[i] | (uintptr_t)C[i]) & 15) == 0, MPV_E_ALIGN, "mpv_gemm_bf16_batched: operands must be 16-byte aligned (problem %d)", i);
+  }
+  GemmArgs g = {};
+  g.M = (int)M; g.N = (int)N; g.K = (int)K;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.alpha = 1.0f;
+  g.amap = g.cmap = g.kmap = RowMap{0, 0, 0};
+  g.a_bytes = (uint32_t)a_bytes;
+  g.b_bytes = (uint32_t)b_bytes;
+  g.tiles_m = (int)((M + BM - 1) / BM);
+  g.tiles_n = (int)((N + BN - 1) / BN);
+  g.nwg = g.tiles_m * g.tiles_n;
+  g.splits = 1;
+  g.k_per_split = (int)K;
+  for (int b0 = 0; b0 < batch; b0 += GEMM_BATCH_MAX) {
+    const int nb = batch - b0 < GEMM_BATCH_MAX ? batch - b0 : GEMM_BATCH_MAX;
+    GemmBatchPtrs bp = {};
+    for (int i = 0; i < nb; ++i) {
+      bp.a[i] = (const bf16*)A[b0 + i];
+      bp.b[i] = (const bf16*)B[b0 + i];
+      bp.c[i] = (bf16*)C[b0 + i];
+    }
+    const dim3 grid((unsigned)g.nwg, (unsigned)nb), block(256);
+    if (!transA && !transB)
+      hipLaunchKernelGGL((gemm_bf16_batched_kernel<false, false>), grid, block, 0, stream, g, bp);
+    else if (!transA && transB)
+      hipLaunchKernelGGL((gemm_bf16_batched_kernel<false, true>), grid, block, 0, stream, g, bp);
+    else
+      hipLaunchKernelGGL((gemm_bf16_batched_kernel<true, true>), grid, block, 0, stream, g, bp);
+  }
+  return mpv_check_launch("mpv_gemm_bf16_batched");
 }

@@ -351,11 +351,34 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     }
   }
   // mapped reduction rows (temporal-branch wgrad): physical row of this lane's k row of the K-tile being issued
-  uint32_t prow[2] = {0u, 0u};
-  auto map_ktile = [&](int kt) {
+  // Round 6: map_ktile is called for K-tiles 0, 1, 2, ... in order, so only K-tile 0 pays the division of map_row; every later tile
+  // advances the lane's (remainder, physical row) pair by TK rows -- two adds and a compare per row instead of a 32-bit divide (~30 VALU
+  // instructions each, 60 per K-tile and lane beside 64 MFMAs: the kmapped weight gradients ran 5-11 % behind their unmapped twins).
+  uint32_t prow[2] = {0u, 0u}, krem[2] = {0u, 0u};
+  auto map_first = [&]() {          // K-tile 0
     if constexpr (kmapped) {
+      const uint32_t g = (uint32_t)p.kmap.group;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) prow[j] = (uint32_t)map_row(p.kmap, kbeg + kt * TK + wave * 8 + j * 4 + (lane >> 4));
+      for (int j = 0; j < 2; ++j) {
+        const uint32_t r = (uint32_t)(kbeg + wave * 8 + j * 4 + (lane >> 4));
+        const uint32_t q = r / g;
+        krem[j] = r - q * g;
+        prow[j] = q * (uint32_t)p.kmap.stride + krem[j] + (uint32_t)p.kmap.offset;
+      }
+    }
+  };
+  auto map_next = [&]() {           // the K-tile behind the one mapped last
+    if constexpr (kmapped) {
+      const uint32_t g = (uint32_t)p.kmap.group;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        krem[j] += TK;
+        prow[j] += TK;
+        while (krem[j] >= g) {          // (at most once when the group is at least a K-tile long: 196 token rows per frame)
+          krem[j] -= g;
+          prow[j] += (uint32_t)p.kmap.stride - g;
+        }
+      }
     }
   };
 
@@ -539,7 +562,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     }
     SCHED_FENCE();
     // unit (4t + j + 6): K-tile t+1 for j < 2 (other buffer), t+2 for j >= 2 (this buffer); unit-in-buffer (j + 2) & 3
-    if constexpr (j == 2) map_ktile(t + 2);
+    if constexpr (j == 2) map_next();      // K-tile t + 2
     issue_unit(IC<((j + 2) & 3)>{}, t + (j < 2 ? 1 : 2), (j < 2 ? (buf ^ 1) : buf) * 4 + ((j + 2) & 3));
     __builtin_amdgcn_s_waitcnt(0x0F76);   // vmcnt(6): everything but the three newest units of this wave has landed
     SCHED_FENCE();
@@ -572,12 +595,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   }
 
   // ---- prologue: units 0..5 (K-tile 0 and U0, U1 of K-tile 1)
-  map_ktile(0);
+  map_first();
   issue_unit(IC<0>{}, 0, 0);
   issue_unit(IC<1>{}, 0, 1);
   issue_unit(IC<2>{}, 0, 2);
   issue_unit(IC<3>{}, 0, 3);
-  map_ktile(1);
+  map_next();       // K-tile 1
   issue_unit(IC<0>{}, 1, 4);
   issue_unit(IC<1>{}, 1, 5);
   // phase 0 reads U0 and U1 only, so it starts once THEY have landed (vmcnt(8): everything but the four newest units of this

@@ -35,9 +35,9 @@ __global__ __launch_bounds__(256) void copy_segments_kernel(const SegArgs a) {
 // the remaining D / 64 workgroups: column sums, 64 columns x 16 row lanes each (1024 threads), eight loads in flight per lane
 // (round 4: with 4 row lanes and a rolled loop a lane walked 192 rows one dependent round trip at a time -- 25.6 us for 1.2 MB).
 constexpr int CF_THREADS = 1024, CF_RL = CF_THREADS / 64;
-__global__ __launch_bounds__(CF_THREADS) void compose_finish_kernel(const bf16* __restrict__ P, const bf16* __restrict__ dbc,
-                                                                    const bf16* __restrict__ bp, const bf16* __restrict__ wf,
-                                                                    bf16* __restrict__ dwf, bf16* __restrict__ dbp, int D, int nrank) {
+__device__ __forceinline__ void compose_finish_body(const bf16* __restrict__ P, const bf16* __restrict__ dbc,
+                                                    const bf16* __restrict__ bp, const bf16* __restrict__ wf,
+                                                    bf16* __restrict__ dwf, bf16* __restrict__ dbp, int D, int nrank) {
   __shared__ float red[CF_RL][64];
   if ((int)blockIdx.x < nrank) {
     const int d8 = D >> 3;
@@ -78,6 +78,45 @@ __global__ __launch_bounds__(CF_THREADS) void compose_finish_kernel(const bf16* 
     for (int r = 0; r < CF_RL; ++r) t += red[r][cl];
     dbp[j] = f2bf(t);
   }
+}
+
+__global__ __launch_bounds__(CF_THREADS) void compose_finish_kernel(const bf16* __restrict__ P, const bf16* __restrict__ dbc,
+                                                                    const bf16* __restrict__ bp, const bf16* __restrict__ wf,
+                                                                    bf16* __restrict__ dwf, bf16* __restrict__ dbp, int D, int nrank) {
+  compose_finish_body(P, dbc, bp, wf, dwf, dbp, D, nrank);
+}
+
+// The same for every block of the tower in ONE launch (blockIdx.y = block; the pointers travel by value), and the forward's
+// bc = Wf bp + bf of every block in one launch: with the [D, D] products batched too (gemm.hip: gemm_bf16_batched_kernel) the composed
+// temporal projection costs the step 5 small launches instead of 60.
+constexpr int COMPOSE_BATCH_MAX = 16;
+struct ComposeBatch {
+  const bf16* p0[COMPOSE_BATCH_MAX];   // finish: dWc Wp^T        bias: Wf
+  const bf16* p1[COMPOSE_BATCH_MAX];   //         d(bc)                 bp
+  const bf16* p2[COMPOSE_BATCH_MAX];   //         bp                    bf
+  const bf16* p3[COMPOSE_BATCH_MAX];   //         Wf                    --
+  bf16* o0[COMPOSE_BATCH_MAX];         //         dWf                   bc
+  bf16* o1[COMPOSE_BATCH_MAX];         //         d(bp)                 --
+};
+__global__ __launch_bounds__(CF_THREADS) void compose_finish_batched_kernel(const ComposeBatch b, int D, int nrank) {
+  const int i = blockIdx.y;
+  compose_finish_body(b.p0[i], b.p1[i], b.p2[i], b.p3[i], b.o0[i], b.o1[i], D, nrank);
+}
+// bc[r] = bf16( sum_j Wf[r][j] bp[j] + bf[r] ): one wave per output row, 16-byte loads, fp32 accumulation (D % 8 == 0)
+__global__ __launch_bounds__(256) void compose_bias_batched_kernel(const ComposeBatch b, int D) {
+  const int blk = blockIdx.y;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= D) return;
+  const bf16* __restrict__ w = b.p0[blk] + (long long)r * D;
+  const bf16* __restrict__ v = b.p1[blk];
+  float acc = 0.f;
+  for (int c = lane * 8; c < D; c += 512) {
+    const f32x8 a = cvt8(*(const bf16x8*)(w + c)), x = cvt8(*(const bf16x8*)(v + c));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc += a[e] * x[e];
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) b.o0[blk][r] = f2bf(acc + bf2f(b.p2[blk][r]));
 }
 
 // ---- caption targets of the loss window ---------------------------------------------------------------------
@@ -283,4 +322,45 @@ extern "C" int mpv_layernorm_dparam_finish(const float* const* partials, const i
     hipLaunchKernelGGL(ln_dparam_finish_kernel<true>, dim3(gx, 1, (unsigned)m), dim3(256), 0, stream, a);
   }
   return mpv_check_launch("mpv_layernorm_dparam_finish");
+}
+
+extern "C" int mpv_vit_compose_bwd_finish_batched(const void* const* dwc_wpT, const void* const* dbc, const void* const* bp, const void* const* wf,
+                                                  void* const* dwf, void* const* dbp, int batch, int D, hipStream_t stream) {
+  MPV_REQUIRE(dwc_wpT && dbc && bp && wf && dwf && dbp && batch > 0, MPV_E_ARG, "mpv_vit_compose_bwd_finish_batched: null pointer table or empty batch");
+  MPV_REQUIRE(D > 0 && D % 8 == 0, MPV_E_SHAPE, "mpv_vit_compose_bwd_finish_batched: D must be a positive multiple of 8");
+  for (int i = 0; i < batch; ++i) {
+    MPV_REQUIRE(dwc_wpT[i] && dbc[i] && bp[i] && wf[i] && dwf[i] && dbp[i], MPV_E_ARG, "mpv_vit_compose_bwd_finish_batched: null pointer in block %d", i);
+    MPV_REQUIRE((((uintptr_t)dwc_wpT[i] | (uintptr_t)bp[i] | (uintptr_t)dwf[i]) & 15) == 0, MPV_E_ALIGN,
+                "mpv_vit_compose_bwd_finish_batched: the matrices must be 16-byte aligned (block %d)", i);
+  }
+  const int nrank = (int)(((long long)D * (D / 8) + CF_THREADS - 1) / CF_THREADS);
+  for (int b0 = 0; b0 < batch; b0 += COMPOSE_BATCH_MAX) {
+    const int nb = batch - b0 < COMPOSE_BATCH_MAX ? batch - b0 : COMPOSE_BATCH_MAX;
+    ComposeBatch cb = {};
+    for (int i = 0; i < nb; ++i) {
+      cb.p0[i] = (const bf16*)dwc_wpT[b0 + i]; cb.p1[i] = (const bf16*)dbc[b0 + i]; cb.p2[i] = (const bf16*)bp[b0 + i];
+      cb.p3[i] = (const bf16*)wf[b0 + i]; cb.o0[i] = (bf16*)dwf[b0 + i]; cb.o1[i] = (bf16*)dbp[b0 + i];
+    }
+    hipLaunchKernelGGL(compose_finish_batched_kernel, dim3((unsigned)(nrank + (D + 63) / 64), (unsigned)nb), dim3(CF_THREADS), 0, stream, cb, D, nrank);
+  }
+  return mpv_check_launch("mpv_vit_compose_bwd_finish_batched");
+}
+
+extern "C" int mpv_vit_compose_bias_batched(const void* const* wf, const void* const* bp, const void* const* bf, void* const* bc, int batch, int D,
+                                            hipStream_t stream) {
+  MPV_REQUIRE(wf && bp && bf && bc && batch > 0, MPV_E_ARG, "mpv_vit_compose_bias_batched: null pointer table or empty batch");
+  MPV_REQUIRE(D > 0 && D % 8 == 0, MPV_E_SHAPE, "mpv_vit_compose_bias_batched: D must be a positive multiple of 8");
+  for (int i = 0; i < batch; ++i) {
+    MPV_REQUIRE(wf[i] && bp[i] && bf[i] && bc[i], MPV_E_ARG, "mpv_vit_compose_bias_batched: null pointer in block %d", i);
+    MPV_REQUIRE((((uintptr_t)wf[i] | (uintptr_t)bp[i]) & 15) == 0, MPV_E_ALIGN, "mpv_vit_compose_bias_batched: Wf and bp must be 16-byte aligned (block %d)", i);
+  }
+  for (int b0 = 0; b0 < batch; b0 += COMPOSE_BATCH_MAX) {
+    const int nb = batch - b0 < COMPOSE_BATCH_MAX ? batch - b0 : COMPOSE_BATCH_MAX;
+    ComposeBatch cb = {};
+    for (int i = 0; i < nb; ++i) {
+      cb.p0[i] = (const bf16*)wf[b0 + i]; cb.p1[i] = (const bf16*)bp[b0 + i]; cb.p2[i] = (const bf16*)bf[b0 + i]; cb.o0[i] = (bf16*)bc[b0 + i];
+    }
+    hipLaunchKernelGGL(compose_bias_batched_kernel, dim3((unsigned)((D + 3) / 4), (unsigned)nb), dim3(256), 0, stream, cb, D);
+  }
+  return mpv_check_launch("mpv_vit_compose_bias_batched");
 }

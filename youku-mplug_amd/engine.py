@@ -62,8 +62,11 @@ def default_stages(model: nn.Module) -> List[Tuple[str, List[nn.Parameter]]]:
     depth = len(ve.blocks)
     stages: List[Tuple[str, List[nn.Parameter]]] = [("head", [])] + [(f"block{i}", []) for i in range(depth - 1, -1, -1)] + [("stem", [])]
     index = {name: i for i, (name, _) in enumerate(stages)}
+    late = {id(p) for p in ve.late_grad_params()} if hasattr(ve, "late_grad_params") else set()
     for n, p in named:
-        if n.startswith("visual_encoder.blocks."):
+        if id(p) in late:
+            stages[index["stem"]][1].append(p)      # complete only at the end of the tower's backward (vision.TimeSformer.late_grad_params)
+        elif n.startswith("visual_encoder.blocks."):
             bi = int(n.split(".")[2])
             stages[index[f"block{bi}"]][1].append(p)
         elif n.startswith("visual_encoder.norm."):

@@ -379,6 +379,39 @@ def vit_compose_bwd_finish(dwc_wpT, dbc, bp, wf, dwf, dbp, D):
                                                 dbp.data_ptr(), D, _stream()), "mpv_vit_compose_bwd_finish")
 
 
+def _ptr_table(tensors):
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def gemm_batched(a_list, b_list, c_list, M, N, K, trans_a=False, trans_b=False):
+    """c_list[i] <- a_list[i] op b_list[i] for every i in ONE launch (include/mpv.h: mpv_gemm_bf16_batched): mpv_gemm_bf16's operand
+    forms, one shape, contiguous bf16 operands, plain epilogue."""
+    global gemm_calls
+    n = len(a_list)
+    assert n == len(b_list) == len(c_list) and n > 0
+    _need_cuda(*a_list, *b_list, *c_list)
+    lda = M if trans_a else K
+    ldb = N if trans_b else K
+    gemm_calls += 1
+    check(_lib.lib().mpv_gemm_bf16_batched(_ptr_table(a_list), _ptr_table(b_list), _ptr_table(c_list), n, M, N, K, lda, ldb, N,
+                                           int(trans_a), int(trans_b), _stream()), "mpv_gemm_bf16_batched")
+    return c_list
+
+
+def vit_compose_bias_batched(wf_list, bp_list, bf_list, bc_list, D):
+    """bc[i] <- bf16(Wf[i] bp[i] + bf[i]) for every block in one launch (include/mpv.h: mpv_vit_compose_bias_batched)."""
+    _need_cuda(*wf_list, *bp_list, *bf_list, *bc_list)
+    check(_lib.lib().mpv_vit_compose_bias_batched(_ptr_table(wf_list), _ptr_table(bp_list), _ptr_table(bf_list), _ptr_table(bc_list),
+                                                  len(wf_list), D, _stream()), "mpv_vit_compose_bias_batched")
+
+
+def vit_compose_bwd_finish_batched(dwc_wpT, dbc, bp, wf, dwf, dbp, D):
+    """mpv_vit_compose_bwd_finish for every block in one launch (lists of tensors)."""
+    _need_cuda(*dwc_wpT, *dbc, *bp, *wf, *dwf, *dbp)
+    check(_lib.lib().mpv_vit_compose_bwd_finish_batched(_ptr_table(dwc_wpT), _ptr_table(dbc), _ptr_table(bp), _ptr_table(wf), _ptr_table(dwf),
+                                                        _ptr_table(dbp), len(wf), D, _stream()), "mpv_vit_compose_bwd_finish_batched")
+
+
 def caption_targets(ids, attention_mask, prompt_len=None):
     """-> (labels int64 [B*L], weights fp32 [B*L]) of the L text positions (include/mpv.h: mpv_caption_targets)."""
     _need_cuda(ids, attention_mask)

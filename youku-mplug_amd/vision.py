@@ -201,6 +201,12 @@ class _WgradLane:
 # two wgrads (backward) instead of the composed projection (TimeSformer.forward_features / backward_features)
 COMPOSE_TEMPORAL_OUT = os.environ.get("MPV_VIT_COMPOSE", "1") != "0"
 _COMPOSE_ON_LANE = os.environ.get("MPV_VIT_COMPOSE_LANE", "1") != "0"    # measurement knob: 0 = the composed weights are built on the main stream
+# Round 6: the [D, D] chain-rule products of the composed projection depend on parameters and per-block reduced gradients only, so all
+# blocks' worth goes out in ONE launch per kind (mpv_gemm_bf16_batched, mpv_vit_compose_bias_batched, ..._finish_batched): Wc / bc at the
+# head of the step, dWf / dWp / d(bp) at the end of the tower's backward -- 5 launches per step instead of 60 (36 of them 768^3 products of
+# 36 workgroups at 42-50 TFLOP/s).  The three gradients then complete with the stem, not with their block (late_grad_params: the engine
+# puts them into the stem's bucket).  MPV_VIT_COMPOSE_GROUP=0: measurement knob, the per-block launches of rounds 3-5.
+COMPOSE_GROUPED = os.environ.get("MPV_VIT_COMPOSE_GROUP", "1") != "0"      # (only read where COMPOSE_TEMPORAL_OUT is on)
 _SMALL_TILE = int(os.environ.get("MPV_VIT_SMALL_TILE", "128"))    # tile kernel of the [D, D] chain-rule products: 36 tiles of 128x128 beat 9 of 256x256 (same-box 78.5 -> 78.35 ms per step)
 
 
@@ -271,6 +277,14 @@ class TimeSformer(nn.Module):
     def no_weight_decay(self):
         return {"temporal_embed", "pos_embed", "cls_token"}
 
+    def late_grad_params(self):
+        """Parameters whose gradients are complete only at the END of the tower's backward (with the stem), not with their block: the
+        composed temporal projection's chain-rule products of all blocks run as one batched launch there (COMPOSE_GROUPED).  The
+        engine's bucket layout reads this (engine.default_stages)."""
+        if not (COMPOSE_TEMPORAL_OUT and COMPOSE_GROUPED):
+            return []
+        return [p for blk in self.blocks for p in (blk.temporal_fc.weight, blk.temporal_attn.proj.weight, blk.temporal_attn.proj.bias)]
+
     # ------------------------------------------------------------------ forward
     def forward_features(self, video: torch.Tensor, tape: dict):
         """video [B,3,T,H,W] bf16 -> image_embeds [B*(1+T*N), D] (cls first, then frame-major tokens,
@@ -309,6 +323,17 @@ class TimeSformer(nn.Module):
             composed = []
 
             def _compose_all():
+                if COMPOSE_GROUPED:
+                    nb = len(self.blocks)
+                    wcs = torch.empty((nb, D, D), dtype=torch.bfloat16, device=video.device)
+                    bcs = torch.empty((nb, D), dtype=torch.bfloat16, device=video.device)
+                    wfs = [blk.temporal_fc.weight.detach() for blk in self.blocks]
+                    ops.gemm_batched(wfs, [blk.temporal_attn.proj.weight.detach() for blk in self.blocks], list(wcs.unbind(0)),
+                                     D, D, D, trans_b=True)                                                  # Wc = Wf Wp, every block
+                    ops.vit_compose_bias_batched(wfs, [blk.temporal_attn.proj.bias.detach() for blk in self.blocks],
+                                                 [blk.temporal_fc.bias.detach() for blk in self.blocks], list(bcs.unbind(0)), D)   # bc = Wf bp + bf
+                    composed.extend(zip(wcs.unbind(0), bcs.unbind(0)))
+                    return
                 for blk in self.blocks:
                     wf, wp = blk.temporal_fc.weight.detach(), blk.temporal_attn.proj.weight.detach()
                     wc = ops.gemm(wf, wp, D, D, D, trans_b=True, tile_hint=_SMALL_TILE)                      # Wc = Wf Wp
@@ -408,6 +433,8 @@ class TimeSformer(nn.Module):
         self._wgrad_lane = wl
         wl.check_memory(demb.device)
         lnb = self.__dict__.setdefault("_ln_batch", ops.LnDparamBatch())   # a block's three dgamma/dbeta reductions: one launch
+        grouped = COMPOSE_TEMPORAL_OUT and COMPOSE_GROUPED
+        dwcs = torch.empty((len(self.blocks), D, D), dtype=torch.bfloat16, device=demb.device) if grouped else None   # dWc of every block
         for bi in range(len(self.blocks) - 1, -1, -1):
             blk, s = self.blocks[bi], tape["blocks"][bi]
             hid = blk.mlp.fc1.out_features
@@ -450,8 +477,11 @@ class TimeSformer(nn.Module):
                 wf, wp = blk.temporal_fc.weight.detach(), blk.temporal_attn.proj.weight.detach()
                 wc = s["wc"]                                                                       # Wc = Wf Wp, from the forward
 
-                def _temporal_out_wgrad(dxt=dxt, wf=wf, wp=wp):
+                def _temporal_out_wgrad(dxt=dxt, wf=wf, wp=wp, bi=bi):
                     dbc = grad_of(blk.temporal_fc.bias)                                   # d(bf) = d(bc) = colsum d(xt)
+                    if grouped:         # dWc is parked; the [D, D] chain rule of all blocks runs as one batch behind block 0
+                        ops.gemm(dxt, s["at"], D, D, Rt, trans_a=True, trans_b=True, kmap=tok, colsum_out=dbc, out=dwcs[bi])
+                        return
                     dwc = ops.gemm(dxt, s["at"], D, D, Rt, trans_a=True, trans_b=True, kmap=tok, colsum_out=dbc)
                     dwf = ops.gemm(dwc, wp, D, D, D, tile_hint=_SMALL_TILE)               # dWc Wp^T
                     ops.gemm(wf, dwc, D, D, D, trans_a=True, trans_b=True, out=grad_of(blk.temporal_attn.proj.weight), tile_hint=_SMALL_TILE)   # Wf^T dWc
@@ -488,6 +518,21 @@ class TimeSformer(nn.Module):
             tape["blocks"][bi] = None          # release activations
             if self.on_block_grads_ready is not None:
                 self.on_block_grads_ready(bi)
+        if grouped:
+            # dWf = dWc Wp^T + d(bc) bp^T, dWp = Wf^T dWc, d(bp) = Wf^T d(bc) of EVERY block: three launches, on the second stream beside the
+            # stem's backward (their operands -- parameters, the parked dWc, the blocks' d(bc) -- are complete)
+            def _compose_chain_rule_all():
+                blks = list(self.blocks)
+                wfs = [b.temporal_fc.weight.detach() for b in blks]
+                wps = [b.temporal_attn.proj.weight.detach() for b in blks]
+                dwc_l = list(dwcs.unbind(0))
+                pre = torch.empty_like(dwcs)
+                ops.gemm_batched(dwc_l, wps, list(pre.unbind(0)), D, D, D)                                     # dWc Wp^T
+                ops.gemm_batched(wfs, dwc_l, [grad_of(b.temporal_attn.proj.weight) for b in blks], D, D, D, trans_a=True, trans_b=True)   # Wf^T dWc
+                ops.vit_compose_bwd_finish_batched(list(pre.unbind(0)), [grad_of(b.temporal_fc.bias) for b in blks],
+                                                   [b.temporal_attn.proj.bias.detach() for b in blks], wfs,
+                                                   [grad_of(b.temporal_fc.weight) for b in blks], [grad_of(b.temporal_attn.proj.bias) for b in blks], D)
+            wl(_compose_chain_rule_all, dwcs)
         if hasattr(self, "norm_pre"):
             m, r = tape["pre_stats"]
             dx = ops.layernorm_bwd(dx, tape["x0"], self.norm_pre.weight, m, r, R, D, dgamma=grad_of(self.norm_pre.weight),
@@ -504,6 +549,8 @@ class TimeSformer(nn.Module):
             gw.view(D, Kc).copy_(tmp[:, :Kc])
         if self.patch_embed.proj.bias is not None:
             ops.colsum(dpatch, Rt, D, out=grad_of(self.patch_embed.proj.bias))
+        if grouped:
+            wl.sync()                                   # the batched chain-rule products (second stream) belong to the stem's bucket
         if self.on_block_grads_ready is not None:
             self.on_block_grads_ready(-1)
 
