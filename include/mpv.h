@@ -107,6 +107,11 @@ typedef struct mpv_gemm_epilogue {
                              plain stores it pushes the operand panels its neighbours share out of the XCD's L2 (round 5: -1.2 ms per
                              step).  1: plain stores -- for a SMALL output that a latency-bound kernel reads right behind this launch
                              (the decoder's qkv product in front of its attention: 26 vs 34 us per layer)                             */
+  float colscale;         /* with colscale_cols > 0 (round 6): output columns n < colscale_cols leave as bf16(bf16(acc + bias) * colscale)  */
+  int colscale_cols;      /* -- a second rounding, exactly `q = q * self.scale` on the q third of the packed qkv product
+                             (models/vision_transformer.py:175-179): the attention kernels then take q as already scaled
+                             (mpv_attn_desc.scale_q_bf16 = 2) and none of the three of them re-scales its q rows per work item.
+                             Multiple of 8; bias-only epilogue (no activation / residual / dropout / accumulate / fp32 output)      */
 } mpv_gemm_epilogue;
 
 size_t mpv_gemm_workspace_size(int64_t M, int64_t N, int64_t K, int transA, int transB);
@@ -187,7 +192,8 @@ typedef struct mpv_attn_desc {
   int batch, heads, sq, sk, head_dim;
   int causal;       /* key j visible to query i iff j <= i + (sk - sq) */
   float scale;      /* softmax(scale * q.k)                            */
-  int scale_q_bf16; /* 1: q' = bf16(q*scale) first (ViT numerics)      */
+  int scale_q_bf16; /* 1: q' = bf16(q*scale) first (ViT numerics); 2: q IS that q' already (written by the qkv product's
+                       colscale epilogue): scores use it as it is, dQ is still the gradient of the UNSCALED q (x scale)  */
   float dropout_p;  /* on the probabilities                            */
   uint64_t seed, offset;
 } mpv_attn_desc;

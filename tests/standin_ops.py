@@ -68,7 +68,7 @@ gemm_calls = 0
 def gemm(a, b, M, N, K, *, out=None, trans_a=False, trans_b=False, lda=None, ldb=None, ldc=None, bias=None, act=0, preact_out=None,
          residual=None, ldr=0, act_bwd_z=None, act_bwd=0, ldz=0, dropout_p=0.0, seed=0, offset=0, alpha_dev=None, alpha=0.0,
          amap=IDENT, cmap=IDENT, kmap=IDENT, out_rows=None, accumulate=False, out_f32=False, colsum_out=None, tile_hint=0,
-         row_tap_out=None, row_tap_group=0, split_hint=0, gm_hint=0, preact_deriv=False, z_is_deriv=False, keep_output=False):
+         row_tap_out=None, row_tap_group=0, split_hint=0, gm_hint=0, preact_deriv=False, z_is_deriv=False, keep_output=False, colscale=None):
     """include/mpv.h mpv_gemm_bf16: C[M,N] = epilogue(sum_k A(m,k) B(n,k)).  preact_deriv / z_is_deriv: the product's own pair of
     switches (ops.gemm): preact_out receives bf16(act'(zb)) and the dgrad multiplies by that tensor (MPV_ACT_DERIV)."""
     from youku_mplug_amd import ops as _ops
@@ -99,6 +99,10 @@ def gemm(a, b, M, N, K, *, out=None, trans_a=False, trans_b=False, lda=None, ldb
     if bias is not None:
         z = z + _flat(bias)[:N].float()[None, :]
     zb = _r16(z)
+    if colscale is not None:          # mpv.h colscale: columns below ncols are rounded, scaled, rounded again
+        assert not (act or act_bwd or residual is not None or preact_out is not None or accumulate or row_tap_out is not None)
+        zb = zb.clone()
+        zb[:, :colscale[0]] = _r16(zb[:, :colscale[0]] * colscale[1])
     v = zb
     if row_tap_out is not None:
         sel = torch.arange(0, M, row_tap_group)
@@ -212,7 +216,9 @@ def _bhrd(t, st, batch, heads, rows, hd):
 def _scores(q, k, lay, batch, heads, sq, sk, hd, causal, scale, scale_q_bf16):
     qf = _bhrd(q, lay.q, batch, heads, sq, hd).float()
     kf = _bhrd(k, lay.k, batch, heads, sk, hd).float()
-    if scale_q_bf16:
+    if scale_q_bf16 == 2:              # q arrives as bf16(q * scale) already (the qkv product's colscale epilogue)
+        sc = 1.0
+    elif scale_q_bf16:
         qf, sc = _r16(qf * scale), 1.0
     else:
         sc = scale

@@ -263,6 +263,47 @@ def test_attention_fwd_bwd(dev, B, H, Sq, Sk, hd, causal, sqb):
         close(dq.permute(0, 2, 1, 3), q2.grad, 3e-2, "dQ (pre-scaled q)")
 
 
+@pytest.mark.parametrize("B,H,S,hd,causal", [(34, 8, 197, 96, False), (3, 2, 197, 96, False), (2, 2, 193, 96, False), (40, 16, 160, 64, True),
+                                             (9, 4, 224, 64, True), (2, 3, 257, 88, False), (2, 2, 786, 96, False), (17, 16, 160, 80, True)])
+def test_attention_with_q_scaled_by_the_producer_is_bit_identical(dev, B, H, S, hd, causal):
+    """Round 6: scale_q_bf16 = 2 -- q arrives as bf16(q * scale), written by the qkv product's colscale epilogue -- against
+    scale_q_bf16 = 1 (every kernel rounds q * scale itself): forward output, statistics, dQ (still the gradient of the UNSCALED q),
+    dK and dV BIT-identical, on every kernel family that honours the flag (persistent / duo ViT kernels, paired-block and one-shot
+    decoder kernels, the chunked kernels of long key ranges, head_dim 88 / 80 instances)."""
+    from youku_mplug_amd import ops
+    q, k, v = rn(B, S, H, hd, dev=dev, seed=30), rn(B, S, H, hd, dev=dev, seed=31), rn(B, S, H, hd, dev=dev, seed=32)
+    do = rn(B, S, H, hd, dev=dev, seed=33)
+    scale = hd ** -0.5
+    qs = (q.float() * scale).to(torch.bfloat16)
+    lay = ops.AttnLayout((S * H * hd, hd, H * hd),) * 4
+    res = []
+    for qq, flag in ((q, 1), (qs, 2)):
+        o = torch.empty_like(q)
+        lse = ops.attn_fwd(qq, k, v, o, lay, B, H, S, S, hd, causal=causal, scale=scale, scale_q_bf16=flag)
+        dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+        ops.attn_bwd(qq, k, v, o, lse, do, dq, dk, dv, lay, B, H, S, S, hd, causal=causal, scale=scale, scale_q_bf16=flag)
+        res.append((o, lse, dq, dk, dv))
+    for name, a, b in zip(("o", "lse", "dq", "dk", "dv"), *res):
+        assert torch.equal(a, b), (name, (a.float() - b.float()).abs().max().item())
+
+
+def test_gemm_colscale_epilogue(dev):
+    """mpv_gemm_epilogue.colscale: columns below colscale_cols leave as bf16(bf16(acc + bias) * s) -- bit-identical to scaling the
+    finished bf16 product (`q = q * self.scale`, models/vision_transformer.py:179), on both tile kernels, every row-band tile variant
+    and a shape whose last tile is split along K; the other columns are untouched."""
+    from youku_mplug_amd import ops
+    for (M, N, K, hint) in ((50432 // 8, 2304, 768, 0), (1576, 2304, 768, 0), (1576, 2304, 768, 128), (520, 264, 2048, 128), (640, 768, 256, 160), (768, 768, 256, 192)):
+        a, w, b = rn(M, K, dev=dev, seed=1), rn(N, K, dev=dev, seed=2, scale=0.05), rn(N, dev=dev, seed=3)
+        ncols, sc = (N // 3 // 8) * 8, 96 ** -0.5
+        plain = ops.gemm(a, w, M, N, K, bias=b, tile_hint=hint)
+        got = ops.gemm(a, w, M, N, K, bias=b, tile_hint=hint, colscale=(ncols, sc))
+        want = plain.clone()
+        want[:, :ncols] = (plain[:, :ncols].float() * sc).to(torch.bfloat16)
+        assert torch.equal(got, want), (M, N, K, hint, (got.float() - want.float()).abs().max().item())
+    with pytest.raises(RuntimeError, match="colscale"):
+        ops.gemm(a, w, M, N, K, bias=b, residual=plain, colscale=(ncols, sc))
+
+
 @pytest.mark.parametrize("B", [2, 80])      # 80 x 4 heads = 320 items: the persistent kernels
 def test_attention_packed_gpt_layout_and_dropout(dev, B):
     """GPT layout: qkv [B,S,np,3*hn] head-interleaved (modeling_distributed_gpt3.py:895-902)."""
@@ -681,7 +722,10 @@ def test_composed_projection_batched_launches_match_per_block(dev, D, nb):
         ops.gemm_batched(a, b, list(out.unbind(0)), D, D, D, trans_a=ta, trans_b=tb)
         for i in range(nb):
             one = ops.gemm(a[i], b[i], D, D, D, trans_a=ta, trans_b=tb, tile_hint=128)
-            assert torch.equal(out[i], one), (ta, tb, i, (out[i].float() - one.float()).abs().max().item())
+            if ta and D >= 512:      # (mpv_gemm_bf16 splits a weight-gradient product of this size along K: another summation order)
+                close(out[i], one, 1e-2, "batched gemm<1,1> vs the split-K launch")
+            else:
+                assert torch.equal(out[i], one), (ta, tb, i, (out[i].float() - one.float()).abs().max().item())
         A = a[0].float().t() if ta else a[0].float()
         Bm = b[0].float() if tb else b[0].float().t()
         close(out[0], A @ Bm, 1e-2, f"batched gemm<{int(ta)},{int(tb)}>")

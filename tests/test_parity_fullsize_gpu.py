@@ -98,7 +98,7 @@ GRAD_L2_GATE = 3.0e-2      # ||g - r||_2 / ||r||_2 over the WHOLE tensor against
 # Round 6: the same whole-tensor distance on EVERY trainable tensor of the model (the live oracle differentiates all of them):
 # a plain number.  Small tensors (a 768-element bias or LayerNorm gain summed over 50 k rows of bf16 products) sit higher than the big
 # weight matrices; measured worst per case in profiles/r06_parity.txt.
-ALL_TENSOR_L2_GATE = 6.0e-2
+ALL_TENSOR_L2_GATE = 3.0e-2      # measured worst: 1.8e-2 (config B, B = 2), 2.0e-2 (B = 32), 1.9e-2 (YAML geometry), 2.3e-2 (config D)
 
 
 def _trainable_keys(model):
@@ -376,10 +376,11 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 #   EVA: logits 8.1e-3, per-token losses 1.5e-3, loss 1.1e-4, worst norm 5.9e-3, whole-tensor L2 2.9e-2 (3.1e-2)
 # (the L2 figures of ITM / CLS are what a bf16 execution of a 9- / 3-sequence batch yields -- medians equal to the reference's own bf16
 # run on the same tensors; the fp32-oracle cases above, where 3e-2 can be reached, ARE gated at 3e-2)
+#   wide-sample L2 over EVERY tensor (round 6): ITM 8.1e-2 (reference bf16 run: 8.2e-2), CLS 7.2e-2 (1.0e-1), EVA 3.5e-2 (3.6e-2)
 FGATES = {
-    "itm": dict(loss_caption=1e-3, loss_cls=1e-2, generation_logits=2e-3, cls_logits=4e-2, norm=4e-2, l2=1.1e-1, wide=1.6e-1),
-    "cls": dict(loss_caption=1e-3, loss_cls=1e-2, generation_logits=2e-3, cls_logits=2.5e-2, norm=4e-2, l2=9e-2, wide=1.6e-1),
-    "eva": dict(logits=1e-2, losses=3e-3, loss=5e-4, norm=1.5e-2, l2=3.5e-2, wide=8e-2),
+    "itm": dict(loss_caption=5e-4, loss_cls=1e-2, generation_logits=2e-3, cls_logits=4e-2, norm=4e-2, l2=1.1e-1, wide=1.0e-1),
+    "cls": dict(loss_caption=5e-4, loss_cls=1e-2, generation_logits=2e-3, cls_logits=2.5e-2, norm=4e-2, l2=9e-2, wide=9e-2),
+    "eva": dict(logits=1e-2, losses=3e-3, loss=2.5e-4, norm=1.2e-2, l2=3.5e-2, wide=4.2e-2),
     "caption": dict(score=3.5e-3),
 }
 

@@ -25,6 +25,7 @@ class GemmEpilogue(C.Structure):
         ("dropout_p", c_float), ("seed", c_uint64), ("offset", c_uint64),
         ("alpha_dev", c_void_p), ("alpha", c_float), ("out_f32", c_int), ("accumulate", c_int),
         ("colsum_out", c_void_p), ("tile_hint", c_int), ("row_tap_out", c_void_p), ("row_tap_group", c_int), ("split_hint", c_int), ("gm_hint", c_int), ("preact_deriv", c_int), ("keep_output", c_int),
+        ("colscale", c_float), ("colscale_cols", c_int),
     ]
 
 

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnArgs p) {
   load_row_frags<HD>(qf, qb, p.q_rs, qrow, p.sq, lane, p.hd);
   float sc = p.scale;
   if (p.scale_q_bf16) {
-    scale_frags_bf16(qf, p.scale);
+    if (p.scale_q_bf16 == 1) scale_frags_bf16(qf, p.scale);      // (2: q arrives scaled, mpv.h)
     sc = 1.0f;
   }
   // keys needed by this workgroup / by this wave (wave-uniform: tiles beyond it are skipped)
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttnArgs p) {
   load_row_frags<HD>(dof, dob, p.o_rs, qrow, p.sq, lane, p.hd);
   float sc = p.scale;
   if (p.scale_q_bf16) {
-    scale_frags_bf16(qf, p.scale);
+    if (p.scale_q_bf16 == 1) scale_frags_bf16(qf, p.scale);      // (2: q arrives scaled, mpv.h)
     sc = 1.0f;
   }
   const bool qok = qrow < p.sq;
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     sq_.issue(qsrc, tid, c_begin * CH, p.sq, p.q_rs, p.hd);
     sd_.issue(dosrc, tid, c_begin * CH, p.sq, p.o_rs, p.hd);
     issue_stats(c_begin);
-    if (p.scale_q_bf16) sq_.scale_bf16(p.scale);
+    if (p.scale_q_bf16 == 1) sq_.scale_bf16(p.scale);
     sq_.commit(smem, tid);
     sd_.commit(smem + CHUNK_BYTES, tid);
     commit_stats(0);
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
       }
     }
     if (c + 1 < nchunk) {
-      if (p.scale_q_bf16) sq_.scale_bf16(p.scale);
+      if (p.scale_q_bf16 == 1) sq_.scale_bf16(p.scale);
       sq_.commit(smem + (cur ^ 1) * 2 * CHUNK_BYTES, tid);
       sd_.commit(smem + (cur ^ 1) * 2 * CHUNK_BYTES + CHUNK_BYTES, tid);
       commit_stats(cur ^ 1);
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(THREADS, WPE) void attn_fwd_res_kernel(const AttnAr
   load_row_frags<HD>(qf, qb, p.q_rs, qrow, p.sq, lane, p.hd);
   float sc = p.scale;
   if (p.scale_q_bf16) {
-    scale_frags_bf16(qf, p.scale);
+    if (p.scale_q_bf16 == 1) scale_frags_bf16(qf, p.scale);      // (2: q arrives scaled, mpv.h)
     sc = 1.0f;
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -858,7 +858,7 @@ __global__ __launch_bounds__(THREADS, WPE) void attn_bwd_dq_res_kernel(const Att
   const float lse_any = p.lse[(long long)bh * p.sq + min(qrow, p.sq - 1)];      // (all requests of the block before the first use of any)
   float sc = p.scale;
   if (p.scale_q_bf16) {
-    scale_frags_bf16(qf, p.scale);
+    if (p.scale_q_bf16 == 1) scale_frags_bf16(qf, p.scale);      // (2: q arrives scaled, mpv.h)
     sc = 1.0f;
   }
   const float lse = qok ? lse_any : INFINITY;
@@ -1010,7 +1010,7 @@ __global__ __launch_bounds__(THREADS, WPE) void attn_bwd_dkv_res_kernel(const At
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
   ASTAMP(2);
-  if (p.scale_q_bf16) {   // q' = bf16(q * scale) in place, once
+  if (p.scale_q_bf16 == 1) {   // q' = bf16(q * scale) in place, once (2: q arrives scaled)
     for (int g = tid; g < p.sq * (HD / 8); g += blockDim.x) {
       const int row = g / (HD / 8), cc = g - row * (HD / 8);
       bf16x8* ptr = (bf16x8*)(ql + row * ROWB + cc * 16);
@@ -1274,7 +1274,7 @@ __global__ __launch_bounds__(THREADS, WPE) void attn_fwd_pres_kernel(const AttnA
       const int wave_first_last = last_visible_key(p, q0);      // tiles entirely <= this need no masking
       const int nt = NTC ? NTC : wave_last / 32 + 1;
       const float c2 = (p.scale_q_bf16 ? 1.0f : p.scale) * 1.4426950408889634f;               // exp2 domain: p = 2^(s*c2 - m)
-      if (p.scale_q_bf16) scale_frags_bf16(qf, p.scale);
+      if (p.scale_q_bf16 == 1) scale_frags_bf16(qf, p.scale);
       const int kbase = cur * setb + vbytes + rows_lane_base<KP>(lane), vbase = cur * setb + cols_lane_base<VP>(lane);
       static_assert(!LEAN || NTC > 1, "LEAN needs a compile-time tile count");
       f32x16 st[LEAN ? NTM - 1 : NTM];
@@ -1604,7 +1604,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
       }
     if (!q_ready) {
       qv = cvt8(q_raw);
-      if (p.scale_q_bf16) qv = cvt8(cvt8(qv * p.scale));
+      if (p.scale_q_bf16 == 1) qv = cvt8(cvt8(qv * p.scale));
       if (!cok) qv = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       q_ready = true;
     }

@@ -97,10 +97,25 @@ struct Loader {
   }
 };
 
+// `batch` independent products of ONE shape in one launch (blockIdx.y = problem; mpv_gemm_bf16_batched): the [D, D] chain-rule products of
+// the composed temporal projection -- Wc = Wf Wp of every ViT block at the head of the step, dWf' = dWc Wp^T and dWp = Wf^T dWc of every
+// block at the end of the tower's backward -- were 36 launches of 36 workgroups each (768^3: 42-50 TFLOP/s, 0.7 ms per step); as three
+// launches of 12 x 36 workgroups they fill the chip once.  The operand pointers of the problems travel by value in the launch
+// (GemmArgs.batch > 0 selects them; an ordinary launch passes an empty table and a grid of height 1).
+constexpr int GEMM_BATCH_MAX = 16;
+struct GemmBatchPtrs {
+  const bf16* a[GEMM_BATCH_MAX];
+  const bf16* b[GEMM_BATCH_MAX];
+  bf16* c[GEMM_BATCH_MAX];
+};
+
 template <bool TA, bool TB>
-__device__ __forceinline__ void gemm_bf16_body(const GemmArgs& p) {
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p, const GemmBatchPtrs bptr) {
   const uint64_t seed_r = p.drop_thr ? mpv_resolve_seed(p.seed) : 0;      // (bit 63 set: the seed lives in device memory, mpv_common.h)
   __shared__ __attribute__((aligned(1024))) char smem[4 * TILE_BYTES];
+  const bf16* const opA = p.batch ? bptr.a[blockIdx.y] : p.A;
+  const bf16* const opB = p.batch ? bptr.b[blockIdx.y] : p.B;
+  void* const opC = p.batch ? (void*)bptr.c[blockIdx.y] : p.C;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -137,8 +152,8 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& p) {
   const int kend = min(p.K, kbeg + (parts > 1 ? p.tail_steps * BK : p.k_per_split));
   const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
 
-  const __amdgpu_buffer_rsrc_t ra_src = make_rsrc(p.A, p.a_bytes);
-  const __amdgpu_buffer_rsrc_t rb_src = make_rsrc(p.B, p.b_bytes);
+  const __amdgpu_buffer_rsrc_t ra_src = make_rsrc(opA, p.a_bytes);
+  const __amdgpu_buffer_rsrc_t rb_src = make_rsrc(opB, p.b_bytes);
 
   Loader<TA> la;
   Loader<TB> lb;
@@ -152,7 +167,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& p) {
 
   // k-contiguous operands: LDS-DMA of K-tile k0 into LDS buffer `buf` (4 x 1 KiB per wave per operand);
   // reduction-slow operands: buffer loads into registers (committed to LDS after the MFMAs)
-  auto issue = [&](int k0, int buf) {
+  auto issue = [&](int k0, int buf) __attribute__((always_inline)) {
     char* pa = smem + buf * 2 * TILE_BYTES + wave * 4096;
     char* pb = pa + TILE_BYTES;
 #pragma unroll
@@ -182,7 +197,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& p) {
   // staging registers -- each thread owns 8 columns x 4 k-rows per K step
   f32x8 csum = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const bool do_colsum = TA && p.colsum_part != nullptr && n0 == 0;
-  auto commit = [&](int buf) {
+  auto commit = [&](int buf) __attribute__((always_inline)) {
     char* pa = smem + buf * 2 * TILE_BYTES;
     char* pb = pa + TILE_BYTES;
 #pragma unroll
@@ -210,7 +225,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& p) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   // fragment fetch: 8 bf16 along k for output index (lane&31) of 32-wide sub-tile `t`
-  auto frag = [&](const char* base, bool tr, int sub0, int s) -> bf16x8 {
+  auto frag = [&](const char* base, bool tr, int sub0, int s) __attribute__((always_inline)) -> bf16x8 {
     if (!tr) {
       const int row = sub0 + (lane & 31);
       const int chunk = s * 2 + (lane >> 5);
@@ -316,7 +331,9 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * alpha;
           if (p.bias && n0 + col < p.N) v += cvt4(*(const bf16x4*)(p.bias + n0 + col));
-          *(bf16x4*)(cb + (wrow * 64 + i * 32 + (lane & 31)) * BP + col) = cvt4(v);
+          bf16x4 zb = cvt4(v);
+          if (n0 + col < p.colscale_cols) zb = cvt4(cvt4(zb) * p.colscale);      // (mpv.h colscale: a second rounding, as `q * scale` on a bf16 q)
+          *(bf16x4*)(cb + (wrow * 64 + i * 32 + (lane & 31)) * BP + col) = zb;
         }
     __syncthreads();
 #pragma unroll
@@ -324,11 +341,11 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& p) {
       const int c = tid + 256 * it;
       const int row = c >> 4, col = (c & 15) * 8;
       const int m = m0 + row, n = n0 + col;
-      if (m < p.M && n < p.N) *(bf16x8*)((bf16*)p.C + map_row(p.cmap, m) * p.ldc + n) = *(const bf16x8*)(cb + row * BP + col);
+      if (m < p.M && n < p.N) *(bf16x8*)((bf16*)opC + map_row(p.cmap, m) * p.ldc + n) = *(const bf16x8*)(cb + row * BP + col);
     }
     return;
   }
-  auto stage = [&](int half) {
+  auto stage = [&](int half) __attribute__((always_inline)) {
     if (wrow == half) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -413,7 +430,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& p) {
         }
         const long long crow = map_row(p.cmap, m);
         if (p.out_f32) {
-          float* cp = (float*)p.C + (long long)split * p.M * p.N + crow * p.ldc + n;
+          float* cp = (float*)opC + (long long)split * p.M * p.N + crow * p.ldc + n;
           if (p.accumulate) {
             const f32x4 o0 = *(const f32x4*)cp, o1 = *(const f32x4*)(cp + 4);
 #pragma unroll
@@ -427,6 +444,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& p) {
           continue;
         }
         if (p.bias) v += cvt8(*(const bf16x8*)(p.bias + n));
+        if (n < p.colscale_cols) v = cvt8(cvt8(v)) * p.colscale;      // (mpv.h colscale; reached by a tail-split tile: the plain path above handles the rest)
         // the product rounds to bf16 before anything else is applied to it (as the unfused reference ops do, and as the
         // 256x256 kernel's staged tile does): results do not depend on which tile kernel took the problem
         if (p.act_bwd || p.drop_thr || p.residual || p.accumulate || p.tap_out) v = cvt8(cvt8(v));
@@ -466,37 +484,13 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& p) {
           v = mpv_dropout_vec<f32x8, 8>(v, seed_r, base, p.drop_thr, p.drop_scale);
         }
         if (p.residual) v += cvt8(*(const bf16x8*)(p.residual + crow * p.ldr + n));
-        bf16* cp = (bf16*)p.C + crow * p.ldc + n;
+        bf16* cp = (bf16*)opC + crow * p.ldc + n;
         if (p.accumulate) v += cvt8(*(const bf16x8*)cp);
         *(bf16x8*)cp = cvt8(v);
       }
     }
     if (!tail_src) __syncthreads();
   }
-}
-
-template <bool TA, bool TB>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs p) {
-  gemm_bf16_body<TA, TB>(p);
-}
-
-// `batch` independent products of ONE shape in one launch (blockIdx.y = problem): the [D, D] chain-rule products of the composed
-// temporal projection -- Wc = Wf Wp of every ViT block at the head of the step, dWf' = dWc Wp^T and dWp = Wf^T dWc of every block at the
-// end of the tower's backward -- were 36 launches of 36 workgroups each (768^3: 42-50 TFLOP/s, 0.7 ms per step); as three launches of
-// 12 x 36 workgroups they fill the chip once.  The operand pointers of the problems travel by value in the launch.
-constexpr int GEMM_BATCH_MAX = 16;
-struct GemmBatchPtrs {
-  const bf16* a[GEMM_BATCH_MAX];
-  const bf16* b[GEMM_BATCH_MAX];
-  bf16* c[GEMM_BATCH_MAX];
-};
-template <bool TA, bool TB>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_batched_kernel(const GemmArgs p, const GemmBatchPtrs bp) {
-  GemmArgs q = p;
-  q.A = bp.a[blockIdx.y];
-  q.B = bp.b[blockIdx.y];
-  q.C = bp.c[blockIdx.y];
-  gemm_bf16_body<TA, TB>(q);
 }
 
 // sum split-K fp32 partials -> bf16 (optionally accumulating into the existing bf16 value); the trailing workgroups of
@@ -777,6 +771,13 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
                 "mpv_gemm_bf16: preact_deriv needs preact_out and a GELU activation");
     g.preact_deriv = ep->preact_deriv ? 1 : 0;
     g.keep_c = ep->keep_output ? 1 : 0;
+    if (ep->colscale_cols > 0) {
+      MPV_REQUIRE(ep->colscale_cols % 8 == 0 && !ep->act && !ep->preact_out && !ep->residual && !ep->act_bwd_z && !(ep->dropout_p > 0.f) &&
+                      !ep->out_f32 && !ep->accumulate && !ep->row_tap_out && !ep->alpha_dev && !(transA && transB),
+                  MPV_E_ARG, "mpv_gemm_bf16: colscale takes a bias-only bf16 forward / dgrad product and a multiple of 8 columns");
+      g.colscale = ep->colscale;
+      g.colscale_cols = ep->colscale_cols;
+    }
     if (ep->dropout_p > 0.f) {
       MPV_REQUIRE(ep->dropout_p < 1.f, MPV_E_ARG, "mpv_gemm_bf16: dropout_p must be < 1");
       g.drop_thr = mpv_drop_threshold(ep->dropout_p);
@@ -798,7 +799,7 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
   void* colsum_out = ep ? ep->colsum_out : nullptr;
   MPV_REQUIRE(!colsum_out || (transA && transB && !g.out_f32), MPV_E_ARG, "mpv_gemm_bf16: colsum_out is a wgrad (transA=transB=1) option");
   // decode regime: a handful of rows against a k-contiguous weight -> the weight-streaming kernel
-  if (!transA && !transB && M <= 16 && !g.out_f32 && !g.accumulate && !g.drop_thr && !g.act_bwd && !g.preact && !g.alpha_dev && !g.tap_out &&
+  if (!transA && !transB && M <= 16 && !g.out_f32 && !g.accumulate && !g.drop_thr && !g.act_bwd && !g.preact && !g.alpha_dev && !g.tap_out && !g.colscale_cols &&
       g.alpha == 1.0f && g.amap.group == 0 && !colsum_out) {
     SmallMArgs sm = {};
     sm.A = g.A; sm.W = g.B; sm.C = (bf16*)C;
@@ -848,7 +849,7 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
       if (ep && ep->split_hint > 0 && K / ep->split_hint >= 64 &&
           (size_t)M * N * sizeof(float) * ep->split_hint + (size_t)ep->split_hint * M * sizeof(float) <= (workspace ? workspace_bytes : 0))
         s256 = ep->split_hint;
-    } else if (!g.out_f32 && t256 * 2 <= 256 && K >= 4096 && !g.act && !g.residual && !g.act_bwd && !g.tap_out &&
+    } else if (!g.out_f32 && t256 * 2 <= 256 && K >= 4096 && !g.act && !g.residual && !g.act_bwd && !g.tap_out && !g.colscale_cols &&
              !g.preact && g.cmap.group == 0 && ldc == N && N % 4 == 0 && ((uintptr_t)g.bias & 7) == 0) {      // (the reduce reads the bias as bf16x4)
       // few tiles, long reduction, plain / bias / bias + dropout epilogue (applied by the reduce): split-K over the idle CUs (at most
       // the 16 splits the workspace size allows for)
@@ -946,11 +947,11 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
     g.accumulate = 0;
   }
   if (!transA && !transB)
-    hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, stream, g, GemmBatchPtrs{});
   else if (!transA && transB)
-    hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, stream, g, GemmBatchPtrs{});
   else
-    hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, stream, g, GemmBatchPtrs{});
   if (splitk > 1) {
     const long long MN = (long long)M * N;
     const int thr = 256;
@@ -993,6 +994,7 @@ extern "C" int mpv_gemm_bf16_batched(const void* const* A, const void* const* B,
   g.nwg = g.tiles_m * g.tiles_n;
   g.splits = 1;
   g.k_per_split = (int)K;
+  g.batch = 1;
   for (int b0 = 0; b0 < batch; b0 += GEMM_BATCH_MAX) {
     const int nb = batch - b0 < GEMM_BATCH_MAX ? batch - b0 : GEMM_BATCH_MAX;
     GemmBatchPtrs bp = {};
@@ -1003,11 +1005,11 @@ extern "C" int mpv_gemm_bf16_batched(const void* const* A, const void* const* B,
     }
     const dim3 grid((unsigned)g.nwg, (unsigned)nb), block(256);
     if (!transA && !transB)
-      hipLaunchKernelGGL((gemm_bf16_batched_kernel<false, false>), grid, block, 0, stream, g, bp);
+      hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, stream, g, bp);
     else if (!transA && transB)
-      hipLaunchKernelGGL((gemm_bf16_batched_kernel<false, true>), grid, block, 0, stream, g, bp);
+      hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, stream, g, bp);
     else
-      hipLaunchKernelGGL((gemm_bf16_batched_kernel<true, true>), grid, block, 0, stream, g, bp);
+      hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, stream, g, bp);
   }
   return mpv_check_launch("mpv_gemm_bf16_batched");
 }

@@ -708,7 +708,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 #pragma unroll
           for (int mb = 0; mb < (mh == 1 ? MB1 : 4); ++mb) {
             const int row = wr * WROWS + mh * 64 + mb * 16 + l15;
-            *(bf16x4*)(cb + row * CPITCH + col) = cvt4(acc[mh][nh][mb][nb] + bv);
+            bf16x4 zb = cvt4(acc[mh][nh][mb][nb] + bv);
+            if constexpr (KIND == EP_PLAIN) {      // mpv.h colscale: columns below colscale_cols are rounded, scaled and rounded again
+              if (n0 + col < p.colscale_cols) zb = cvt4(cvt4(zb) * p.colscale);
+            }
+            *(bf16x4*)(cb + row * CPITCH + col) = zb;
           }
         }
     __syncthreads();     // the staged tile is complete

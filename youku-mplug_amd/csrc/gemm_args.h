@@ -34,6 +34,9 @@ struct GemmArgs {
   int tile_rows;        // gemm256: 0 = pick 256 / 192 / 160 tile rows per problem, else pinned (tile_hint 192 / 160 / 256)
   int gm;               // gemm256: m-tiles per n-tile in an XCD's tile walk (0 -> default)
   int keep_c;           // gemm256: plain instead of non-temporal output stores (mpv.h: keep_output)
+  int batch;            // gemm.hip: > 0 = the operand pointers come from the launch's pointer table, problem blockIdx.y (mpv_gemm_bf16_batched)
+  float colscale;       // columns n < colscale_cols: bf16(bf16(acc + bias) * colscale) (mpv.h: colscale / colscale_cols; plain epilogue only)
+  int colscale_cols;
   bf16* tap_out;        // rows m % tap_group == 0 also store bf16(acc * alpha + bias) at tap_out[(m / tap_group) * N + n]
   int tap_group;
   float* colsum_part;   // wgrad only: [splits][M] fp32 partial column sums of the A operand (bias gradient)

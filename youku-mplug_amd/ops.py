@@ -59,8 +59,9 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: Optio
          alpha_dev=None, alpha: float = 0.0, amap: RowMap = IDENT, cmap: RowMap = IDENT, kmap: RowMap = IDENT,
          out_rows: Optional[int] = None, accumulate: bool = False, out_f32: bool = False, colsum_out=None,
          tile_hint: int = 0, row_tap_out=None, row_tap_group: int = 0, split_hint: int = 0, gm_hint: int = 0,
-         preact_deriv: bool = False, z_is_deriv: bool = False, keep_output: bool = False) -> torch.Tensor:
+         preact_deriv: bool = False, z_is_deriv: bool = False, keep_output: bool = False, colscale=None) -> torch.Tensor:
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)).  See include/mpv.h:mpv_gemm_bf16.
+    colscale = (ncols, s): output columns below ncols leave as bf16(bf16(acc + bias) * s) (the q third of a packed qkv product).
     preact_deriv (forward of an MLP's first product): preact_out receives act'(z) instead of z; z_is_deriv (the matching dgrad):
     act_bwd_z is that tensor, multiply by it.  A call-site PAIR: both follow the one knob GELU_DERIV_FWD.
     keep_output: the output is small and read right behind this launch by a latency-bound kernel: plain instead of non-temporal stores."""
@@ -100,6 +101,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: Optio
     ep.gm_hint = gm_hint
     ep.preact_deriv = int(bool(preact_deriv and GELU_DERIV_FWD and preact_out is not None))
     ep.keep_output = int(bool(keep_output))
+    if colscale is not None:
+        ep.colscale_cols, ep.colscale = int(colscale[0]), float(colscale[1])
     if z_is_deriv and GELU_DERIV_FWD and act_bwd_z is not None:
         ep.act_bwd = ACT_DERIV
     ws, wsn = None, 0

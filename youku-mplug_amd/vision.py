@@ -207,6 +207,10 @@ _COMPOSE_ON_LANE = os.environ.get("MPV_VIT_COMPOSE_LANE", "1") != "0"    # measu
 # 36 workgroups at 42-50 TFLOP/s).  The three gradients then complete with the stem, not with their block (late_grad_params: the engine
 # puts them into the stem's bucket).  MPV_VIT_COMPOSE_GROUP=0: measurement knob, the per-block launches of rounds 3-5.
 COMPOSE_GROUPED = os.environ.get("MPV_VIT_COMPOSE_GROUP", "1") != "0"      # (only read where COMPOSE_TEMPORAL_OUT is on)
+# Round 6: the spatial attention's `q * scale` (a second bf16 rounding, models/vision_transformer.py:179) is applied by the qkv product's
+# epilogue (mpv_gemm_epilogue.colscale) instead of by each of the three attention kernels on its q rows / q image per work item.
+# MPV_VIT_PRESCALE_Q=0: measurement knob, the kernels scale (rounds 1-5).  Bit-identical either way (tested).
+PRESCALE_Q = os.environ.get("MPV_VIT_PRESCALE_Q", "1") != "0"
 _SMALL_TILE = int(os.environ.get("MPV_VIT_SMALL_TILE", "128"))    # tile kernel of the [D, D] chain-rule products: 36 tiles of 128x128 beat 9 of 256x256 (same-box 78.5 -> 78.35 ms per step)
 
 
@@ -379,12 +383,15 @@ class TimeSformer(nn.Module):
             ops.copy_rows(x, xt, B * T, D, smap=(1, N1, 0), dmap=(1, N1, 0))          # cls slots pass through
             # ---- spatial branch on all rows (:254-267)
             l1, s["m1"], s["r1"] = ops.layernorm_fwd(xt, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, R, D)
-            qkv_s = ops.gemm(l1, blk.attn.qkv.weight, R, 3 * D, D, bias=qkv_b[2 * bi + 1])
+            # (PRESCALE_Q: the q third leaves the product as bf16(bf16(q) * scale) -- `q * self.scale`, :179 -- so that none of the
+            # three attention kernels re-scales its q rows per work item; dQ stays the gradient of the unscaled q)
+            qkv_s = ops.gemm(l1, blk.attn.qkv.weight, R, 3 * D, D, bias=qkv_b[2 * bi + 1],
+                             colscale=(D, blk.attn.scale) if PRESCALE_Q else None)
             a_s = torch.empty((R, D), dtype=torch.bfloat16, device=x.device)
             st3 = (N1 * 3 * D, hd, 3 * D)
             lay = ops.AttnLayout(st3, st3, st3, (N1 * D, hd, D))
             lse = ops.attn_fwd(qkv_s, qkv_s[:, D:], qkv_s[:, 2 * D:], a_s, lay, B * T, heads, N1, N1, hd,
-                               scale=blk.attn.scale, scale_q_bf16=True)
+                               scale=blk.attn.scale, scale_q_bf16=2 if PRESCALE_Q else True)
             # y = xt + proj(a_s) straight from the GEMM's residual epilogue; the projection's cls rows are tapped out of the
             # same launch and only the B*T cls slots are rewritten as xt_cls + mean_t(proj cls)              (:263-270)
             tap = torch.empty((B * T, D), dtype=torch.bfloat16, device=x.device)
@@ -460,7 +467,7 @@ class TimeSformer(nn.Module):
             qkv_s = s["qkv_s"]
             dqkv = torch.empty_like(qkv_s)
             ops.attn_bwd(qkv_s, qkv_s[:, D:], qkv_s[:, 2 * D:], s["a_s"], s["lse"], das, dqkv, dqkv[:, D:], dqkv[:, 2 * D:],
-                         s["lay"], B * T, heads, N1, N1, hd, scale=blk.attn.scale, scale_q_bf16=True)
+                         s["lay"], B * T, heads, N1, N1, hd, scale=blk.attn.scale, scale_q_bf16=2 if PRESCALE_Q else True)
             bsum = torch.empty((2, 3 * D), dtype=torch.bfloat16, device=dqkv.device)   # packed bias gradients of the two qkv products
             wl(lambda: ops.gemm(dqkv, s["l1"], 3 * D, D, R, trans_a=True, trans_b=True, out=grad_of(blk.attn.qkv.weight),
                                 colsum_out=bsum[0]), dqkv)
