@@ -417,9 +417,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--step-mode", choices=["auto", "eager", "graph"], default=None,
-                    help="auto (default): N > 1 replays the step as a chain of HIP-graph segments IF a start-up self-check finds the replay "
-                         "bit-identical to the eager step on every rank, else eager; N = 1 runs eager.  MPV_GRAPH=1 / 0 in the environment "
-                         "mean graph / eager when the flag is absent")
+                    help="auto (default): on N > 1 ranks a start-up self-check compares the replayed step (a chain of HIP-graph segments, "
+                         "all-reduces between them) with the eager step bit for bit on every rank; if it passes, four fenced steps of each mode "
+                         "are timed and the faster one (slowest rank) runs; N = 1 runs eager.  MPV_GRAPH=1 / 0 in the environment mean "
+                         "graph / eager when the flag is absent")
     ap.add_argument("--_test-cpu", dest="test_cpu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     global _ON_CPU
@@ -514,11 +515,10 @@ def main():
         ok, why = engine.graph_self_check(*inputs, before_step=set_lr)
         self_check = {"passed": bool(ok), "detail": why}
         use_graph = bool(ok)
-    step_mode = "graph" if use_graph else "eager"
 
-    def step(i, eager=False):
+    def step(i, eager=False, replay=False):
         set_lr(i)
-        if use_graph and not eager:
+        if replay or (use_graph and not eager):
             return engine.graph_step(video, text, idx) if args.config == "E" else engine.graph_step(video, text)
         if args.config == "E":
             loss = engine(video, text, idx)                          # downstream/run_retrieval_distributed_gpt3.py:137
@@ -531,15 +531,40 @@ def main():
     def log(msg):
         if rank == 0:
             print(f"[bench +{time.perf_counter() - t_start:7.1f}s] {msg}", file=sys.stderr, flush=True)
-    log("model + engine built" + ("" if self_check is None else f"; graph self-check: {self_check} -> step mode {step_mode}"))
-    for i in range(args.warmup):
-        loss = step(i)
-    _sync()
-    log("warmup done")
+
     def fence():
         if dist_on:
             dist.barrier()
         _sync()
+    # auto mode on a process group, self-check passed: MEASURE which mode this host / node runs faster -- four fenced steps of each, the
+    # slowest rank's time -- and take it.  (On a 1-GPU box the replay is ~1 % slower on the device -- the second stream of the
+    # weight-gradient lane overlaps less as graph branches -- and saves ~25 ms of host CPU per step: which of the two matters depends on
+    # the cores eight ranks have to share, which nobody can know before the node exists.)  The state is rewound afterwards.
+    mode_probe = None
+    if mode == "auto" and use_graph:
+        snap = engine.snapshot_state()
+        probe = {}
+        for arm in ("graph", "eager"):
+            step(0, eager=arm == "eager")              # (untimed: the first launch of a mode)
+            fence()
+            tp = time.perf_counter()
+            for i in range(4):
+                step(1 + i, eager=arm == "eager")
+            fence()
+            tt = torch.tensor([time.perf_counter() - tp], device=dev, dtype=torch.float64)
+            if dist_on:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            probe[arm] = tt.item() / 4 * 1e3
+        engine._graph_inflight.clear()
+        engine.restore_state(snap)
+        mode_probe = {k: round(v, 2) for k, v in probe.items()}
+        use_graph = probe["graph"] <= probe["eager"]       # (the same numbers on every rank: MAX-reduced)
+    step_mode = "graph" if use_graph else "eager"
+    log("model + engine built" + ("" if self_check is None else f"; graph self-check: {self_check}; mode probe (ms/step, slowest rank): {mode_probe} -> step mode {step_mode}"))
+    for i in range(args.warmup):
+        loss = step(i)
+    _sync()
+    log("warmup done")
     # per-step HIP events on the launch stream (torch's current stream is the stream every kernel of the step is launched
     # on) give the distribution; the reported value is the whole timed region between two fences (the contract)
     marks = [_event() for _ in range(args.steps + 1)]
@@ -572,18 +597,21 @@ def main():
     _sync()
     log(f"host time to launch one step on an idle queue: {min(t[0] for t in t_idle) * 1e3:.1f} ms wall, {min(t[1] for t in t_idle) * 1e3:.1f} ms CPU")
     host = {"mode": step_mode, "cpu_ms_per_step": round(t_cpu / args.steps * 1e3, 2), "enqueue_wall_ms_per_step": round(t_enq / args.steps * 1e3, 2),
-            "idle_queue_launch_ms": round(min(t[0] for t in t_idle) * 1e3, 2), "graph_self_check": self_check}
-    if use_graph:
-        # the OTHER mode's host cost, for the record: three eager steps on the same queue (every rank: they carry the collectives)
+            "idle_queue_launch_ms": round(min(t[0] for t in t_idle) * 1e3, 2), "graph_self_check": self_check,
+            "mode_probe_ms_per_step": mode_probe}
+    # the OTHER mode's host cost, for the record (every rank: the steps carry the collectives): the CPU time this thread spends enqueueing
+    # eight steps back to back (a filling queue, as in the timed region)
+    other = None
+    if self_check is not None and self_check["passed"]:
+        other_eager = use_graph
         c1 = time.thread_time()
-        for i in range(3):
-            step(total - 1, eager=True)
-        host["cpu_ms_per_step_eager"] = round((time.thread_time() - c1) / 3 * 1e3, 2)
-        host["cpu_ms_per_step_graph"] = host["cpu_ms_per_step"]
+        for i in range(8):
+            step(total - 1, eager=other_eager, replay=not other_eager)
+        other = round((time.thread_time() - c1) / 8 * 1e3, 2)
         _sync()
-    else:
-        host["cpu_ms_per_step_eager"] = host["cpu_ms_per_step"]
-        host["cpu_ms_per_step_graph"] = None          # not run (N = 1 default, a failed self-check, or --step-mode eager)
+        engine._graph_inflight.clear()
+    host["cpu_ms_per_step_eager"] = host["cpu_ms_per_step"] if not use_graph else other
+    host["cpu_ms_per_step_graph"] = host["cpu_ms_per_step"] if use_graph else other      # None: the replay never ran (N = 1 default, failed self-check, --step-mode eager)
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     if dist_on:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)

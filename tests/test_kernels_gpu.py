@@ -275,7 +275,7 @@ def test_attention_with_q_scaled_by_the_producer_is_bit_identical(dev, B, H, S, 
     do = rn(B, S, H, hd, dev=dev, seed=33)
     scale = hd ** -0.5
     qs = (q.float() * scale).to(torch.bfloat16)
-    lay = ops.AttnLayout((S * H * hd, hd, H * hd),) * 4
+    lay = ops.AttnLayout(*(((S * H * hd, hd, H * hd),) * 4))
     res = []
     for qq, flag in ((q, 1), (qs, 2)):
         o = torch.empty_like(q)

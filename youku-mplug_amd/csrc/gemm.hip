@@ -660,12 +660,22 @@ constexpr int SLOTS = 512;                                   // resident workgro
 constexpr size_t TAIL_WS_BYTES = (size_t)SLOTS * BM * BN * sizeof(float);   // 32 MiB of partial tiles
 constexpr size_t TAIL_CNT_BYTES = SLOTS * sizeof(unsigned);                  // + their arrival counters, in the caller's workspace
 
+// Forward / dgrad products with at most half a round of 256-tiles are split along K when the reduction is at least this long
+// (MPV_FWD_SPLIT_MINK: measurement knob; 4096 = rounds 4-5: the LM head's dgrad on the loss window, the 2.7B decoder's 4h -> h product)
+static int fwd_split_min_k() {
+  static const int v = [] {
+    const char* e = getenv("MPV_FWD_SPLIT_MINK");
+    return e && atoi(e) >= 512 ? atoi(e) : 4096;
+  }();
+  return v;
+}
+
 extern "C" size_t mpv_gemm_workspace_size(int64_t M, int64_t N, int64_t K, int transA, int transB) {
   if (!(transA && transB)) {
     // forward / dgrad products with few output tiles and a long reduction (the LM head's dgrad on the loss window:
     // 1024 x 2048 x 51200) are split along K like a wgrad: fp32 partials of up to 16 splits
     const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
-    const size_t part = (t256 * 2 <= 256 && K >= 4096) ? (size_t)M * N * sizeof(float) * 16 : 0;
+    const size_t part = (t256 * 2 <= 256 && K >= fwd_split_min_k()) ? (size_t)M * N * sizeof(float) * 16 : 0;
     return (part > TAIL_WS_BYTES ? part : TAIL_WS_BYTES) + TAIL_CNT_BYTES;
   }
   // wgrad: split the (long) reduction so that >= ~2 workgroups per CU exist (+ the per-split column sums of the fused
@@ -849,7 +859,7 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
       if (ep && ep->split_hint > 0 && K / ep->split_hint >= 64 &&
           (size_t)M * N * sizeof(float) * ep->split_hint + (size_t)ep->split_hint * M * sizeof(float) <= (workspace ? workspace_bytes : 0))
         s256 = ep->split_hint;
-    } else if (!g.out_f32 && t256 * 2 <= 256 && K >= 4096 && !g.act && !g.residual && !g.act_bwd && !g.tap_out && !g.colscale_cols &&
+    } else if (!g.out_f32 && t256 * 2 <= 256 && K >= fwd_split_min_k() && !g.act && !g.residual && !g.act_bwd && !g.tap_out && !g.colscale_cols &&
              !g.preact && g.cmap.group == 0 && ldc == N && N % 4 == 0 && ((uintptr_t)g.bias & 7) == 0) {      // (the reduce reads the bias as bf16x4)
       // few tiles, long reduction, plain / bias / bias + dropout epilogue (applied by the reduce): split-K over the idle CUs (at most
       // the 16 splits the workspace size allows for)
