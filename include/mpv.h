@@ -394,8 +394,11 @@ int mpv_soft_target_ce(const float* sim, const int64_t* row_ids, const int64_t* 
 /* ------------------------------------------------------------------------------------------
  * Optimizer (DeepSpeed FusedAdam + global-norm clip, run_pretrain_distributed_gpt3.py:137;
  * math of optim/adamw.py:66-115; torch.nn.utils.clip_grad_norm_ semantics, utils.py:308).
- * sumsq (fp32 scalar, pre-zeroed) += sum g^2 over n bf16 gradients. */
-int mpv_grad_sumsq(const void* grad, int64_t n, float* sumsq, mpv_stream_t stream);
+ * sumsq (fp32 scalar, pre-zeroed) += sum g^2 over n bf16 gradients -- BIT-REPRODUCIBLE since round 6: per-workgroup partial sums in
+ * `workspace` (mpv_grad_sumsq_workspace_size() bytes), added up in a fixed order by a second launch (the clip coefficient, hence every
+ * update of a clipped step, hangs on the last bits of this scalar; an atomicAdd per workgroup made them depend on arrival order). */
+size_t mpv_grad_sumsq_workspace_size(void);
+int mpv_grad_sumsq(const void* grad, int64_t n, float* sumsq, void* workspace, size_t workspace_bytes, mpv_stream_t stream);
 /* One AdamW step over a flat range: master/m/v fp32, grad bf16, param bf16 written back.
  * clip coefficient = min(1, max_norm / (sqrt(*sumsq) * inv_world ... ) computed in-kernel from
  * the device scalar; grad_scale multiplies g first (1/world for averaged all-reduce sums). */

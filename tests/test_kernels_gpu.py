@@ -527,6 +527,17 @@ def test_adamw_and_gradnorm(dev):
     sumsq = torch.zeros((), device=dev)
     ops.grad_sumsq(g, sumsq)
     assert abs(sumsq.item() - (g.float() ** 2).sum().item()) < 1e-3 * sumsq.item()
+    # round 6: the norm is BIT-reproducible (per-workgroup partials added in a fixed order; an atomicAdd per workgroup made the last bits --
+    # and with them the clip coefficient of every clipped step -- depend on arrival order).  130 M elements = the 2048-workgroup launch of the step.
+    big = (torch.randn(130_000_000 // 8 * 8 + 5 * 8, device=dev) * 1e-3).bfloat16()
+    vals = set()
+    for _ in range(40):
+        s2 = torch.zeros((), device=dev)
+        ops.grad_sumsq(big, s2)
+        vals.add(s2.item())
+    assert len(vals) == 1, vals
+    ref = (big.double() ** 2).sum().item()
+    assert abs(vals.pop() - ref) < 1e-5 * ref
     lr, b1, b2, eps, wd, clip = 1e-3, 0.9, 0.999, 1e-6, 0.05, 3.0
     for step in (1, 2, 3):
         ops.adamw_step(p16, master, m, v, g, lr, b1, b2, eps, wd, step, 1.0, sumsq, clip)

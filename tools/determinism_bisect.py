@@ -47,11 +47,38 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--eval", action="store_true")
     ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=2, help="steps before the logged ones (0: the logged step starts from the seeded initial weights -- "
+                    "what two PROCESSES must agree on from the first call)")
     ap.add_argument("--poison", type=float, default=0.0,
                     help="GiB of device memory to fill with 0xFF bytes (NaN in bf16 and fp32) and hand back to the caching allocator BEFORE anything "
                          "is built: every later allocation then starts as NaN, and an uninitialised read that reaches the loss shows up as a NaN "
                          "loss; the tensors that hold NaNs after each call are listed in call order")
+    ap.add_argument("--zero-empty", action="store_true", help="torch.empty / empty_like return zero-filled tensors in this process: unwritten "
+                    "rows of row-mapped outputs are then the same bits in every process, and a result that depends on uninitialised memory stops varying")
+    ap.add_argument("--dump", default=None, help="write run 0's call log (name, tensor tags, shapes, checksums) as JSON: compare two PROCESSES with --compare")
+    ap.add_argument("--compare", nargs=2, default=None, help="two --dump files: print the first calls whose checksums differ")
     args = ap.parse_args()
+    if args.compare:
+        import json
+        a, b = (json.load(open(f)) for f in args.compare)
+        print(f"{len(a)} / {len(b)} calls")
+        shown = 0
+        for i, ((na, ta), (nb, tb)) in enumerate(zip(a, b)):
+            if na == "workspace":
+                continue
+            bad = [(x[0], x[1]) for x, y in zip(ta, tb) if x[2] != y[2]]
+            if na != nb or bad:
+                print(f"call {i}: {na} differs in {bad}")
+                shown += 1
+                if shown >= 12:
+                    break
+        if not shown:
+            print("the two processes agree on every call")
+        return
+    if args.zero_empty:
+        _e, _el = torch.empty, torch.empty_like
+        torch.empty = lambda *a, **k: _e(*a, **k).zero_()
+        torch.empty_like = lambda *a, **k: _el(*a, **k).zero_()
     import bench
     import youku_mplug_amd  # noqa: F401
     from youku_mplug_amd import engine as eng, ops
@@ -61,7 +88,9 @@ def main():
     B, T, L = args.batch or geo["batch"], geo["frames"], geo["text_len"]
     S.num_frames = T
     dev = torch.device("cuda", 0)
-    if args.poison > 0:
+    def poison():
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()        # nothing cached but what is poisoned next
         chunks = [torch.empty(int(2 ** 30), dtype=torch.uint8, device=dev) for _ in range(int(args.poison))]
         for c in chunks:
             c.fill_(0xFF)
@@ -80,7 +109,7 @@ def main():
     video = torch.randn(B, 3, T, S.img_size, S.img_size, device=dev).to(torch.bfloat16)
     ids = torch.randint(0, S.vocab, (B, L), device=dev)
     text = types.SimpleNamespace(input_ids=ids, attention_mask=torch.ones(B, L, dtype=torch.long, device=dev))
-    for _ in range(2):                      # lazily created buffers exist, the allocator is warm
+    for _ in range(args.warmup):            # lazily created buffers exist, the allocator is warm
         loss, _ = e(video, text)
         e.backward(loss)
         e.step()
@@ -92,6 +121,8 @@ def main():
     nan_log = []
     for run in range(args.steps):
         e.restore_state(snap)
+        if args.poison > 0:
+            poison()                    # every activation of this step is carved out of NaN-filled memory
         log = []
         orig = {n: getattr(ops, n) for n in names}
 
@@ -124,6 +155,9 @@ def main():
         log.append(("FINAL", [("loss", (), checksum(loss.detach().float().view(1))), ("params", (), checksum(e.flat.params)), ("grads", (), checksum(e.flat.grads))]))
         logs.append(log)
         print(f"run {run}: {len(log)} calls, loss {loss.item():.6f}")
+        if args.dump and run == 0:
+            import json
+            json.dump(log, open(args.dump, "w"))
     if args.poison > 0:
         seen = set()
         print(f"tensors holding NaNs after a call (first occurrence per (entry point, tensor, shape)); {len(nan_log)} in all:")

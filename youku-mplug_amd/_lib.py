@@ -108,7 +108,8 @@ _SIGS = {
     "mpv_logprob_topk_workspace_size": (c_size_t, [c_int64, c_int]),
     "mpv_logprob_topk": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mpv_soft_target_ce": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
-    "mpv_grad_sumsq": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "mpv_grad_sumsq_workspace_size": (c_size_t, []),
+    "mpv_grad_sumsq": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mpv_adamw_step": (c_int, [c_void_p] * 5 + [c_int64] + [c_float] * 5 + [c_int, c_float, c_void_p, c_float, c_void_p]),
     "mpv_adamw_hyper_pack": (c_int, [C.POINTER(c_float), C.POINTER(c_float), c_int, c_float, c_float, c_int, C.POINTER(c_float)]),
     "mpv_adamw_step_grouped_dev": (c_int, [c_void_p] * 5 + [c_int64, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_void_p,

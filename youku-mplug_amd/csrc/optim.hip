@@ -6,6 +6,11 @@
 
 namespace {
 
+// Round 6: the per-workgroup sums go to a partials array and ONE workgroup adds them up in index order (grad_sumsq_final_kernel).  Until
+// round 5 every workgroup added its sum to the scalar with atomicAdd: the order of 2048 floating-point additions then depended on which
+// workgroup arrived first, the norm differed in its last bits from process to process, and whenever the clip was ACTIVE (norm > max_norm)
+// so did the clip coefficient, the update and every later step -- found through config D's final loss, which varied from run to run on one
+// tree (profiles/r06_c8_first_step_across_processes.log: the first entry point whose output differed between processes).
 __global__ __launch_bounds__(256) void grad_sumsq_kernel(const bf16* __restrict__ g, long long n, float* __restrict__ out) {
   __shared__ float red[4];
   float s = 0.f;
@@ -22,7 +27,17 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(const bf16* __restrict_
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];      // out: this launch's partials
+}
+// *sumsq += sum of `nblk` partials (<= 2048), a fixed order: thread t adds partials t, t + 256, ...; wave_sum; four waves in order
+__global__ __launch_bounds__(256) void grad_sumsq_final_kernel(const float* __restrict__ part, int nblk, float* __restrict__ sumsq) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += 256) s += part[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *sumsq += (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(bf16* __restrict__ p16, float* __restrict__ p, float* __restrict__ m,
@@ -188,14 +203,19 @@ extern "C" int mpv_adamw_step_grouped_dev(void* param_bf16, float* master, float
   return mpv_check_launch("mpv_adamw_step_grouped_dev");
 }
 
-extern "C" int mpv_grad_sumsq(const void* grad, int64_t n, float* sumsq, hipStream_t stream) {
+extern "C" size_t mpv_grad_sumsq_workspace_size(void) { return 2048 * sizeof(float); }
+
+extern "C" int mpv_grad_sumsq(const void* grad, int64_t n, float* sumsq, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   MPV_REQUIRE(grad && sumsq, MPV_E_ARG, "mpv_grad_sumsq: null pointer");
   MPV_REQUIRE(n >= 0 && (((uintptr_t)grad) & 15) == 0, MPV_E_ALIGN, "mpv_grad_sumsq: grad must be 16-byte aligned");
+  MPV_REQUIRE(workspace && workspace_bytes >= 2048 * sizeof(float) && (((uintptr_t)workspace) & 3) == 0, MPV_E_ARG,
+              "mpv_grad_sumsq: needs mpv_grad_sumsq_workspace_size() bytes of workspace (the per-workgroup partial sums)");
   if (n == 0) return MPV_OK;
   long long blocks = (n / 8 + 255) / 256;
   if (blocks < 1) blocks = 1;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(grad_sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16*)grad, (long long)n, sumsq);
+  hipLaunchKernelGGL(grad_sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16*)grad, (long long)n, (float*)workspace);
+  hipLaunchKernelGGL(grad_sumsq_final_kernel, dim3(1), dim3(256), 0, stream, (const float*)workspace, (int)blocks, sumsq);
   return mpv_check_launch("mpv_grad_sumsq");
 }
 

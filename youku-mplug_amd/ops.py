@@ -459,7 +459,9 @@ def cross_entropy(logits, labels, weight, rows, vocab, *, ld=None, dlogits=None,
 
 
 def grad_sumsq(grad_flat, sumsq):
-    check(_lib.lib().mpv_grad_sumsq(grad_flat.data_ptr(), grad_flat.numel(), sumsq.data_ptr(), _stream()), "mpv_grad_sumsq")
+    """sumsq += sum g^2, bit-reproducible (include/mpv.h: per-workgroup partials in the workspace, added in a fixed order)"""
+    ws = workspace(_lib.lib().mpv_grad_sumsq_workspace_size(), grad_flat.device)
+    check(_lib.lib().mpv_grad_sumsq(grad_flat.data_ptr(), grad_flat.numel(), sumsq.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "mpv_grad_sumsq")
 
 
 def adamw_step(p16, master, m, v, g16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, sumsq=None, max_norm=0.0):
