@@ -561,13 +561,6 @@ def main():
         use_graph = probe["graph"] <= probe["eager"]       # (the same numbers on every rank: MAX-reduced)
     step_mode = "graph" if use_graph else "eager"
     log("model + engine built" + ("" if self_check is None else f"; graph self-check: {self_check}; mode probe (ms/step, slowest rank): {mode_probe} -> step mode {step_mode}"))
-    # MPV_BENCH_MAIN_PRIORITY=high: measurement knob -- the whole step is enqueued on a high-priority stream instead of the default
-    # stream (the weight-gradient lane stays at normal priority: its workgroups then only take CUs the critical dX chain leaves idle)
-    main_stream = None
-    if os.environ.get("MPV_BENCH_MAIN_PRIORITY", "") == "high" and not _ON_CPU:
-        main_stream = torch.cuda.Stream(device=dev, priority=-1)
-        main_stream.wait_stream(torch.cuda.current_stream())
-        torch.cuda.set_stream(main_stream)
     for i in range(args.warmup):
         loss = step(i)
     _sync()
