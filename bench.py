@@ -512,9 +512,25 @@ def main():
     self_check = None
     use_graph = False
     if mode == "graph" or (mode == "auto" and dist_on):
-        ok, why = engine.graph_self_check(*inputs, before_step=set_lr)
-        self_check = {"passed": bool(ok), "detail": why}
-        use_graph = bool(ok)
+        roomy = True
+        if mode == "auto" and not _ON_CPU:
+            # a captured step keeps a second copy of the step's activations in the graph's private pool: only where that fits easily
+            # (config E at its YAML batch holds 130 GiB of activations: the replay is not even tried there)
+            snap0 = engine.snapshot_state()
+            set_lr(0)
+            l0 = engine(*inputs)
+            engine.backward(l0[0] if isinstance(l0, (tuple, list)) else l0)
+            engine.step()
+            _sync()
+            engine.restore_state(snap0)
+            peak = torch.cuda.max_memory_allocated(dev)
+            roomy = peak < 0.35 * torch.cuda.get_device_properties(dev).total_memory
+            if not roomy:
+                self_check = {"passed": False, "detail": f"not tried: an eager step peaks at {peak / 2**30:.0f} GiB, a captured one would hold as much again"}
+        if roomy:
+            ok, why = engine.graph_self_check(*inputs, before_step=set_lr)
+            self_check = {"passed": bool(ok), "detail": why}
+            use_graph = bool(ok)
 
     def step(i, eager=False, replay=False):
         set_lr(i)

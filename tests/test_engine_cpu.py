@@ -342,6 +342,14 @@ def test_checkpoint_round_trip_deepspeed_layout(monkeypatch):
         e2, _, _, _ = eng.initialize(model=m2, model_parameters=eng.get_parameter_groups(m2, 0.05), config=dict(lr=1e-2))
         path, client = e2.load_checkpoint(d)
         assert client == {"epoch": 3} and path.endswith("checkpoint-3")
+        assert e2.micro_batches_seen == 3
+        # a rank WITHOUT an optimizer-state file of its own (a ZeRO-1 resume at a larger world size: ADVICE r05) still continues the dropout
+        # stream where the checkpoint left it: the position is read from the model-states file, which every rank loads
+        os.remove(os.path.join(d, "checkpoint-3", "mp_rank_00_optim_states.pt"))
+        m3 = _StubModel(seed=11)
+        e3, _, _, _ = eng.initialize(model=m3, model_parameters=eng.get_parameter_groups(m3, 0.05), config=dict(lr=1e-2))
+        e3.load_checkpoint(d)
+        assert e3.micro_batches_seen == 3 and e3.optimizer.step_count == 0 and torch.equal(e3.flat.params, e1.flat.params)
     assert torch.equal(e1.flat.params, e2.flat.params)
     for a, b in ((e1.optimizer.master, e2.optimizer.master), (e1.optimizer.exp_avg, e2.optimizer.exp_avg),
                  (e1.optimizer.exp_avg_sq, e2.optimizer.exp_avg_sq)):
