@@ -112,6 +112,11 @@ class FlatParams:
             if group_of is not None:
                 tiles[o // TILE:(o + n + TILE - 1) // TILE] = group_of[id(p)]
         self.tile_group = tiles.to(self.device)
+        # Fingerprint of the flat LAYOUT (which tensor sits where): the optimizer's fp32 state is one flat buffer in this order, so a
+        # checkpoint's moments only mean anything under the layout they were saved with.  (Round 6 moved three tensors per ViT block
+        # into the stem's stage -- vision.TimeSformer.late_grad_params --: same element count, other order.)
+        import hashlib
+        self.layout = hashlib.sha1(";".join(f"{o}:{n}:{tuple(p.shape)}" for p, o, n in self.slots).encode() + f"|{off}".encode()).hexdigest()[:16]
 
 
 class DPReducer:
@@ -253,7 +258,7 @@ class FlatAdamW:
 
     def state_dict(self):
         return {"master": self.master, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count,
-                "shard": (self.lo, self.hi),
+                "shard": (self.lo, self.hi), "layout": self.flat.layout,
                 "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
 
     def load_state_dict(self, sd):
@@ -729,7 +734,8 @@ class MplugEngine(nn.Module):
         seen_osd = state.pop("micro_batches_seen", None)          # (the model file: the same for every rank)
         if seen_osd is None and osd is not None:                  # checkpoints written before round 6 kept it per optimizer file
             seen_osd = osd.get("micro_batches_seen")
-        usable = osd is not None and osd["master"].numel() == self.optimizer.master.numel() and \
+        # (a state saved under another flat layout -- or before layouts were recorded -- has the right SIZE and the wrong order: unusable)
+        usable = osd is not None and osd.get("layout") == self.flat.layout and osd["master"].numel() == self.optimizer.master.numel() and \
             tuple(osd.get("shard", (0, self.flat.numel))) == (self.optimizer.lo, self.optimizer.hi)
         if self.zero_shards is not None:
             # every rank must take the SAME branch (one rank resuming its Adam moments while another restarts from zero would run
@@ -741,7 +747,7 @@ class MplugEngine(nn.Module):
                       f"{[r for r, f in enumerate(flags) if not f]} (saved at another world size?): ALL ranks restart the optimizer state")
             usable = all(flags)
         elif osd is not None and not usable:
-            print(f"load_checkpoint: optimizer state of {d} does not fit this model's flat buffer (resized embeddings?): fresh optimizer state")
+            print(f"load_checkpoint: optimizer state of {d} does not fit this model's flat buffer (resized embeddings, or saved under another flat layout / before layouts were recorded): fresh optimizer state")
         if usable:
             self.optimizer.load_state_dict(osd)
         else:       # weights only, or a checkpoint of another shape (resized embeddings): fresh optimizer state, as the
