@@ -1,7 +1,7 @@
 #!/bin/bash
-# Closing validation of a tree whose hot kernels are the ones of the last profile set (tools/r03_final.sh): the GPU suite, smoke, the
+# Closing validation of a tree whose hot kernels are the ones of the last profile set (scripts/r03_calls/r03_final.sh): the GPU suite, smoke, the
 # default bench line exactly as the driver runs it (cpu baseline included), the graph-mode bench and the two side configurations.
-# Every command under its own timeout, stdin closed.   Usage (GPU box): bash tools/r03_close.sh <tag>
+# Every command under its own timeout, stdin closed.   Usage (GPU box): bash scripts/r03_calls/r03_close.sh <tag>
 set -u
 TAG=${1:-r03_final5}
 R=$PWD; OUT=$R/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
