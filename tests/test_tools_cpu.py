@@ -130,3 +130,21 @@ def test_bench_clock_power_sampler_without_and_with_a_source():
     r = s.summary()
     assert r["clock_power_source"] == "fake" and r["clock_power_samples"] >= 5
     assert r["sclk_mhz_min"] == 2050.0 and r["power_w_max"] == 1350.0 and r["sclk_mhz"] == 2070.0 and r["power_w"] == 1310.0
+
+
+def test_floor_table_tool_on_the_committed_profiles():
+    """tools/floor_table.py: on the committed in-step GEMM table + kernel trace of the closing set it reproduces the
+    committed floor table -- GEMM floor = executed FLOPs / 1.7 PF (or bytes / 6.3 TB/s where larger), every non-GEMM family priced on its
+    algorithmic bytes, the step floor below north_star's 61 ms."""
+    import re
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join("tools", "floor_table.py"), os.path.join("profiles", "r06_final_gemm_in_step_by_shape.md"),
+                          os.path.join("profiles", "r06_final_kernel_trace.md"), "7"], capture_output=True, text=True, check=True, cwd=ROOT).stdout
+    assert out == open(os.path.join(ROOT, "profiles", "r06_floor_table_final_tree.md")).read()
+    m = re.search(r"Step floor of the present decomposition: ([\d.]+) \(GEMM\) \+ ([\d.]+) \(everything else\) = ([\d.]+) ms", out)
+    g, o, t = (float(x) for x in m.groups())
+    assert abs(g + o - t) < 0.11 and 30 < g < 40 and 10 < o < 15 and t < 61.0
+    fam = re.search(r"\*\*GEMM family\*\* \| \| \| \| \| \| \*\*([\d.]+)\*\* \| \| \| \*\*([\d.]+)\*\*", out)
+    assert float(fam.group(1)) > float(fam.group(2)) > 0
+
