@@ -85,21 +85,27 @@ __global__ void embed_assemble_fwd_kernel(const bf16* __restrict__ patch, const 
 
 // dpos[s] = sum_{b,t} dx[b,t,s] (dcls = the s = 0 row): columns of the flattened [(1+N) * D] row, 8 per thread (16-byte
 // loads), 64 column groups x 4 row lanes per workgroup, the B*T rows looped per lane and folded through LDS.
-__global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const bf16* __restrict__ dx, bf16* __restrict__ dcls, bf16* __restrict__ dpos,
-                                                            int BT, long long C, int D) {
-  __shared__ float red[4][64][8];
+constexpr int EBP_RL = 16;      // row lanes (round 6: 16 waves per workgroup instead of 4 -- 64 dependent-accumulate trips per lane became 16)
+__global__ __launch_bounds__(64 * EBP_RL) void embed_bwd_pos_kernel(const bf16* __restrict__ dx, bf16* __restrict__ dcls, bf16* __restrict__ dpos,
+                                                                    int BT, long long C, int D) {
+  __shared__ float red[EBP_RL][64][8];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const long long c8 = (long long)blockIdx.x * 64 + cl;     // column group
   f32x8 a = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (c8 * 8 < C)
-    for (int r = rl; r < BT; r += 4) a += cvt8(*(const bf16x8*)(dx + (long long)r * C + c8 * 8));
+    for (int r = rl; r < BT; r += EBP_RL) a += cvt8(*(const bf16x8*)(dx + (long long)r * C + c8 * 8));
 #pragma unroll
   for (int e = 0; e < 8; ++e) red[rl][cl][e] = a[e];
   __syncthreads();
   if (rl == 0 && c8 * 8 < C) {
     f32x8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (red[0][cl][e] + red[1][cl][e]) + (red[2][cl][e] + red[3][cl][e]);
+    for (int e = 0; e < 8; ++e) {
+      float t = 0.f;
+#pragma unroll
+      for (int l = 0; l < EBP_RL; ++l) t += red[l][cl][e];
+      o[e] = t;
+    }
     const bf16x8 ob = cvt8(o);
     *(bf16x8*)(dpos + c8 * 8) = ob;
     if (c8 * 8 < D) *(bf16x8*)(dcls + c8 * 8) = ob;
@@ -107,16 +113,19 @@ __global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const bf16* __restri
 }
 // dtemporal[t] = sum_{b,n} dx[b,t,1+n]: one workgroup per (t, 64-column stripe) = 8 column groups x 32 row lanes, every
 // lane looping over its share of the B*N token rows with 16-byte loads (a row's stripe is one 128-byte line); no scratch.
-__global__ __launch_bounds__(256) void embed_bwd_temporal_kernel(const bf16* __restrict__ dx, bf16* __restrict__ dtemporal, int B, int T,
-                                                                 int N, int D) {
-  __shared__ float red[32][8][8];
+// (round 6: 128 row lanes instead of 32 -- the launch is T x D/64 = 96 workgroups on 256 CUs, each walking B*N rows: with 256 threads a
+// lane made 196 dependent-accumulate trips, 82 us for 77 MB; the sum order of a column changes, not its precision)
+constexpr int EBT_RL = 128;
+__global__ __launch_bounds__(8 * EBT_RL) void embed_bwd_temporal_kernel(const bf16* __restrict__ dx, bf16* __restrict__ dtemporal, int B, int T,
+                                                                        int N, int D) {
+  __shared__ float red[EBT_RL][8][8];
   const int t = blockIdx.x;
   const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
   const int c = blockIdx.y * 64 + cg * 8;
   f32x8 a = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (c < D) {
     const int rows = B * N;
-    for (int r = rl; r < rows; r += 32) {
+    for (int r = rl; r < rows; r += EBT_RL) {
       const int b = r / N, n = r - b * N;
       a += cvt8(*(const bf16x8*)(dx + (((long long)b * T + t) * (N + 1) + 1 + n) * D + c));
     }
@@ -127,8 +136,8 @@ __global__ __launch_bounds__(256) void embed_bwd_temporal_kernel(const bf16* __r
   if (threadIdx.x < 64 && blockIdx.y * 64 + (int)threadIdx.x < D) {
     const int g = threadIdx.x >> 3, e = threadIdx.x & 7;
     float o = 0.f;
-#pragma unroll
-    for (int l = 0; l < 32; ++l) o += red[l][g][e];
+#pragma unroll 8
+    for (int l = 0; l < EBT_RL; ++l) o += red[l][g][e];
     dtemporal[(long long)t * D + blockIdx.y * 64 + threadIdx.x] = f2bf(o);
   }
 }
@@ -335,11 +344,15 @@ __global__ void gpt_embed_bwd_full_kernel(const bf16* __restrict__ dh, bf16* __r
 
 // ---------------------------------------------------------------- masked cross-entropy
 // one workgroup per row; two sweeps over the row (second one hits L2): stats, then gradient.
-__global__ __launch_bounds__(256) void cross_entropy_kernel(const bf16* __restrict__ logits, const int64_t* __restrict__ labels,
+// THREADS: 1024 for the LM head's rows (51200 logits: 25 trips of a 256-thread sweep were three latency-bound passes per row, 64 us for the
+// 1024 loss-window rows; round 6), 256 for short rows
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void cross_entropy_kernel(const bf16* __restrict__ logits, const int64_t* __restrict__ labels,
                                                             const float* __restrict__ weight, float* __restrict__ losses,
                                                             float* __restrict__ loss_sum, bf16* dlogits, int vocab,
                                                             long long ld) {
-  __shared__ float red[9];
+  constexpr int NW = THREADS / 64;
+  __shared__ float red[2 * NW + 1];      // [max per wave | sum per wave | target logit]
   const long long r = blockIdx.x;
   const bf16* row = logits + r * ld;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -350,35 +363,39 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const bf16* __restri
   const bool tgt_ok = tgt_raw >= 0 && tgt_raw < (int64_t)vocab;
   const long long tgt = tgt_ok ? (long long)tgt_raw : -1;
   float mx = -INFINITY;
-  for (int c = tid; c < V8; c += 256) {
+  for (int c = tid; c < V8; c += THREADS) {
     const f32x8 v = cvt8(*(const bf16x8*)(row + c * 8));
 #pragma unroll
     for (int e = 0; e < 8; ++e) mx = fmaxf(mx, v[e]);
     // the target logit is captured here, by the thread that owns its chunk: with dlogits aliasing logits the gradient
     // sweep below overwrites the row, so it must not be re-read after that sweep has started anywhere in the workgroup
-    if (tgt_ok && (long long)c == (tgt >> 3)) red[8] = v[(int)(tgt & 7)];
+    if (tgt_ok && (long long)c == (tgt >> 3)) red[2 * NW] = v[(int)(tgt & 7)];
   }
   mx = wave_max(mx);
   if (lane == 0) red[wave] = mx;
   __syncthreads();
-  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  mx = red[0];
+#pragma unroll
+  for (int w2 = 1; w2 < NW; ++w2) mx = fmaxf(mx, red[w2]);
   float sum = 0.f;
-  for (int c = tid; c < V8; c += 256) {
+  for (int c = tid; c < V8; c += THREADS) {
     const f32x8 v = cvt8(*(const bf16x8*)(row + c * 8));
 #pragma unroll
     for (int e = 0; e < 8; ++e) sum += __expf(v[e] - mx);
   }
   sum = wave_sum(sum);
-  if (lane == 0) red[4 + wave] = sum;
+  if (lane == 0) red[NW + wave] = sum;
   __syncthreads();
-  sum = red[4] + red[5] + red[6] + red[7];
+  sum = red[NW];
+#pragma unroll
+  for (int w2 = 1; w2 < NW; ++w2) sum += red[NW + w2];
   const float w = (weight ? weight[r] : 1.0f) * (tgt_ok ? 1.0f : 0.0f);
   const float lse = mx + __logf(sum);
-  if (tid == 0 && losses) losses[r] = tgt_ok ? lse - red[8] : 0.f;
+  if (tid == 0 && losses) losses[r] = tgt_ok ? lse - red[2 * NW] : 0.f;
   if (dlogits) {
     bf16* drow = dlogits + r * ld;
     const float inv = 1.0f / sum;
-    for (int c = tid; c < V8; c += 256) {
+    for (int c = tid; c < V8; c += THREADS) {
       const f32x8 v = cvt8(*(const bf16x8*)(row + c * 8));
       f32x8 g;
 #pragma unroll
@@ -733,9 +750,9 @@ extern "C" int mpv_vit_embed_assemble_bwd(const void* dx, void* dpatch, void* dc
   hipLaunchKernelGGL(copy_rows_kernel, dim3(ew_grid(rows * (D / 4))), dim3(256), 0, stream, (const bf16*)dx, (bf16*)dpatch, rows, D,
                      (long long)D, (long long)D, RowMap{N, N + 1, 1}, RowMap{0, 0, 0});
   const long long C = (long long)(N + 1) * D;
-  hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3((unsigned)((C / 8 + 63) / 64)), dim3(256), 0, stream, (const bf16*)dx, (bf16*)dcls, (bf16*)dpos,
+  hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3((unsigned)((C / 8 + 63) / 64)), dim3(64 * EBP_RL), 0, stream, (const bf16*)dx, (bf16*)dcls, (bf16*)dpos,
                      B * T, C, D);
-  hipLaunchKernelGGL(embed_bwd_temporal_kernel, dim3(T, (D + 63) / 64), dim3(256), 0, stream, (const bf16*)dx, (bf16*)dtemporal, B, T,
+  hipLaunchKernelGGL(embed_bwd_temporal_kernel, dim3(T, (D + 63) / 64), dim3(8 * EBT_RL), 0, stream, (const bf16*)dx, (bf16*)dtemporal, B, T,
                      N, D);
   return mpv_check_launch("mpv_vit_embed_assemble_bwd");
 }
@@ -840,7 +857,9 @@ extern "C" int mpv_cross_entropy(const void* logits, const int64_t* labels, cons
   MPV_REQUIRE(logits && labels, MPV_E_ARG, "mpv_cross_entropy: null pointer");
   MPV_REQUIRE(rows > 0 && vocab > 0 && vocab % 8 == 0 && ld % 8 == 0, MPV_E_SHAPE, "mpv_cross_entropy: vocab/ld must be multiples of 8");
   MPV_REQUIRE(!loss_sum || losses, MPV_E_ARG, "mpv_cross_entropy: loss_sum needs the per-row losses buffer");
-  hipLaunchKernelGGL(cross_entropy_kernel, dim3((unsigned)rows), dim3(256), 0, stream, (const bf16*)logits, labels, weight, losses,
+if (vocab >= 16384)   hipLaunchKernelGGL(cross_entropy_kernel<1024>, dim3((unsigned)rows), dim3(1024), 0, stream, (const bf16*)logits, labels, weight, losses,
+                     loss_sum, (bf16*)dlogits, (int)vocab, (long long)ld);
+  else   hipLaunchKernelGGL(cross_entropy_kernel<256>, dim3((unsigned)rows), dim3(256), 0, stream, (const bf16*)logits, labels, weight, losses,
                      loss_sum, (bf16*)dlogits, (int)vocab, (long long)ld);
   if (loss_sum)
     hipLaunchKernelGGL(weighted_sum_kernel, dim3(1), dim3(256), 0, stream, (const float*)losses, weight, loss_sum, (long long)rows);
