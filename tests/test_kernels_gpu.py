@@ -53,6 +53,29 @@ def test_gemm_wgrad_tn(dev, M, N, K):
     close(out, dy.float().t() @ x.float(), 1e-2, "dW = dY^T X")
 
 
+@pytest.mark.parametrize("M,N,K", [(1536, 768, 50208), (512, 512, 200), (768, 256, 72), (2304, 768, 6304 + 32)])
+def test_gemm_wgrad_ragged_reduction_on_the_256_kernel(dev, M, N, K):
+    """Round 6: the weight-gradient form (both operands reduction-slow) takes a reduction length that is NOT a multiple of the 64-row
+    K-tile on the 256x256 kernel (rows past K read as zeros behind the buffer descriptors) -- the abstractor's K / V weight gradient
+    reduces over B * (1 + T * N) rows (50208 at config B).  Against fp32, against the 128x128 kernel, with the fused bias gradient, and with
+    NaN-filled memory behind both operands (a row past K must never be READ as data)."""
+    from youku_mplug_amd import ops
+    pad = 4096
+    abuf = torch.full((K * M + pad,), float("nan"), dtype=torch.bfloat16, device=dev)
+    bbuf = torch.full((K * N + pad,), float("nan"), dtype=torch.bfloat16, device=dev)
+    a, b = abuf[:K * M].view(K, M), bbuf[:K * N].view(K, N)
+    a.copy_(rn(K, M, dev=dev, seed=5))
+    b.copy_(rn(K, N, dev=dev, seed=6))
+    cs = torch.empty(M, dtype=torch.bfloat16, device=dev)
+    got = ops.gemm(a, b, M, N, K, trans_a=True, trans_b=True, colsum_out=cs)
+    ref = a.float().t() @ b.float()
+    assert torch.isfinite(got.float()).all()
+    close(got, ref, 1e-2, "ragged-K wgrad on the 256x256 kernel")
+    close(cs, a.float().sum(0), 1e-2, "fused bias gradient")
+    small = ops.gemm(a, b, M, N, K, trans_a=True, trans_b=True, tile_hint=128)
+    close(got, small, 1e-2, "256x256 vs 128x128 kernel")
+
+
 def test_gemm_bitwise_deterministic(dev):
     """No races in the LDS-DMA / register pipelines: repeated launches are bit-identical."""
     from youku_mplug_amd import ops

@@ -851,7 +851,7 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
 
   // ---- 256x256 eight-phase kernel (gemm256.hip) for the problems that fill the chip with 256-tiles
   const int variant = (ep && ep->tile_hint) ? ep->tile_hint : gemm_variant();
-  if (variant != 128 && K % 64 == 0 && (M >= 256 || variant == 160 || variant == 192) && N >= 256) {
+  if (variant != 128 && (K % 64 == 0 || (transA && transB && K >= 64 && g.kmap.group == 0)) && (M >= 256 || variant == 160 || variant == 192) && N >= 256) {
     const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
     int s256 = 1;
     if (transA && transB && !g.out_f32) {
@@ -872,9 +872,9 @@ extern "C" int mpv_gemm_bf16(const void* A, const void* B, void* C, int64_t M, i
       h.tile_rows = (variant == 160 || variant == 192 || variant == 256) ? variant : 0;
       h.gm = (ep && ep->gm_hint > 0) ? ep->gm_hint : 0;
       h.splits = s256;
-      h.k_per_split = (int)K;
+      h.k_per_split = (int)((K + 63) / 64 * 64);      // (= K for whole K-tiles; a weight-gradient product may end in a partial one)
       if (s256 > 1) {
-        h.k_per_split = (int)(((K / 64 + s256 - 1) / s256) * 64);
+        h.k_per_split = (int)((((K + 63) / 64 + s256 - 1) / s256) * 64);
         h.splits = (int)((K + h.k_per_split - 1) / h.k_per_split);
       }
       void* user_c256 = C;

@@ -309,7 +309,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 
   const int kbeg = split * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
-  const int nk = (kend - kbeg) / TK;            // launcher guarantees whole K-tiles
+  // whole K-tiles for the k-contiguous forms (launcher); the weight-gradient form (both operands reduction-slow: a K row is a memory row) may
+  // end in a partial tile -- its rows past K lie behind the operands' buffer descriptors and read as zeros (round 6: the abstractor's K / V
+  // weight gradient reduces over B * (1 + T * N) = 50208 rows, not a multiple of 64, and used to fall back to the 128 x 128 kernel)
+  const int nk = (kend - kbeg + TK - 1) / TK;
 
   const i32x4 ra = raw_rsrc(p.A, p.a_bytes);
   const i32x4 rb = raw_rsrc(p.B, p.b_bytes);
@@ -815,7 +818,7 @@ extern "C" int mpv_gemm_plan_bands(int64_t M, int64_t N, int64_t K, int ncu, int
 // mpv_gemm_bf16 (epilogue, maps, byte extents, split-K fields for wgrad: splits / k_per_split / C = fp32 workspace).
 bool mpv_gemm256_try_launch(const GemmArgs& g0, int transA, int transB, hipStream_t stream) {
   GemmArgs g = g0;
-  if (g.K % TK != 0 || g.k_per_split % TK != 0) return false;
+  if ((g.K % TK != 0 && !(transA && transB)) || g.k_per_split % TK != 0) return false;
   if (g.tail_g > 1) return false;
   if (g.bias && ((uintptr_t)g.bias & 15) != 0) return false;      // the bias slice of a tile is fetched by 16-byte LDS-DMA
   g.tiles_n = (g.N + TN - 1) / TN;
