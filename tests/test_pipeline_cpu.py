@@ -380,6 +380,7 @@ def _entry_world2_worker(rank, world, port, d, which, q):
     import json
     import sys
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)        # two ranks on a shared 8-core host: neither may oversubscribe it (a loaded host once ran this test into its timeout)
     from test_engine_cpu import _stub_optimizer_kernels
     import test_entrypoint_gpu as t
     mp_ = _MP()
