@@ -282,12 +282,15 @@ class TimeSformer(nn.Module):
         return {"temporal_embed", "pos_embed", "cls_token"}
 
     def late_grad_params(self):
-        """Parameters whose gradients are complete only at the END of the tower's backward (with the stem), not with their block: the
+        """Parameters whose gradients may only be handed to the reducer at the END of the tower's backward (with the stem), not with their block: the
         composed temporal projection's chain-rule products of all blocks run as one batched launch there (COMPOSE_GROUPED).  The
         engine's bucket layout reads this (engine.default_stages)."""
         if not (COMPOSE_TEMPORAL_OUT and COMPOSE_GROUPED):
             return []
-        return [p for blk in self.blocks for p in (blk.temporal_fc.weight, blk.temporal_attn.proj.weight, blk.temporal_attn.proj.bias)]
+        # temporal_fc.bias too: its gradient d(bc) = colsum d(xt) is complete with its block, but it is an OPERAND of the batched finish
+        # (dWf += d(bc) bp^T, d(bp) = Wf^T d(bc)) -- handed to the reducer with its block it would be the cross-rank SUM by then (an
+        # in-place all-reduce), and the rank-1 terms would count `world` times (found by the two-rank GPU test of round 6)
+        return [p for blk in self.blocks for p in (blk.temporal_fc.weight, blk.temporal_fc.bias, blk.temporal_attn.proj.weight, blk.temporal_attn.proj.bias)]
 
     # ------------------------------------------------------------------ forward
     def forward_features(self, video: torch.Tensor, tape: dict):
