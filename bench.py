@@ -422,6 +422,9 @@ def main():
                          "are timed and the faster one (slowest rank) runs; N = 1 runs eager.  MPV_GRAPH=1 / 0 in the environment mean "
                          "graph / eager when the flag is absent")
     ap.add_argument("--_test-cpu", dest="test_cpu", action="store_true", help=argparse.SUPPRESS)
+    # TEST HOOK (tests/test_entrypoint_gpu.py): N ranks on ONE GPU over gloo on device tensors (RCCL refuses two ranks per device) -- the whole N > 1
+    # flow (self-check, mode probe, fenced timed region, roofline steps on every rank) on real kernels where only 1-GPU boxes exist; the line says TEST
+    ap.add_argument("--_test-one-gpu", dest="test_one_gpu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     global _ON_CPU
     _ON_CPU = bool(args.test_cpu)
@@ -436,6 +439,8 @@ def main():
     if _ON_CPU:
         dev = torch.device("cpu")
     else:
+        if args.test_one_gpu:
+            local = 0
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
     # MPV_BENCH_FORCE_DIST=1 runs the distributed code path (RCCL init, broadcast, barriers, bucketed all-reduce, max-over-ranks
@@ -446,7 +451,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29577")
         with _StdoutToStderr():
             from youku_mplug_amd.engine import init_process_group_for_dp      # RCCL on a high-priority stream (engine.py)
-            if _ON_CPU:
+            if _ON_CPU or args.test_one_gpu:
                 init_process_group_for_dp("gloo", rank=rank, world_size=world)
             else:
                 init_process_group_for_dp("nccl", rank=rank, world_size=world, device_id=dev)
@@ -708,7 +713,8 @@ def main():
                "ms_per_step_hip_events": {"median": round(per_step[len(per_step) // 2], 2), "mean": round(sum(per_step) / len(per_step), 2),
                                           "p10": round(per_step[len(per_step) // 10], 2), "p90": round(per_step[(9 * len(per_step)) // 10], 2)},
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "bf16", "data": "TEST (cpu stand-ins via --_test-cpu: control flow only, not a measurement)" if _ON_CPU else "synthetic",
+               "dtype": "bf16", "data": "TEST (cpu stand-ins via --_test-cpu: control flow only, not a measurement)" if _ON_CPU else
+               "TEST (--_test-one-gpu: every rank on one GPU over gloo, not a measurement)" if args.test_one_gpu else "synthetic",
                "step_mode": step_mode, "host": host,
                "config": {"workload": f"{names[args.config]}, per-GPU bs={B} x {T} frames x 224^2 + {L}-token titles",
                           "global_batch": world * B, "frames": T, "text_len": L, "queries": Shapes.num_queries, "parallelism": f"dp{world}",

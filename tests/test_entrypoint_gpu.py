@@ -461,3 +461,42 @@ def test_bench_contract_line_forced_distributed_path():
     if roof["clock_power_source"] is not None:      # a box whose SMI answers: plausible MI355X figures, sampled during the timed region
         assert roof["clock_power_samples"] >= 1 and 500 < roof["sclk_mhz"] < 3000 and 100 < roof["power_w"] < 2000
     assert 30.0 < rec["ms_per_step"] < 400.0
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py launched as the driver launches it for N = 2 (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, `--gpus 2`), both
+    ranks on this box's one GPU over gloo on device tensors (`--_test-one-gpu`: RCCL refuses two ranks per device; the line is stamped TEST):
+    the N > 1 flow on REAL kernels -- process group, parameter broadcast, the memory guard's eager step, engine.graph_self_check on two ranks
+    (must pass bit for bit), the measured mode choice, fenced timed region with MAX over ranks, roofline steps on every rank, exactly one
+    JSON line from rank 0 and nothing on rank 1's stdout."""
+    import subprocess
+    port = 27000 + os.getpid() % 2000
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.pop("MPV_BENCH_FORCE_DIST", None)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4",
+                                       "--no-cpu-baseline", "--_test-one-gpu"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env,
+                                      stdin=subprocess.DEVNULL))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, o, e))
+    for r, (rc, o, e) in enumerate(outs):
+        assert rc == 0, (r, e[-2500:])
+    assert outs[1][1].strip() == "", outs[1][1][:300]
+    lines = [ln for ln in outs[0][1].splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 8 and rec["config"]["parallelism"] == "dp2" and rec["data"].startswith("TEST")
+    assert rec["host"]["graph_self_check"] == {"passed": True, "detail": "bit-identical"}, rec["host"]
+    assert set(rec["host"]["mode_probe_ms_per_step"]) == {"graph", "eager"} and rec["step_mode"] in ("graph", "eager")
+    assert rec["value"] == pytest.approx(8 * 3 / (rec["ms_per_step"] * 3e-3), rel=1e-3)
+    assert rec["roofline"] is not None and rec["roofline"]["launches_per_step"] > 0 and rec["cpu_baseline"] is None
+    assert math.isfinite(rec["config"]["final_loss"])
+
