@@ -204,7 +204,7 @@ _COMPOSE_ON_LANE = os.environ.get("MPV_VIT_COMPOSE_LANE", "1") != "0"    # measu
 # Round 6: the [D, D] chain-rule products of the composed projection depend on parameters and per-block reduced gradients only, so all
 # blocks' worth goes out in ONE launch per kind (mpv_gemm_bf16_batched, mpv_vit_compose_bias_batched, ..._finish_batched): Wc / bc at the
 # head of the step, dWf / dWp / d(bp) at the end of the tower's backward -- 5 launches per step instead of 60 (36 of them 768^3 products of
-# 36 workgroups at 42-50 TFLOP/s).  The three gradients then complete with the stem, not with their block (late_grad_params: the engine
+# 36 workgroups at 42-50 TFLOP/s).  Those gradients (and temporal_fc.bias, an operand of the finish) go out with the stem, not with their block (late_grad_params: the engine
 # puts them into the stem's bucket).  MPV_VIT_COMPOSE_GROUP=0: measurement knob, the per-block launches of rounds 3-5.
 COMPOSE_GROUPED = os.environ.get("MPV_VIT_COMPOSE_GROUP", "1") != "0"      # (only read where COMPOSE_TEMPORAL_OUT is on)
 # Round 6: the spatial attention's `q * scale` (a second bf16 rounding, models/vision_transformer.py:179) is applied by the qkv product's
