@@ -510,3 +510,84 @@ def test_bench_two_ranks_on_one_gpu():
     assert rec["roofline"] is not None and rec["roofline"]["launches_per_step"] > 0 and rec["cpu_baseline"] is None
     assert math.isfinite(rec["config"]["final_loss"])
 
+
+def _entry_two_rank_gpu_worker(rank, world, port, d, graph, zero, q):
+    import traceback
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                          MPV_GRAPH="1" if graph else "0")
+        sys.path.insert(0, ROOT)
+        import youku_mplug_amd  # noqa: F401
+        from youku_mplug_amd import engine as eng
+        orig_pg = eng.init_process_group_for_dp
+        eng.init_process_group_for_dp = lambda backend=None, **kw: orig_pg("gloo", **kw)      # RCCL refuses two ranks on one device
+        seen = {}
+        orig_init = eng.initialize
+
+        def spy(**kw):
+            r = orig_init(**kw)
+            seen["engine"] = r[0]
+            return r
+        eng.initialize = spy
+        import run_pretrain_distributed_gpt3 as entry
+        entry.mpv_engine.initialize = spy
+        entry.mpv_engine.init_process_group_for_dp = eng.init_process_group_for_dp
+        logs = []
+        out = os.path.join(d, f"out_g{int(graph)}_z{zero}")
+        args, config = entry.get_args(["--config", os.path.join(d, "pretrain.yaml"), "--output_dir", out, "--bf16", "--enable_deepspeed",
+                                       "--synthetic_steps", "3", "--seed", "7", "--zero_stage", str(zero)])
+        stats = entry.main(args, config)
+        e = seen["engine"]
+        torch.cuda.synchronize()
+        q.put((rank, e.flat.params.float().cpu().numpy(), e.zero_shards, {k: v for k, v in stats.items() if isinstance(v, (int, float))},
+               bool(getattr(e, "_graph_dp_ok", False)), sorted(os.listdir(os.path.join(out, "checkpoint-1")))))
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, "ERROR", traceback.format_exc()))
+        raise
+
+
+@pytest.mark.parametrize("graph,zero", [(False, 1), (True, 0)])
+def test_entrypoint_two_ranks_on_one_gpu(tmp_path, graph, zero):
+    """run_pretrain_distributed_gpt3.py as TWO ranks on real kernels (both on this box's GPU; the test worker swaps the communicator's backend
+    for gloo, nothing in the product changes): (False, 1) the command line's default ZeRO stage 1 -- ranks end with identical parameters, one
+    zero_pp_rank_<r> optimizer file each; (True, 0) MPV_GRAPH=1 -- the segmented replay is used only after engine.graph_self_check has passed on
+    both ranks, and the run ends with identical parameters on both."""
+    import torch.multiprocessing as mp
+    d = str(tmp_path)
+    _write_configs(d)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 41000 + os.getpid() % 2000 + (3 if graph else 0)
+    procs = [ctx.Process(target=_entry_two_rank_gpu_worker, args=(r, 2, port, d, graph, zero, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(200):
+        try:
+            r = q.get(timeout=2)
+            res[r[0]] = r[1:]
+        except Exception:
+            if any(p.exitcode not in (None, 0) for p in procs):
+                break
+        if len(res) == 2:
+            break
+    for p in procs:
+        p.join(timeout=120 if len(res) == 2 else 5)
+        if p.is_alive():
+            p.kill()
+    assert len(res) == 2 and not any(isinstance(v[0], str) for v in res.values()), res
+    import numpy as np
+    assert np.array_equal(res[0][0], res[1][0]), "ranks must end with identical parameters"
+    assert np.isfinite(res[0][0]).all() and abs(res[0][0]).sum() > 0
+    files = res[0][4]
+    if zero == 1:
+        assert res[0][1] is not None and len(res[0][1]) == 2
+        assert files == ["mp_rank_00_model_states.pt", "zero_pp_rank_0_mp_rank_00_optim_states.pt", "zero_pp_rank_1_mp_rank_00_optim_states.pt"], files
+    else:
+        assert files == ["mp_rank_00_model_states.pt", "mp_rank_00_optim_states.pt"], files
+    if graph:
+        assert res[0][3] and res[1][3], "MPV_GRAPH=1 on two ranks: the start-up self-check must have passed on both"
+
