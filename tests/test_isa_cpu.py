@@ -136,6 +136,24 @@ def test_persistent_attention_kernels_never_touch_scratch(kernels):
         assert len(re.findall(r"s_waitcnt vmcnt\(", loop)) <= 2, (n, re.findall(r"s_waitcnt vmcnt\(\d+\)", loop))
 
 
+def test_vit_attention_forward_instruction_budget(kernels):
+    """attn_fwd_pres_kernel<96, 7, ..., LEAN> is bound by its instruction count (NOTEBOOK section 12 item 8): pin it.  Per work item and wave: 81
+    MFMAs (7 x 6 score + 13 x 3 value products), exactly 100 exponentials (6 tiles x 16 + 4 of the 5-key tile), <= 100 packed bf16 conversions, and a
+    static VALU count that must not creep (856 when round 6 moved `q * scale` into the qkv product's epilogue -- at run time that branch is
+    skipped: 11.9 M VALU instructions per launch against 13.3 M, profiles/r06_final_sq_insts_attention_gemm.txt)."""
+    ks, _ = kernels
+    name = next(n for n in ks if "attn_fwd_pres_kernelILi96ELi7ELi8ELi512ELi1ELb1E" in n)
+    dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--disassemble-symbols=" + name, ks[name]["file"]], capture_output=True, text=True).stdout
+    body = dis[:dis.index("s_endpgm")]
+    ops = re.findall(r"^\s+[0-9a-f]*\s*(v_\w+)", body, flags=re.M) or re.findall(r"\b(v_\w+)", body)
+    mfma = sum(o.startswith("v_mfma") for o in ops)
+    valu = len(ops) - mfma
+    assert mfma == 81, mfma
+    assert sum(o.startswith("v_exp_f32") for o in ops) == 100
+    assert sum(o.startswith("v_cvt_pk_bf16_f32") for o in ops) <= 100
+    assert valu <= 900, valu
+
+
 def test_layernorm_backward_keeps_its_prefetch_in_flight(kernels):
     """ln_bwd8_kernel<2, true, PF>: the next row of a wave is requested before the current one is reduced.  That only works if the
     compiler waits for the CURRENT row with a counted s_waitcnt -- which it can only do when every request of a row is branch-free
